@@ -1,0 +1,13 @@
+"""chalametpir_amd -- MI355X-native server hot path for ChalametPIR (reference itzmeanjan/ChalametPIR v0.7.0).
+
+Public surface mirrors the reference's server crate (chalametpir_server/src/lib.rs:80-81): `Server`, `ChalametPIRError`,
+`SEED_BYTE_LEN`.  All compute runs in libchalamet_hip.so (hand-written HIP kernels for gfx950, include/chalamet_hip.h);
+importing this package never falls back to a CPU implementation.
+"""
+from .errors import ChalametPIRError
+from .params import LWE_DIMENSION, SEED_BYTE_LEN
+from .server import (Device, Server, dtc_layout_for, encode_kv_database, encoded_num_cols, filter_shape,
+                     find_encoded_db_matrix_element_bit_length, generate_from_seed, tuning_set)
+
+__all__ = ["Server", "Device", "ChalametPIRError", "SEED_BYTE_LEN", "LWE_DIMENSION", "dtc_layout_for", "encode_kv_database", "encoded_num_cols",
+           "filter_shape", "find_encoded_db_matrix_element_bit_length", "generate_from_seed", "tuning_set"]

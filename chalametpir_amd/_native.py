@@ -1,0 +1,130 @@
+"""ctypes binding of libchalamet_hip.so (the C ABI declared in include/chalamet_hip.h).
+
+The library is built in-tree by `make -C chalametpir_amd/csrc` (see __graft_entry__.build()).  There is no CPU
+fallback anywhere in this package: if the shared library is missing, `load()` raises, and if no HIP device is
+usable every compute entry point returns CPIR_ERR_NO_DEVICE / CPIR_ERR_HIP, surfaced as ChalametPIRError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libchalamet_hip.so")
+CSRC_DIR = os.path.join(_PKG, "csrc")
+HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "chalamet_hip.h")
+
+LWE_DIMENSION = 1774
+SEED_BYTE_LEN = 32
+FILTER_PARAM_BYTE_LEN = 68
+
+u8p = C.POINTER(C.c_uint8)
+u32p = C.c_void_p  # device or host u32 pointers are passed as raw addresses
+vp = C.c_void_p
+
+
+class DtcLayout(C.Structure):
+    """cpir_dtc_layout"""
+
+    _fields_ = [
+        ("num_slots", C.c_uint64),
+        ("num_cols", C.c_uint32),
+        ("mat_elem_bit_len", C.c_uint32),
+        ("compression_factor", C.c_uint32),
+        ("words_per_row", C.c_uint64),
+        ("words_per_row_padded", C.c_uint64),
+        ("rows_padded", C.c_uint32),
+        ("total_words", C.c_uint64),
+    ]
+
+
+class KvDb(C.Structure):
+    """cpir_kv_db"""
+
+    _fields_ = [
+        ("num_pairs", C.c_uint64),
+        ("keys", C.c_void_p),
+        ("key_off", C.c_void_p),
+        ("values", C.c_void_p),
+        ("val_off", C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/chalamet_hip.h declares appears here
+SIGNATURES = {
+    "cpir_strerror": (C.c_char_p, [C.c_int]),
+    "cpir_last_hip_error": (C.c_char_p, []),
+    "cpir_version": (C.c_char_p, []),
+    "cpir_tuning_set": (C.c_int, [C.c_char_p, C.c_int]),
+    "cpir_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "cpir_device_open": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "cpir_device_close": (None, [vp]),
+    "cpir_device_ordinal": (C.c_int, [vp, C.POINTER(C.c_int)]),
+    "cpir_device_synchronize": (C.c_int, [vp]),
+    "cpir_compression_factor": (C.c_uint32, [C.c_uint32]),
+    "cpir_find_encoded_db_matrix_element_bit_length": (C.c_int, [C.c_uint64, C.POINTER(C.c_uint32)]),
+    "cpir_filter_shape": (C.c_int, [C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    "cpir_encoded_num_cols": (C.c_uint64, [C.c_uint64, C.c_uint32]),
+    "cpir_generate_from_seed": (C.c_int, [C.c_uint64, C.c_uint64, u8p, vp]),
+    "cpir_op_mat_x_mat": (C.c_int, [vp, u32p, C.c_uint64, u32p, C.c_uint64, u32p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
+                                    C.c_uint32, C.c_int, vp]),
+    "cpir_dtc_layout_for": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(DtcLayout)]),
+    "cpir_op_transpose_compress": (C.c_int, [vp, u32p, C.c_uint64, C.POINTER(DtcLayout), u32p, u32p, vp]),
+    "cpir_op_dtc_import": (C.c_int, [vp, u32p, C.POINTER(DtcLayout), u32p, vp]),
+    "cpir_op_dtc_export": (C.c_int, [vp, u32p, C.POINTER(DtcLayout), u32p, vp]),
+    "cpir_respond_scratch_words": (C.c_uint64, [C.POINTER(DtcLayout)]),
+    "cpir_op_respond": (C.c_int, [vp, u32p, C.POINTER(DtcLayout), u32p, C.c_uint64, C.c_uint64, u32p, u32p, vp]),
+    "cpir_respond_batch_scratch_words": (C.c_uint64, [C.POINTER(DtcLayout), C.c_uint32]),
+    "cpir_op_respond_batch": (C.c_int, [vp, u32p, C.POINTER(DtcLayout), u32p, C.c_uint64, C.c_uint64, C.c_uint32, u32p, u32p, vp]),
+    "cpir_op_synth_fill": (C.c_int, [vp, u32p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, vp]),
+    "cpir_respond_kernel_name": (C.c_char_p, [C.POINTER(DtcLayout)]),
+    "cpir_server_setup": (C.c_int, [vp, u8p, u32p, u32p, C.c_uint64, C.c_uint32, C.c_uint32, u32p, C.POINTER(vp)]),
+    "cpir_server_setup_kv": (C.c_int, [vp, C.c_uint32, u8p, C.POINTER(KvDb), u8p, C.c_uint32, vp, C.c_size_t, C.POINTER(C.c_size_t),
+                                       u8p, C.POINTER(vp)]),
+    "cpir_encode_kv_database": (C.c_int, [C.c_uint32, C.POINTER(KvDb), C.c_uint32, u8p, C.c_uint32, u8p, vp, C.c_uint64,
+                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    "cpir_setup_kv_shape": (C.c_int, [C.c_uint32, C.POINTER(KvDb), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
+                                      C.POINTER(C.c_uint32), C.POINTER(C.c_size_t)]),
+    "cpir_server_from_device_matrix": (C.c_int, [vp, u32p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp,
+                                                 C.POINTER(vp)]),
+    "cpir_server_from_compressed": (C.c_int, [vp, u32p, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(vp)]),
+    "cpir_server_export_compressed": (C.c_int, [vp, u32p, C.c_uint64]),
+    "cpir_server_retain": (vp, [vp]),
+    "cpir_server_release": (None, [vp]),
+    "cpir_server_layout": (C.c_int, [vp, C.POINTER(DtcLayout)]),
+    "cpir_server_shard": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "cpir_server_dtc_device_ptr": (vp, [vp]),
+    "cpir_server_respond_bytes": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "cpir_server_respond": (C.c_int, [vp, u32p, C.c_uint32, C.c_uint64, u32p]),
+    "cpir_server_respond_device": (C.c_int, [vp, u32p, u32p, u32p, vp]),
+    "cpir_server_respond_batch_device": (C.c_int, [vp, u32p, C.c_uint32, u32p, u32p, vp]),
+}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-C", CSRC_DIR, "clean"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", CSRC_DIR, "-j8", "-s"], check=True)
+    return LIB_PATH
+
+
+def load():
+    """dlopen libchalamet_hip.so and type every entry point.  Raises if the library is not built: fail loudly."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make -C {CSRC_DIR}` (or __graft_entry__.build()). "
+                "chalametpir_amd has no CPU fallback."
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib

@@ -1,0 +1,703 @@
+// capi.hip -- the extern "C" boundary of libchalamet_hip.so (include/chalamet_hip.h): device context, the device-resident
+// Server handle, and the host-side orchestration of Server::setup / Server::respond
+// (reference chalametpir_server/src/server.rs:47-78, 103-167, 184-190).
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <thread>
+
+#include "cpir_internal.hpp"
+
+namespace cpir {
+
+// ---------------------------------------------------------------------------------------------------------------
+// error text
+// ---------------------------------------------------------------------------------------------------------------
+static thread_local char t_last_hip_error[512] = "";
+
+void set_last_hip_error(hipError_t e, const char* what, const char* file, int line) {
+  snprintf(t_last_hip_error, sizeof(t_last_hip_error), "%s (%d) from `%s` at %s:%d", hipGetErrorString(e), (int)e, what, file, line);
+  (void)hipGetLastError();  // clear the sticky per-thread error so later calls report their own failures
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Server handle
+// ---------------------------------------------------------------------------------------------------------------
+struct RespondSlot {
+  hipStream_t stream = nullptr;
+  uint32_t* q_dev = nullptr;   // total_slots u32
+  uint32_t* r_dev = nullptr;   // C u32
+  uint32_t* q_pinned = nullptr;
+  uint32_t* r_pinned = nullptr;
+  bool busy = false;
+};
+
+struct Server {
+  std::atomic<int> refs{1};
+  Device* dev = nullptr;
+  cpir_dtc_layout layout{};
+  uint32_t* dtc = nullptr;  // device, layout.total_words u32
+  uint64_t slot_offset = 0;
+  uint64_t total_slots = 0;
+
+  // pool of per-call resources so respond(&self) is re-entrant (reference: Arc<Server> shared by many tokio tasks)
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<std::unique_ptr<RespondSlot>> slots;
+  static constexpr size_t kMaxSlots = 8;
+};
+
+static void device_retain(Device* d) { d->refs.fetch_add(1); }
+static void device_release(Device* d) {
+  if (d && d->refs.fetch_sub(1) == 1) {
+    DeviceGuard g(d->ordinal);
+    if (d->stream) (void)hipStreamDestroy(d->stream);
+    delete d;
+  }
+}
+
+static void slot_destroy(RespondSlot* s) {
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  if (s->q_dev) (void)hipFree(s->q_dev);
+  if (s->r_dev) (void)hipFree(s->r_dev);
+  if (s->q_pinned) (void)hipHostFree(s->q_pinned);
+  if (s->r_pinned) (void)hipHostFree(s->r_pinned);
+}
+
+static int slot_create(const Server* srv, std::unique_ptr<RespondSlot>* out) {
+  std::unique_ptr<RespondSlot> s(new RespondSlot);
+  auto fail = [&](int st) { slot_destroy(s.get()); return st; };
+  const size_t qb = (size_t)srv->total_slots * 4, rb = (size_t)srv->layout.num_cols * 4;
+#define TRY_(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_last_hip_error(_e, #e, __FILE__, __LINE__); \
+    return fail(_e == hipErrorOutOfMemory ? CPIR_ERR_OUT_OF_DEVICE_MEMORY : CPIR_ERR_HIP); } } while (0)
+  TRY_(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  TRY_(hipMalloc(&s->q_dev, qb));
+  TRY_(hipMalloc(&s->r_dev, rb));
+  TRY_(hipHostMalloc(&s->q_pinned, qb, hipHostMallocDefault));
+  TRY_(hipHostMalloc(&s->r_pinned, rb, hipHostMallocDefault));
+#undef TRY_
+  *out = std::move(s);
+  return CPIR_OK;
+}
+
+// borrow a slot (creating up to kMaxSlots, then waiting for a free one)
+static int slot_acquire(Server* srv, RespondSlot** out) {
+  std::unique_lock<std::mutex> lk(srv->mu);
+  for (;;) {
+    for (auto& s : srv->slots)
+      if (!s->busy) {
+        s->busy = true;
+        *out = s.get();
+        return CPIR_OK;
+      }
+    if (srv->slots.size() < Server::kMaxSlots) {
+      std::unique_ptr<RespondSlot> s;
+      const int st = slot_create(srv, &s);
+      if (st != CPIR_OK) {
+        if (srv->slots.empty()) return st;  // nothing to wait for
+      } else {
+        s->busy = true;
+        *out = s.get();
+        srv->slots.push_back(std::move(s));
+        return CPIR_OK;
+      }
+    }
+    srv->cv.wait(lk);
+  }
+}
+
+static void slot_release(Server* srv, RespondSlot* s) {
+  {
+    std::lock_guard<std::mutex> lk(srv->mu);
+    s->busy = false;
+  }
+  srv->cv.notify_one();
+}
+
+static void server_destroy(Server* srv) {
+  if (!srv) return;
+  {
+    DeviceGuard g(srv->dev->ordinal);
+    for (auto& s : srv->slots) slot_destroy(s.get());
+    srv->slots.clear();
+    if (srv->dtc) (void)hipFree(srv->dtc);
+  }
+  device_release(srv->dev);
+  delete srv;
+}
+
+static Server* server_new(Device* dev, const cpir_dtc_layout& L, uint64_t slot_offset, uint64_t total_slots) {
+  Server* s = new Server;
+  s->dev = dev;
+  device_retain(dev);
+  s->layout = L;
+  s->slot_offset = slot_offset;
+  s->total_slots = total_slots;
+  return s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// setup orchestration
+// ---------------------------------------------------------------------------------------------------------------
+// Expands the public matrix A (1774 x N) on a host thread -- TurboSHAKE128 squeezed row block by row block into two
+// pinned staging buffers -- and streams it into HBM on its own copy stream while the caller encodes / uploads / packs D.
+// A stays resident (8.4 GB at 2^20 keys, 33 GB at 2^22: sized for 288 GB of HBM) so the hint is ONE matmul launch.
+class PublicMatrixUpload {
+ public:
+  PublicMatrixUpload(Device* dev, uint64_t N) : dev_(dev), N_(N) {}
+  ~PublicMatrixUpload() {
+    join();
+    DeviceGuard g(dev_->ordinal);
+    for (int i = 0; i < 2; i++) {
+      if (pinned_[i]) (void)hipHostFree(pinned_[i]);
+      if (ev_[i]) (void)hipEventDestroy(ev_[i]);
+    }
+    if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
+    if (A_dev_) (void)hipFree(A_dev_);
+  }
+
+  int start(const uint8_t seed[32], const uint32_t* A_host) {
+    DeviceGuard g(dev_->ordinal);
+    const uint64_t rows = CPIR_LWE_DIMENSION;
+    CPIR_HIP_TRY(hipMalloc(&A_dev_, (size_t)rows * N_ * 4));
+    CPIR_HIP_TRY(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+    if (A_host) {  // caller supplied A: plain upload, no XOF
+      CPIR_HIP_TRY(hipMemcpyAsync(A_dev_, A_host, (size_t)rows * N_ * 4, hipMemcpyHostToDevice, copy_stream_));
+      return CPIR_OK;
+    }
+    // ~64 MiB staging blocks, whole rows
+    rows_per_block_ = (uint64_t)(64ull << 20) / (N_ * 4);
+    if (rows_per_block_ < 1) rows_per_block_ = 1;
+    if (rows_per_block_ > rows) rows_per_block_ = rows;
+    for (int i = 0; i < 2; i++) {
+      CPIR_HIP_TRY(hipHostMalloc(&pinned_[i], (size_t)rows_per_block_ * N_ * 4, hipHostMallocDefault));
+      CPIR_HIP_TRY(hipEventCreateWithFlags(&ev_[i], hipEventDisableTiming));
+    }
+    memcpy(seed_, seed, 32);
+    worker_ = std::thread([this] { status_ = run(); });
+    return CPIR_OK;
+  }
+
+  // wait until all of A is in HBM
+  int finish(const uint32_t** A_dev) {
+    join();
+    if (status_ != CPIR_OK) return status_;
+    DeviceGuard g(dev_->ordinal);
+    CPIR_HIP_TRY(hipStreamSynchronize(copy_stream_));
+    *A_dev = A_dev_;
+    return CPIR_OK;
+  }
+
+ private:
+  void join() {
+    if (worker_.joinable()) worker_.join();
+  }
+  int run() {
+    DeviceGuard g(dev_->ordinal);
+    TurboShake128 xof;  // matrix.rs:542-544
+    xof.absorb(seed_, 32);
+    xof.finalize(0x1F);
+    const uint64_t rows = CPIR_LWE_DIMENSION;
+    int buf = 0;
+    bool used[2] = {false, false};
+    for (uint64_t r0 = 0; r0 < rows; r0 += rows_per_block_, buf ^= 1) {
+      const uint64_t rb = (rows - r0 < rows_per_block_) ? rows - r0 : rows_per_block_;
+      if (used[buf]) CPIR_HIP_TRY(hipEventSynchronize(ev_[buf]));  // staging buffer free again?
+      xof.squeeze(reinterpret_cast<uint8_t*>(pinned_[buf]), (size_t)rb * N_ * 4);  // matrix.rs:546-555: row-major LE u32
+      CPIR_HIP_TRY(hipMemcpyAsync(A_dev_ + r0 * N_, pinned_[buf], (size_t)rb * N_ * 4, hipMemcpyHostToDevice, copy_stream_));
+      CPIR_HIP_TRY(hipEventRecord(ev_[buf], copy_stream_));
+      used[buf] = true;
+    }
+    return CPIR_OK;
+  }
+
+  Device* dev_;
+  uint64_t N_;
+  uint32_t* A_dev_ = nullptr;
+  uint32_t* pinned_[2] = {nullptr, nullptr};
+  hipEvent_t ev_[2] = {nullptr, nullptr};
+  hipStream_t copy_stream_ = nullptr;
+  uint64_t rows_per_block_ = 0;
+  uint8_t seed_[32];
+  std::thread worker_;
+  int status_ = CPIR_OK;
+};
+
+struct DevBuf {  // scoped device allocation
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+};
+
+// The matrix half of setup once D sits on the host: upload D, pack it, wait for A, one matmul, hint back.
+static int setup_from_host_matrix(Device* dev, PublicMatrixUpload& upA, const uint32_t* D, uint64_t N, uint32_t C, uint32_t b,
+                                  uint32_t* hint_out, Server** out) {
+  cpir_dtc_layout L;
+  CPIR_TRY(dtc_layout_for(N, C, b, &L));
+  DeviceGuard g(dev->ordinal);
+  hipStream_t stream = dev->stream;
+  DevBuf D_dev, flag, M_dev;
+  CPIR_HIP_TRY(hipMalloc(&D_dev.p, (size_t)N * C * 4));
+  CPIR_HIP_TRY(hipMalloc(&flag.p, 4));
+  CPIR_HIP_TRY(hipMalloc(&M_dev.p, (size_t)CPIR_LWE_DIMENSION * C * 4));
+  Server* srv = server_new(dev, L, 0, N);
+  auto fail = [&](int st) { server_destroy(srv); return st; };
+#define TRY_(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_last_hip_error(_e, #e, __FILE__, __LINE__); \
+    return fail(_e == hipErrorOutOfMemory ? CPIR_ERR_OUT_OF_DEVICE_MEMORY : CPIR_ERR_HIP); } } while (0)
+  TRY_(hipMalloc(&srv->dtc, (size_t)L.total_words * 4));
+  TRY_(hipMemcpyAsync(D_dev.p, D, (size_t)N * C * 4, hipMemcpyHostToDevice, stream));
+  TRY_(hipMemsetAsync(flag.p, 0, 4, stream));
+  int st = launch_transpose_compress(dev, (const uint32_t*)D_dev.p, C, L, srv->dtc, (uint32_t*)flag.p, stream);
+  if (st != CPIR_OK) return fail(st);
+  uint32_t ored = 0;
+  TRY_(hipMemcpyAsync(&ored, flag.p, 4, hipMemcpyDeviceToHost, stream));
+  TRY_(hipStreamSynchronize(stream));
+  // the hint uses the UNMASKED entries of D (server.rs:61 multiplies before any masking); the packed-16 kernel is
+  // exact only if every entry is < 2^16, which holds for every encoded DB (entries < 2^b <= 2^14) and is verified here
+  const uint32_t rhs_bits = (ored >> 16) ? 32u : 16u;
+  const uint32_t* A_dev = nullptr;
+  st = upA.finish(&A_dev);
+  if (st != CPIR_OK) return fail(st);
+  st = launch_mat_x_mat(dev, A_dev, N, (const uint32_t*)D_dev.p, C, (uint32_t*)M_dev.p, C, CPIR_LWE_DIMENSION, N, C, rhs_bits, 0, stream);
+  if (st != CPIR_OK) return fail(st);
+  TRY_(hipMemcpyAsync(hint_out, M_dev.p, (size_t)CPIR_LWE_DIMENSION * C * 4, hipMemcpyDeviceToHost, stream));
+  TRY_(hipStreamSynchronize(stream));
+#undef TRY_
+  *out = srv;
+  return CPIR_OK;
+}
+
+static bool has_device(int* count) {
+  int n = 0;
+  const hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    set_last_hip_error(e, "hipGetDeviceCount", __FILE__, __LINE__);
+    n = 0;
+  }
+  if (count) *count = n;
+  return n > 0;
+}
+
+}  // namespace cpir
+
+using namespace cpir;
+
+struct cpir_device : Device {};
+struct cpir_server : Server {};
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------------------------
+// misc
+// ---------------------------------------------------------------------------------------------------------------
+const char* cpir_strerror(int status) {
+  switch (status) {  // texts follow the Display impl of ChalametPIRError (reference chalametpir_common/src/error.rs:51-100)
+    case CPIR_OK: return "ok";
+    case CPIR_ERR_INVALID_MATRIX_DIMENSION: return "The number of rows and columns in the matrix must be non-zero.";
+    case CPIR_ERR_INCOMPATIBLE_DIM_MATMUL: return "The matrix dimensions do not allow multiplication.";
+    case CPIR_ERR_INVALID_NUMBER_OF_ELEMENTS: return "The matrix must have \"rows * columns\" elements.";
+    case CPIR_ERR_INCOMPATIBLE_DIM_ROWVEC_X_TRANSPOSED:
+      return "The dimensions are incompatible for multiplication of a row vector and a transposed matrix.";
+    case CPIR_ERR_FAILED_TO_DESERIALIZE_MATRIX: return "Matrix deserialization failed";
+    case CPIR_ERR_EMPTY_KV_DATABASE: return "Cannot encode empty key-value database.";
+    case CPIR_ERR_EXHAUSTED_ATTEMPTS_3WISE: return "Exhausted all attempts to build 3-wise XOR binary fuse filter.";
+    case CPIR_ERR_EXHAUSTED_ATTEMPTS_4WISE: return "Exhausted all attempts to build 4-wise XOR binary fuse filter.";
+    case CPIR_ERR_KV_DATABASE_SIZE_TOO_LARGE: return "The key-value database is too large; it can have a maximum of 2^42 entries.";
+    case CPIR_ERR_UNSUPPORTED_ARITY: return "Binary Fuse Filter supports arity of either 3 or 4.";
+    case CPIR_ERR_IMPOSSIBLE_ELEMENT_BIT_LENGTH: return "Encoded database matrix's element bit length mustn't ever exceed 16.";
+    case CPIR_ERR_NO_DEVICE: return "No usable HIP device (there is no CPU fallback).";
+    case CPIR_ERR_HIP: return "A HIP runtime call failed; see cpir_last_hip_error().";
+    case CPIR_ERR_OUT_OF_DEVICE_MEMORY: return "Failed to allocate device or pinned host memory.";
+    case CPIR_ERR_BUFFER_TOO_SMALL: return "Caller-provided output buffer is too small.";
+    case CPIR_ERR_INVALID_ARGUMENT: return "Invalid argument.";
+    case CPIR_ERR_SHARD_RANGE: return "Shard boundaries are not aligned to the packing unit or exceed the query length.";
+    default: return "unknown status";
+  }
+}
+
+const char* cpir_last_hip_error(void) { return t_last_hip_error; }
+const char* cpir_version(void) { return "chalamet_hip 0.1.0 (gfx950)"; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// device
+// ---------------------------------------------------------------------------------------------------------------
+int cpir_device_count(int* count) {
+  if (!count) return CPIR_ERR_INVALID_ARGUMENT;
+  return has_device(count) ? CPIR_OK : CPIR_ERR_NO_DEVICE;
+}
+
+int cpir_device_open(int ordinal, cpir_device** out) {
+  if (!out) return CPIR_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int n = 0;
+  if (!has_device(&n)) return CPIR_ERR_NO_DEVICE;
+  if (ordinal < 0 || ordinal >= n) return CPIR_ERR_NO_DEVICE;
+  DeviceGuard g(ordinal);
+  if (!g.ok) return CPIR_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  CPIR_HIP_TRY(hipGetDeviceProperties(&prop, ordinal));
+  cpir_device* d = new cpir_device;
+  d->ordinal = ordinal;
+  d->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+  const hipError_t e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    set_last_hip_error(e, "hipStreamCreateWithFlags", __FILE__, __LINE__);
+    delete d;
+    return CPIR_ERR_HIP;
+  }
+  *out = d;
+  return CPIR_OK;
+}
+
+void cpir_device_close(cpir_device* dev) { device_release(dev); }
+
+int cpir_device_ordinal(const cpir_device* dev, int* ordinal) {
+  if (!dev || !ordinal) return CPIR_ERR_INVALID_ARGUMENT;
+  *ordinal = dev->ordinal;
+  return CPIR_OK;
+}
+
+int cpir_device_synchronize(cpir_device* dev) {
+  if (!dev) return CPIR_ERR_INVALID_ARGUMENT;
+  DeviceGuard g(dev->ordinal);
+  CPIR_HIP_TRY(hipDeviceSynchronize());
+  return CPIR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// shapes
+// ---------------------------------------------------------------------------------------------------------------
+uint32_t cpir_compression_factor(uint32_t b) { return compression_factor(b); }
+int cpir_find_encoded_db_matrix_element_bit_length(uint64_t n, uint32_t* b) { return find_bit_len(n, b); }
+int cpir_filter_shape(uint32_t arity, uint64_t n, uint32_t* sl, uint32_t* scl, uint64_t* nf) { return filter_shape(arity, n, sl, scl, nf); }
+uint64_t cpir_encoded_num_cols(uint64_t max_value_byte_len, uint32_t b) { return encoded_num_cols(max_value_byte_len, b); }
+int cpir_dtc_layout_for(uint64_t N, uint32_t C, uint32_t b, cpir_dtc_layout* out) { return dtc_layout_for(N, C, b, out); }
+
+int cpir_generate_from_seed(uint64_t rows, uint64_t cols, const uint8_t seed[CPIR_SEED_BYTE_LEN], uint32_t* out) {
+  if (!seed || !out) return CPIR_ERR_INVALID_ARGUMENT;
+  if (rows == 0 || cols == 0) return CPIR_ERR_INVALID_MATRIX_DIMENSION;  // Matrix::from_values, matrix.rs:69-79
+  TurboShake128 xof;
+  xof.absorb(seed, CPIR_SEED_BYTE_LEN);
+  xof.finalize(0x1F);
+  xof.squeeze(reinterpret_cast<uint8_t*>(out), (size_t)(rows * cols) * 4);
+  return CPIR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// low-level device operations
+// ---------------------------------------------------------------------------------------------------------------
+int cpir_op_mat_x_mat(cpir_device* dev, const uint32_t* A, uint64_t lda, const uint32_t* D, uint64_t ldd, uint32_t* M, uint64_t ldm,
+                      uint64_t rows, uint64_t inner, uint64_t cols, uint32_t rhs_max_bits, int accumulate, void* stream) {
+  if (!dev) return CPIR_ERR_INVALID_ARGUMENT;
+  DeviceGuard g(dev->ordinal);
+  return launch_mat_x_mat(dev, A, lda, D, ldd, M, ldm, rows, inner, cols, rhs_max_bits, accumulate, pick_stream(dev, stream));
+}
+
+int cpir_op_transpose_compress(cpir_device* dev, const uint32_t* D, uint64_t ldd, const cpir_dtc_layout* layout, uint32_t* dtc,
+                               uint32_t* or_of_entries, void* stream) {
+  if (!dev || !layout) return CPIR_ERR_INVALID_ARGUMENT;
+  DeviceGuard g(dev->ordinal);
+  return launch_transpose_compress(dev, D, ldd, *layout, dtc, or_of_entries, pick_stream(dev, stream));
+}
+
+int cpir_op_dtc_import(cpir_device* dev, const uint32_t* compressed, const cpir_dtc_layout* layout, uint32_t* dtc, void* stream) {
+  if (!dev || !layout) return CPIR_ERR_INVALID_ARGUMENT;
+  DeviceGuard g(dev->ordinal);
+  return launch_dtc_import(dev, compressed, *layout, dtc, pick_stream(dev, stream));
+}
+
+int cpir_op_dtc_export(cpir_device* dev, const uint32_t* dtc, const cpir_dtc_layout* layout, uint32_t* compressed, void* stream) {
+  if (!dev || !layout) return CPIR_ERR_INVALID_ARGUMENT;
+  DeviceGuard g(dev->ordinal);
+  return launch_dtc_export(dev, dtc, *layout, compressed, pick_stream(dev, stream));
+}
+
+uint64_t cpir_respond_scratch_words(const cpir_dtc_layout* layout) { return layout ? respond_scratch_words(*layout, 1) : 0; }
+uint64_t cpir_respond_batch_scratch_words(const cpir_dtc_layout* layout, uint32_t batch) {
+  return layout ? respond_scratch_words(*layout, batch) : 0;
+}
+
+int cpir_op_respond(cpir_device* dev, const uint32_t* dtc, const cpir_dtc_layout* layout, const uint32_t* q, uint64_t q_len,
+                    uint64_t q_slot_offset, uint32_t* r, uint32_t* scratch, void* stream) {
+  if (!dev || !layout) return CPIR_ERR_INVALID_ARGUMENT;
+  DeviceGuard g(dev->ordinal);
+  return launch_respond(dev, dtc, *layout, q, q_len, q_slot_offset, 1, r, scratch, pick_stream(dev, stream));
+}
+
+// any batch size: issued as passes of 4 / 2 / 1 queries, each pass streaming the database once
+static int respond_batched(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
+                           uint64_t q_slot_offset, uint32_t batch, uint32_t* r, uint32_t* scratch, hipStream_t stream) {
+  uint32_t done = 0;
+  while (done < batch) {
+    const uint32_t left = batch - done;
+    const uint32_t step = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
+    CPIR_TRY(launch_respond(dev, dtc, L, q + (uint64_t)done * q_len, q_len, q_slot_offset, step, r + (uint64_t)done * L.num_cols, scratch, stream));
+    done += step;
+  }
+  return CPIR_OK;
+}
+
+int cpir_op_respond_batch(cpir_device* dev, const uint32_t* dtc, const cpir_dtc_layout* layout, const uint32_t* q, uint64_t q_len,
+                          uint64_t q_slot_offset, uint32_t batch, uint32_t* r, uint32_t* scratch, void* stream) {
+  if (!dev || !layout || batch == 0) return CPIR_ERR_INVALID_ARGUMENT;
+  DeviceGuard g(dev->ordinal);
+  return respond_batched(dev, dtc, *layout, q, q_len, q_slot_offset, batch, r, scratch, pick_stream(dev, stream));
+}
+
+int cpir_op_synth_fill(cpir_device* dev, uint32_t* out, uint64_t count, uint64_t seed, uint64_t index0, uint32_t mask, void* stream) {
+  if (!dev) return CPIR_ERR_INVALID_ARGUMENT;
+  DeviceGuard g(dev->ordinal);
+  return launch_synth_fill(dev, out, count, seed, index0, mask, pick_stream(dev, stream));
+}
+
+const char* cpir_respond_kernel_name(const cpir_dtc_layout* layout) { return layout ? respond_kernel_name(*layout) : ""; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// server: construction
+// ---------------------------------------------------------------------------------------------------------------
+int cpir_server_setup(cpir_device* dev, const uint8_t seed_mu[CPIR_SEED_BYTE_LEN], const uint32_t* pub_mat_a, const uint32_t* D,
+                      uint64_t N, uint32_t C, uint32_t b, uint32_t* hint_out, cpir_server** out) {
+  if (!dev || !D || !hint_out || !out || (!seed_mu && !pub_mat_a)) return CPIR_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (N == 0 || C == 0) return CPIR_ERR_INVALID_MATRIX_DIMENSION;
+  if (compression_factor(b) == 0) return CPIR_ERR_IMPOSSIBLE_ELEMENT_BIT_LENGTH;  // matrix.rs:99-101
+  PublicMatrixUpload upA(dev, N);
+  static const uint8_t zero_seed[32] = {0};
+  CPIR_TRY(upA.start(seed_mu ? seed_mu : zero_seed, pub_mat_a));  // server.rs:59 (runs concurrently with the D work)
+  Server* srv = nullptr;
+  CPIR_TRY(setup_from_host_matrix(dev, upA, D, N, C, b, hint_out, &srv));
+  *out = static_cast<cpir_server*>(srv);
+  return CPIR_OK;
+}
+
+int cpir_setup_kv_shape(uint32_t arity, const cpir_kv_db* db, uint32_t* b_out, uint64_t* N, uint32_t* C, size_t* hint_bytes_len) {
+  if (!db) return CPIR_ERR_INVALID_ARGUMENT;
+  if (arity != 3 && arity != 4) return CPIR_ERR_UNSUPPORTED_ARITY;
+  if (db->num_pairs == 0) return CPIR_ERR_EMPTY_KV_DATABASE;  // server.rs:48-51
+  if (!db->val_off) return CPIR_ERR_INVALID_ARGUMENT;
+  uint32_t b = 0;
+  CPIR_TRY(find_bit_len(db->num_pairs, &b));  // server.rs:53
+  uint64_t nf = 0;
+  CPIR_TRY(filter_shape(arity, db->num_pairs, nullptr, nullptr, &nf));
+  uint64_t max_len = 0;
+  for (uint64_t i = 0; i < db->num_pairs; i++) {
+    const uint64_t l = db->val_off[i + 1] - db->val_off[i];
+    if (l > max_len) max_len = l;
+  }
+  const uint64_t cols = encoded_num_cols(max_len, b);
+  if (cols == 0 || cols > 0xffffffffull) return CPIR_ERR_INVALID_MATRIX_DIMENSION;
+  if (b_out) *b_out = b;
+  if (N) *N = nf;
+  if (C) *C = (uint32_t)cols;
+  if (hint_bytes_len) *hint_bytes_len = 8 + (size_t)CPIR_LWE_DIMENSION * cols * 4;
+  return CPIR_OK;
+}
+
+int cpir_encode_kv_database(uint32_t arity, const cpir_kv_db* db, uint32_t b, const uint8_t* filter_seed_material, uint32_t max_attempts,
+                            uint8_t filter_param_bytes_out[CPIR_FILTER_PARAM_BYTE_LEN], uint32_t* D_out, uint64_t D_cap_words, uint64_t* N,
+                            uint32_t* C) {
+  if (!db || !filter_param_bytes_out || !D_out || !N || !C) return CPIR_ERR_INVALID_ARGUMENT;
+  if (max_attempts == 0) max_attempts = 100;
+  Filter filter;
+  std::vector<uint32_t> D;
+  CPIR_TRY(encode_kv_database(arity, *db, b, filter_seed_material, max_attempts, &filter, &D, N, C));
+  if (D_cap_words < D.size()) return CPIR_ERR_BUFFER_TOO_SMALL;
+  memcpy(D_out, D.data(), D.size() * 4);
+  filter.to_bytes(filter_param_bytes_out);
+  return CPIR_OK;
+}
+
+int cpir_server_setup_kv(cpir_device* dev, uint32_t arity, const uint8_t seed_mu[CPIR_SEED_BYTE_LEN], const cpir_kv_db* db,
+                         const uint8_t* filter_seed_material, uint32_t max_attempts, uint8_t* hint_bytes_out, size_t hint_bytes_cap,
+                         size_t* hint_bytes_len, uint8_t filter_param_bytes_out[CPIR_FILTER_PARAM_BYTE_LEN], cpir_server** out) {
+  if (!dev || !seed_mu || !db || !hint_bytes_out || !hint_bytes_len || !filter_param_bytes_out || !out) return CPIR_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  uint32_t b = 0, C = 0;
+  uint64_t N = 0;
+  size_t need = 0;
+  CPIR_TRY(cpir_setup_kv_shape(arity, db, &b, &N, &C, &need));
+  if (hint_bytes_cap < need) return CPIR_ERR_BUFFER_TOO_SMALL;
+  if (reinterpret_cast<uintptr_t>(hint_bytes_out) % 4 != 0) return CPIR_ERR_INVALID_ARGUMENT;
+  if (max_attempts == 0) max_attempts = 100;  // SERVER_SETUP_MAX_ATTEMPT_COUNT, params.rs:10
+
+  // N is known from the key count alone, so the (sequential, seconds-long) XOF expansion of A starts right away and
+  // overlaps the (also sequential) filter construction and row encoding below
+  PublicMatrixUpload upA(dev, N);
+  CPIR_TRY(upA.start(seed_mu, nullptr));
+
+  Filter filter;
+  std::vector<uint32_t> D;
+  uint64_t N2 = 0;
+  uint32_t C2 = 0;
+  CPIR_TRY(encode_kv_database(arity, *db, b, filter_seed_material, max_attempts, &filter, &D, &N2, &C2));  // server.rs:54
+  if (N2 != N || C2 != C) return CPIR_ERR_INVALID_ARGUMENT;
+
+  Server* srv = nullptr;
+  // hint_bytes = Matrix::to_bytes(hint): [rows][cols][elems] (matrix.rs:947-971, server.rs:62)
+  CPIR_TRY(setup_from_host_matrix(dev, upA, D.data(), N, C, b, reinterpret_cast<uint32_t*>(hint_bytes_out + 8), &srv));
+  const uint32_t hr = CPIR_LWE_DIMENSION, hc = C;
+  memcpy(hint_bytes_out, &hr, 4);
+  memcpy(hint_bytes_out + 4, &hc, 4);
+  *hint_bytes_len = need;
+  filter.to_bytes(filter_param_bytes_out);  // server.rs:63
+  *out = static_cast<cpir_server*>(srv);
+  return CPIR_OK;
+}
+
+int cpir_server_from_device_matrix(cpir_device* dev, const uint32_t* D_dev, uint64_t ldd, uint64_t N_shard, uint32_t C, uint32_t b,
+                                   uint64_t slot_offset, uint64_t total_slots, void* stream, cpir_server** out) {
+  if (!dev || !D_dev || !out) return CPIR_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  cpir_dtc_layout L;
+  CPIR_TRY(dtc_layout_for(N_shard, C, b, &L));
+  if (slot_offset % L.compression_factor != 0 || slot_offset + N_shard > total_slots) return CPIR_ERR_SHARD_RANGE;
+  DeviceGuard g(dev->ordinal);
+  Server* srv = server_new(dev, L, slot_offset, total_slots);
+  hipError_t e = hipMalloc(&srv->dtc, (size_t)L.total_words * 4);
+  if (e != hipSuccess) {
+    set_last_hip_error(e, "hipMalloc(dtc)", __FILE__, __LINE__);
+    server_destroy(srv);
+    return CPIR_ERR_OUT_OF_DEVICE_MEMORY;
+  }
+  hipStream_t s = pick_stream(dev, stream);
+  int st = launch_transpose_compress(dev, D_dev, ldd, L, srv->dtc, nullptr, s);
+  if (st == CPIR_OK) {
+    e = hipStreamSynchronize(s);
+    if (e != hipSuccess) set_last_hip_error(e, "hipStreamSynchronize", __FILE__, __LINE__), st = CPIR_ERR_HIP;
+  }
+  if (st != CPIR_OK) {
+    server_destroy(srv);
+    return st;
+  }
+  *out = static_cast<cpir_server*>(srv);
+  return CPIR_OK;
+}
+
+int cpir_server_from_compressed(cpir_device* dev, const uint32_t* compressed, uint32_t C, uint64_t N, uint32_t b, cpir_server** out) {
+  if (!dev || !compressed || !out) return CPIR_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  cpir_dtc_layout L;
+  CPIR_TRY(dtc_layout_for(N, C, b, &L));
+  DeviceGuard g(dev->ordinal);
+  DevBuf src;
+  const size_t src_bytes = (size_t)C * L.words_per_row * 4;
+  CPIR_HIP_TRY(hipMalloc(&src.p, src_bytes));
+  Server* srv = server_new(dev, L, 0, N);
+  auto fail = [&](int st) { server_destroy(srv); return st; };
+  hipError_t e = hipMalloc(&srv->dtc, (size_t)L.total_words * 4);
+  if (e != hipSuccess) { set_last_hip_error(e, "hipMalloc(dtc)", __FILE__, __LINE__); return fail(CPIR_ERR_OUT_OF_DEVICE_MEMORY); }
+  e = hipMemcpyAsync(src.p, compressed, src_bytes, hipMemcpyHostToDevice, dev->stream);
+  if (e != hipSuccess) { set_last_hip_error(e, "hipMemcpyAsync", __FILE__, __LINE__); return fail(CPIR_ERR_HIP); }
+  int st = launch_dtc_import(dev, (const uint32_t*)src.p, L, srv->dtc, dev->stream);
+  if (st != CPIR_OK) return fail(st);
+  e = hipStreamSynchronize(dev->stream);
+  if (e != hipSuccess) { set_last_hip_error(e, "hipStreamSynchronize", __FILE__, __LINE__); return fail(CPIR_ERR_HIP); }
+  *out = static_cast<cpir_server*>(srv);
+  return CPIR_OK;
+}
+
+int cpir_server_export_compressed(const cpir_server* srv, uint32_t* compressed_out, uint64_t out_words) {
+  if (!srv || !compressed_out) return CPIR_ERR_INVALID_ARGUMENT;
+  const cpir_dtc_layout& L = srv->layout;
+  const uint64_t words = (uint64_t)L.num_cols * L.words_per_row;
+  if (out_words < words) return CPIR_ERR_BUFFER_TOO_SMALL;
+  DeviceGuard g(srv->dev->ordinal);
+  DevBuf tmp;
+  CPIR_HIP_TRY(hipMalloc(&tmp.p, (size_t)words * 4));
+  CPIR_TRY(launch_dtc_export(srv->dev, srv->dtc, L, (uint32_t*)tmp.p, srv->dev->stream));
+  CPIR_HIP_TRY(hipMemcpyAsync(compressed_out, tmp.p, (size_t)words * 4, hipMemcpyDeviceToHost, srv->dev->stream));
+  CPIR_HIP_TRY(hipStreamSynchronize(srv->dev->stream));
+  return CPIR_OK;
+}
+
+cpir_server* cpir_server_retain(cpir_server* srv) {
+  if (srv) srv->refs.fetch_add(1);
+  return srv;
+}
+
+void cpir_server_release(cpir_server* srv) {
+  if (srv && srv->refs.fetch_sub(1) == 1) server_destroy(srv);
+}
+
+int cpir_server_layout(const cpir_server* srv, cpir_dtc_layout* out) {
+  if (!srv || !out) return CPIR_ERR_INVALID_ARGUMENT;
+  *out = srv->layout;
+  return CPIR_OK;
+}
+
+int cpir_server_shard(const cpir_server* srv, uint64_t* slot_offset, uint64_t* total_slots) {
+  if (!srv) return CPIR_ERR_INVALID_ARGUMENT;
+  if (slot_offset) *slot_offset = srv->slot_offset;
+  if (total_slots) *total_slots = srv->total_slots;
+  return CPIR_OK;
+}
+
+const uint32_t* cpir_server_dtc_device_ptr(const cpir_server* srv) { return srv ? srv->dtc : nullptr; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// server: respond
+// ---------------------------------------------------------------------------------------------------------------
+int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_rows, uint64_t q_cols, uint32_t* r_out) {
+  if (!csrv || !q || !r_out) return CPIR_ERR_INVALID_ARGUMENT;
+  Server* srv = const_cast<cpir_server*>(csrv);  // the pool is the only mutable state; it is internally locked
+  // matrix.rs:329-331: the query must be a 1 x N row vector
+  if (!(q_rows == 1 && q_cols == srv->total_slots)) return CPIR_ERR_INCOMPATIBLE_DIM_ROWVEC_X_TRANSPOSED;
+  DeviceGuard g(srv->dev->ordinal);
+  RespondSlot* s = nullptr;
+  CPIR_TRY(slot_acquire(srv, &s));
+  struct Release {
+    Server* srv;
+    RespondSlot* s;
+    ~Release() { slot_release(srv, s); }
+  } rel{srv, s};
+  const size_t qb = (size_t)srv->total_slots * 4, rb = (size_t)srv->layout.num_cols * 4;
+  memcpy(s->q_pinned, q, qb);  // the reference copies too (from_bytes .to_vec(), matrix.rs:1001-1007); pinned => true async DMA
+  CPIR_HIP_TRY(hipMemcpyAsync(s->q_dev, s->q_pinned, qb, hipMemcpyHostToDevice, s->stream));
+  CPIR_TRY(launch_respond(srv->dev, srv->dtc, srv->layout, s->q_dev, srv->total_slots, srv->slot_offset, 1, s->r_dev, nullptr, s->stream));
+  CPIR_HIP_TRY(hipMemcpyAsync(s->r_pinned, s->r_dev, rb, hipMemcpyDeviceToHost, s->stream));
+  CPIR_HIP_TRY(hipStreamSynchronize(s->stream));
+  memcpy(r_out, s->r_pinned, rb);
+  return CPIR_OK;
+}
+
+int cpir_server_respond_bytes(const cpir_server* srv, const uint8_t* query, size_t query_len, uint8_t* response, size_t response_cap,
+                              size_t* response_len) {
+  if (!srv || !query || !response || !response_len) return CPIR_ERR_INVALID_ARGUMENT;
+  // Matrix::from_bytes (matrix.rs:973-1010)
+  if (query_len <= 8) return CPIR_ERR_FAILED_TO_DESERIALIZE_MATRIX;
+  uint32_t rows, cols;
+  memcpy(&rows, query, 4);
+  memcpy(&cols, query + 4, 4);
+  const uint64_t num = (uint64_t)rows * cols;
+  if (num == 0 || num * 4 != (uint64_t)(query_len - 8)) return CPIR_ERR_FAILED_TO_DESERIALIZE_MATRIX;
+  const uint32_t C = srv->layout.num_cols;
+  const size_t need = 8 + (size_t)C * 4;
+  if (response_cap < need) return CPIR_ERR_BUFFER_TOO_SMALL;
+  // query + 8 may be only byte-aligned; cpir_server_respond memcpy's from it, so no alignment is required here
+  std::vector<uint32_t> r(C);
+  CPIR_TRY(cpir_server_respond(srv, reinterpret_cast<const uint32_t*>(query + 8), rows, cols, r.data()));
+  const uint32_t one = 1;  // Matrix::to_bytes of the 1 x C response (matrix.rs:947-971)
+  memcpy(response, &one, 4);
+  memcpy(response + 4, &C, 4);
+  memcpy(response + 8, r.data(), (size_t)C * 4);
+  *response_len = need;
+  return CPIR_OK;
+}
+
+int cpir_server_respond_device(const cpir_server* srv, const uint32_t* q_dev, uint32_t* r_dev, uint32_t* scratch_dev, void* stream) {
+  if (!srv || !q_dev || !r_dev) return CPIR_ERR_INVALID_ARGUMENT;
+  DeviceGuard g(srv->dev->ordinal);
+  return launch_respond(srv->dev, srv->dtc, srv->layout, q_dev, srv->total_slots, srv->slot_offset, 1, r_dev, scratch_dev,
+                        pick_stream(srv->dev, stream));
+}
+
+int cpir_server_respond_batch_device(const cpir_server* srv, const uint32_t* q_dev, uint32_t batch, uint32_t* r_dev, uint32_t* scratch_dev,
+                                     void* stream) {
+  if (!srv || !q_dev || !r_dev || batch == 0) return CPIR_ERR_INVALID_ARGUMENT;
+  DeviceGuard g(srv->dev->ordinal);
+  return respond_batched(srv->dev, srv->dtc, srv->layout, q_dev, srv->total_slots, srv->slot_offset, batch, r_dev, scratch_dev,
+                         pick_stream(srv->dev, stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+// Internal declarations shared by the translation units of libchalamet_hip.so (not part of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/chalamet_hip.h"
+
+namespace cpir {
+
+// ---- error plumbing --------------------------------------------------------------------------
+void set_last_hip_error(hipError_t e, const char* what, const char* file, int line);
+
+#define CPIR_HIP_TRY(expr)                                                    \
+  do {                                                                        \
+    hipError_t _e = (expr);                                                   \
+    if (_e != hipSuccess) {                                                   \
+      ::cpir::set_last_hip_error(_e, #expr, __FILE__, __LINE__);              \
+      return (_e == hipErrorOutOfMemory) ? CPIR_ERR_OUT_OF_DEVICE_MEMORY      \
+             : (_e == hipErrorNoDevice || _e == hipErrorInvalidDevice) ? CPIR_ERR_NO_DEVICE \
+                                                                       : CPIR_ERR_HIP;      \
+    }                                                                         \
+  } while (0)
+
+#define CPIR_TRY(expr)            \
+  do {                            \
+    int _s = (expr);              \
+    if (_s != CPIR_OK) return _s; \
+  } while (0)
+
+// ---- device context ---------------------------------------------------------------------------
+struct Device {
+  std::atomic<int> refs{1};
+  int ordinal = 0;
+  int num_cus = 0;
+  hipStream_t stream = nullptr;  // the handle's own stream (used when the caller passes NULL)
+};
+
+// RAII "make this device current for the calling thread"
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int ordinal) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = (prev == ordinal) || (hipSetDevice(ordinal) == hipSuccess);
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+inline hipStream_t pick_stream(const Device* dev, void* stream) {
+  return stream ? reinterpret_cast<hipStream_t>(stream) : dev->stream;
+}
+
+// ---- kernel launchers (defined in the .hip files) ---------------------------------------------
+// respond.hip
+uint64_t respond_scratch_words(const cpir_dtc_layout& L, uint32_t batch);
+int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
+                   uint64_t q_slot_offset, uint32_t batch, uint32_t* r, uint32_t* scratch, hipStream_t stream);
+const char* respond_kernel_name(const cpir_dtc_layout& L);
+
+// pack.hip
+int launch_transpose_compress(const Device* dev, const uint32_t* D, uint64_t ldd, const cpir_dtc_layout& L, uint32_t* dtc,
+                              uint32_t* or_of_entries, hipStream_t stream);
+int launch_dtc_import(const Device* dev, const uint32_t* compressed, const cpir_dtc_layout& L, uint32_t* dtc, hipStream_t stream);
+int launch_dtc_export(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, uint32_t* compressed, hipStream_t stream);
+
+// matmul.hip
+int launch_mat_x_mat(const Device* dev, const uint32_t* A, uint64_t lda, const uint32_t* D, uint64_t ldd, uint32_t* M,
+                     uint64_t ldm, uint64_t rows, uint64_t inner, uint64_t cols, uint32_t rhs_max_bits, int accumulate,
+                     hipStream_t stream);
+
+// synth.hip
+int launch_synth_fill(const Device* dev, uint32_t* out, uint64_t count, uint64_t seed, uint64_t index0, uint32_t mask,
+                      hipStream_t stream);
+
+// ---- host-side pieces (plain C++) -------------------------------------------------------------
+// host_xof.cpp : TurboSHAKE128 (RFC 9861)
+struct TurboShake128 {
+  uint64_t s[25];
+  unsigned pos;
+  TurboShake128();
+  void absorb(const uint8_t* in, size_t len);
+  void finalize(uint8_t domain_sep = 0x1F);
+  void squeeze(uint8_t* out, size_t len);
+};
+void turboshake128(const uint8_t* msg, size_t len, uint8_t* out, size_t out_len);
+
+// host_shapes.cpp
+uint32_t compression_factor(uint32_t b);
+int find_bit_len(uint64_t n, uint32_t* b);
+int filter_shape(uint32_t arity, uint64_t n, uint32_t* seg_len, uint32_t* seg_count_len, uint64_t* num_fp);
+uint64_t encoded_num_cols(uint64_t max_value_byte_len, uint32_t b);
+int dtc_layout_for(uint64_t N, uint32_t C, uint32_t b, cpir_dtc_layout* out);
+
+// host_encoder.cpp : binary fuse filter + row codec (Matrix::from_kv_database)
+struct Filter {
+  uint8_t seed[32];
+  uint32_t arity;
+  uint32_t segment_length;
+  uint32_t segment_count_length;
+  uint64_t num_fingerprints;
+  uint64_t filter_size;
+  uint64_t mat_elem_bit_len;
+  void to_bytes(uint8_t out[CPIR_FILTER_PARAM_BYTE_LEN]) const;
+};
+int encode_kv_database(uint32_t arity, const cpir_kv_db& db, uint32_t b, const uint8_t* filter_seeds, uint32_t max_attempts,
+                       Filter* filter, std::vector<uint32_t>* D, uint64_t* N, uint32_t* C);
+
+}  // namespace cpir

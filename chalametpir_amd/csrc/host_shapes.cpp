@@ -1,0 +1,81 @@
+// host_shapes.cpp -- host-only shape arithmetic of the server path (no device needed).
+#include <cmath>
+
+#include "cpir_internal.hpp"
+
+namespace cpir {
+
+// reference chalametpir_common/src/matrix.rs:103-167: packing factor by element bit length
+uint32_t compression_factor(uint32_t b) {
+  if (b < CPIR_MIN_ELEM_BIT_LEN || b > CPIR_MAX_ELEM_BIT_LEN) return 0;
+  return b >= 11 ? 2u : (b >= 9 ? 3u : 4u);
+}
+
+// reference chalametpir_server/src/server.rs:193-218: largest b with 2^32 >= 8 * (2^b)^2 * floor(sqrt(n))
+int find_bit_len(uint64_t n, uint32_t* out) {
+  if (!out) return CPIR_ERR_INVALID_ARGUMENT;
+  if (n == 0) return CPIR_ERR_EMPTY_KV_DATABASE;  // Server::setup rejects an empty DB first (server.rs:49-51)
+  uint64_t root = (uint64_t)std::sqrt((long double)n);
+  while (root * root > n) root--;
+  while ((root + 1) * (root + 1) <= n) root++;
+  const unsigned __int128 q = (unsigned __int128)1 << 32;
+  uint32_t b = 0;
+  while (b < 32 && q >= ((unsigned __int128)8 << (2 * b)) * root) b++;
+  b = b ? b - 1 : 0;
+  if (b < CPIR_MIN_ELEM_BIT_LEN) return CPIR_ERR_KV_DATABASE_SIZE_TOO_LARGE;
+  *out = b;
+  return CPIR_OK;
+}
+
+// reference chalametpir_common/src/binary_fuse_filter.rs:519-538 (segment_length, size_factor) and :52-67 / :261-276
+int filter_shape(uint32_t arity, uint64_t n, uint32_t* seg_len, uint32_t* seg_count_len, uint64_t* num_fp) {
+  if (arity != 3 && arity != 4) return CPIR_ERR_UNSUPPORTED_ARITY;
+  if (n == 0) return CPIR_ERR_EMPTY_KV_DATABASE;
+  const double size = (double)(uint32_t)n;
+  double exponent, factor;
+  if (arity == 3) {
+    exponent = std::floor(std::log(size) / std::log(3.33) + 2.25);
+    factor = std::fmax(1.125, 0.875 + 0.25 * std::log(1e6) / std::log(size));
+  } else {
+    exponent = std::floor(std::log(size) / std::log(2.91) - 0.5);
+    factor = std::fmax(1.075, 0.77 + 0.305 * std::log(6e5) / std::log(size));
+  }
+  // the reference casts the f64 exponent with `as usize`, which saturates negatives to 0 (4-wise filter, one key)
+  uint32_t seg = 1u << (unsigned)(exponent < 0 ? 0.0 : exponent);
+  if (seg > (1u << 18)) seg = 1u << 18;
+  const uint32_t capacity = n > 1 ? (uint32_t)std::round(size * factor) : 0;
+  const uint32_t init_segments = (capacity + seg - 1) / seg;
+  const uint32_t proposed = (init_segments * seg + seg - 1) / seg;
+  const uint32_t segments = proposed < arity ? 1 : proposed - (arity - 1);
+  if (seg_len) *seg_len = seg;
+  if (seg_count_len) *seg_count_len = segments * seg;
+  if (num_fp) *num_fp = (uint64_t)(segments + arity - 1) * seg;
+  return CPIR_OK;
+}
+
+// reference chalametpir_common/src/matrix.rs:694-700: 256-bit key digest + value + 1 boundary byte, b bits per element
+uint64_t encoded_num_cols(uint64_t max_value_byte_len, uint32_t b) {
+  if (b == 0) return 0;
+  return (256 + 8 * max_value_byte_len + 8 + b - 1) / b;
+}
+
+int dtc_layout_for(uint64_t N, uint32_t C, uint32_t b, cpir_dtc_layout* out) {
+  if (!out) return CPIR_ERR_INVALID_ARGUMENT;
+  const uint32_t cf = compression_factor(b);
+  if (cf == 0) return CPIR_ERR_IMPOSSIBLE_ELEMENT_BIT_LENGTH;  // matrix.rs:99-101
+  if (N == 0 || C == 0) return CPIR_ERR_INVALID_MATRIX_DIMENSION;
+  memset(out, 0, sizeof(*out));
+  out->num_slots = N;
+  out->num_cols = C;
+  out->mat_elem_bit_len = b;
+  out->compression_factor = cf;
+  out->words_per_row = (N + cf - 1) / cf;
+  out->words_per_row_padded = (out->words_per_row + CPIR_DTC_WORD_ALIGN - 1) / CPIR_DTC_WORD_ALIGN * CPIR_DTC_WORD_ALIGN;
+  const uint64_t rp = ((uint64_t)C + CPIR_DTC_ROW_ALIGN - 1) / CPIR_DTC_ROW_ALIGN * CPIR_DTC_ROW_ALIGN;
+  if (rp > 0xffffffffull) return CPIR_ERR_INVALID_MATRIX_DIMENSION;
+  out->rows_padded = (uint32_t)rp;
+  out->total_words = rp * out->words_per_row_padded;
+  return CPIR_OK;
+}
+
+}  // namespace cpir

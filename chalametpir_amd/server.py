@@ -1,0 +1,335 @@
+"""Host-side mirror of `chalametpir_server::Server` (reference chalametpir_server/src/server.rs:15-219) over the C ABI.
+
+    server, hint_bytes, filter_param_bytes = Server.setup(seed_mu, db, arity=3)     # server.rs:47 / 103
+    response_bytes = server.respond(query_bytes)                                      # server.rs:184
+
+Same names, argument meaning and error behaviour as the reference (errors are raised as ChalametPIRError carrying the
+reference's variant name).  Everything that computes goes through libchalamet_hip.so; there is no CPU path here.
+PyTorch is optional plumbing: tensors are only used to hand device memory / streams to the *_device entry points.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Mapping, Optional, Tuple
+
+import numpy as np
+
+from . import _native
+from ._native import DtcLayout, KvDb
+from .errors import ChalametPIRError
+from .params import LWE_DIMENSION, SEED_BYTE_LEN, SERVER_SETUP_MAX_ATTEMPT_COUNT
+
+
+def _check(status: int) -> None:
+    if status != 0:
+        lib = _native.load()
+        msg = lib.cpir_strerror(status).decode()
+        detail = lib.cpir_last_hip_error().decode() if status in (64, 65, 66) else ""
+        raise ChalametPIRError(status, msg, detail)
+
+
+def _seed_arg(seed: bytes):
+    if len(seed) != SEED_BYTE_LEN:
+        raise ValueError(f"seed must be {SEED_BYTE_LEN} bytes")  # &[u8; SEED_BYTE_LEN] in the reference: a type error there
+    return (C.c_uint8 * SEED_BYTE_LEN).from_buffer_copy(seed)
+
+
+def _u32_host(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _ptr(a: np.ndarray) -> int:
+    return a.ctypes.data
+
+
+def _tensor_ptr(t) -> int:
+    """device address of a torch tensor holding 32-bit elements (int32 / uint32 views are both fine)"""
+    if t.element_size() != 4 or not t.is_contiguous():
+        raise ValueError("expected a contiguous tensor of 4-byte elements")
+    return t.data_ptr()
+
+
+def _stream_ptr(stream) -> Optional[int]:
+    if stream is None:
+        return None
+    return int(getattr(stream, "cuda_stream", stream))
+
+
+class Device:
+    """cpir_device: replaces gpu_utils::setup_gpu() (reference gpu_utils.rs:25-79)."""
+
+    def __init__(self, ordinal: int = 0):
+        self._lib = _native.load()
+        h = C.c_void_p()
+        _check(self._lib.cpir_device_open(ordinal, C.byref(h)))
+        self._h = h
+        self.ordinal = ordinal
+
+    @staticmethod
+    def count() -> int:
+        n = C.c_int()
+        st = _native.load().cpir_device_count(C.byref(n))
+        return n.value if st == 0 else 0
+
+    def synchronize(self) -> None:
+        _check(self._lib.cpir_device_synchronize(self._h))
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.cpir_device_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- low-level device ops on caller-owned device memory (torch tensors or raw addresses) -----------------------
+    def mat_x_mat(self, A, D, M, rows: int, inner: int, cols: int, *, lda=None, ldd=None, ldm=None, rhs_max_bits: int = 32,
+                  accumulate: bool = False, stream=None) -> None:
+        """gpu_utils::mat_x_mat (reference gpu_utils.rs:156-220)"""
+        _check(self._lib.cpir_op_mat_x_mat(self._h, _tensor_ptr(A), lda or inner, _tensor_ptr(D), ldd or cols, _tensor_ptr(M),
+                                           ldm or cols, rows, inner, cols, rhs_max_bits, int(accumulate), _stream_ptr(stream)))
+
+    def transpose_compress(self, D, layout: DtcLayout, dtc, *, ldd=None, or_of_entries=None, stream=None) -> None:
+        """gpu_utils::mat_transpose + Matrix::row_wise_compress (reference gpu_utils.rs:222-281, matrix.rs:98-205)"""
+        _check(self._lib.cpir_op_transpose_compress(self._h, _tensor_ptr(D), ldd or layout.num_cols, C.byref(layout), _tensor_ptr(dtc),
+                                                    _tensor_ptr(or_of_entries) if or_of_entries is not None else None,
+                                                    _stream_ptr(stream)))
+
+    def respond(self, dtc, layout: DtcLayout, q, r, *, q_len=None, q_slot_offset: int = 0, stream=None) -> None:
+        """Matrix::row_vector_x_compressed_transposed_matrix (reference matrix.rs:328-485) on device tensors"""
+        _check(self._lib.cpir_op_respond(self._h, _tensor_ptr(dtc), C.byref(layout), _tensor_ptr(q),
+                                         q_len if q_len is not None else q.numel(), q_slot_offset, _tensor_ptr(r), None,
+                                         _stream_ptr(stream)))
+
+    def synth_fill(self, out, count: int, seed: int, index0: int = 0, mask: int = 0xFFFFFFFF, *, offset_words: int = 0, stream=None) -> None:
+        _check(self._lib.cpir_op_synth_fill(self._h, _tensor_ptr(out) + 4 * offset_words, count, seed, index0, mask, _stream_ptr(stream)))
+
+
+def dtc_layout_for(num_slots: int, num_cols: int, mat_elem_bit_len: int) -> DtcLayout:
+    L = DtcLayout()
+    _check(_native.load().cpir_dtc_layout_for(num_slots, num_cols, mat_elem_bit_len, C.byref(L)))
+    return L
+
+
+def find_encoded_db_matrix_element_bit_length(db_entry_count: int) -> int:
+    """Server::find_encoded_db_matrix_element_bit_length (reference server.rs:193-218)"""
+    b = C.c_uint32()
+    _check(_native.load().cpir_find_encoded_db_matrix_element_bit_length(db_entry_count, C.byref(b)))
+    return b.value
+
+
+def filter_shape(arity: int, db_entry_count: int) -> Tuple[int, int, int]:
+    """(segment_length, segment_count_length, num_fingerprints) (reference binary_fuse_filter.rs:52-67, 519-538)"""
+    sl, scl, nf = C.c_uint32(), C.c_uint32(), C.c_uint64()
+    _check(_native.load().cpir_filter_shape(arity, db_entry_count, C.byref(sl), C.byref(scl), C.byref(nf)))
+    return sl.value, scl.value, nf.value
+
+
+def encoded_num_cols(max_value_byte_len: int, mat_elem_bit_len: int) -> int:
+    return int(_native.load().cpir_encoded_num_cols(max_value_byte_len, mat_elem_bit_len))
+
+
+def generate_from_seed(rows: int, cols: int, seed: bytes) -> np.ndarray:
+    """Matrix::generate_from_seed (reference matrix.rs:541-558); host-side XOF of the product library"""
+    out = np.empty((rows, cols), dtype=np.uint32)
+    _check(_native.load().cpir_generate_from_seed(rows, cols, _seed_arg(seed), _ptr(out)))
+    return out
+
+
+def encode_kv_database(db: Mapping[bytes, bytes], arity: int, mat_elem_bit_len: int, filter_seed_material: Optional[bytes] = None,
+                       max_attempts: int = SERVER_SETUP_MAX_ATTEMPT_COUNT) -> Tuple[np.ndarray, bytes]:
+    """Matrix::from_kv_database::<ARITY> (reference matrix.rs:633-648) on the host -> (D as N x C u32, filter_param_bytes)"""
+    lib = _native.load()
+    if len(db) == 0:
+        raise ChalametPIRError(8, lib.cpir_strerror(8).decode())
+    flat = _FlatKvDb(db)
+    _, _, nf = filter_shape(arity, len(db))
+    cols = encoded_num_cols(max(len(v) for v in db.values()), mat_elem_bit_len)
+    D = np.empty((nf, cols), dtype=np.uint32)
+    fbytes = (C.c_uint8 * _native.FILTER_PARAM_BYTE_LEN)()
+    seeds = None
+    if filter_seed_material is not None:
+        if len(filter_seed_material) < 32 * max_attempts:
+            raise ValueError("filter_seed_material must hold 32 bytes per attempt")
+        seeds = (C.c_uint8 * len(filter_seed_material)).from_buffer_copy(filter_seed_material)
+    N, Cc = C.c_uint64(), C.c_uint32()
+    _check(lib.cpir_encode_kv_database(arity, C.byref(flat.c), mat_elem_bit_len, seeds, max_attempts, fbytes, _ptr(D), D.size, C.byref(N),
+                                       C.byref(Cc)))
+    assert (N.value, Cc.value) == D.shape
+    return D, bytes(fbytes)
+
+
+def tuning_set(key: str, value: int) -> None:
+    _check(_native.load().cpir_tuning_set(key.encode(), int(value)))
+
+
+class _FlatKvDb:
+    """HashMap<&[u8], &[u8]> flattened into the cpir_kv_db arrays (iteration order of the mapping = key order)."""
+
+    def __init__(self, db: Mapping[bytes, bytes]):
+        keys = list(db.keys())
+        vals = [db[k] for k in keys]
+        self.n = len(keys)
+        self.kbuf = np.frombuffer(b"".join(keys) or b"\0", dtype=np.uint8).copy()
+        self.vbuf = np.frombuffer(b"".join(vals) or b"\0", dtype=np.uint8).copy()
+        self.koff = np.zeros(self.n + 1, dtype=np.uint64)
+        self.voff = np.zeros(self.n + 1, dtype=np.uint64)
+        if self.n:
+            np.cumsum([len(k) for k in keys], out=self.koff[1:])
+            np.cumsum([len(v) for v in vals], out=self.voff[1:])
+        self.c = KvDb(self.n, _ptr(self.kbuf), _ptr(self.koff), _ptr(self.vbuf), _ptr(self.voff))
+
+
+class Server:
+    """Device-resident replacement of `struct Server` (reference server.rs:15-21): the packed, transposed DB lives in HBM."""
+
+    def __init__(self, handle: C.c_void_p, device: Device):
+        self._lib = _native.load()
+        self._h = handle
+        self.device = device
+        L = DtcLayout()
+        _check(self._lib.cpir_server_layout(self._h, C.byref(L)))
+        self.layout = L
+        off, tot = C.c_uint64(), C.c_uint64()
+        _check(self._lib.cpir_server_shard(self._h, C.byref(off), C.byref(tot)))
+        self.slot_offset, self.total_slots = off.value, tot.value
+
+    # ---- construction -------------------------------------------------------------------------------------------------
+    @staticmethod
+    def setup(seed_mu: bytes, db: Mapping[bytes, bytes], arity: int = 3, *, device: Optional[Device] = None,
+              filter_seed_material: Optional[bytes] = None,
+              max_attempts: int = SERVER_SETUP_MAX_ATTEMPT_COUNT) -> Tuple["Server", bytes, bytes]:
+        """Server::setup::<ARITY>(seed_mu, db) -> (Server, hint_bytes, filter_param_bytes)   (reference server.rs:47-78 / 103-167)"""
+        lib = _native.load()
+        if arity not in (3, 4):
+            raise ChalametPIRError(17, lib.cpir_strerror(17).decode())  # const { assert!(ARITY == 3 || ARITY == 4) }, matrix.rs:638
+        if len(db) == 0:
+            raise ChalametPIRError(8, lib.cpir_strerror(8).decode())  # EmptyKVDatabase, server.rs:48-51
+        flat = _FlatKvDb(db)
+        b, N, Cc, need = C.c_uint32(), C.c_uint64(), C.c_uint32(), C.c_size_t()
+        _check(lib.cpir_setup_kv_shape(arity, C.byref(flat.c), C.byref(b), C.byref(N), C.byref(Cc), C.byref(need)))
+        device = device or Device(0)
+        hint = np.empty(need.value // 4, dtype=np.uint32)  # 4-byte aligned wire image
+        hint_len = C.c_size_t()
+        fbytes = (C.c_uint8 * _native.FILTER_PARAM_BYTE_LEN)()
+        seeds = None
+        if filter_seed_material is not None:
+            if len(filter_seed_material) < 32 * max_attempts:
+                raise ValueError("filter_seed_material must hold 32 bytes per attempt")
+            seeds = (C.c_uint8 * len(filter_seed_material)).from_buffer_copy(filter_seed_material)
+        h = C.c_void_p()
+        _check(lib.cpir_server_setup_kv(device._h, arity, _seed_arg(seed_mu), C.byref(flat.c), seeds, max_attempts, _ptr(hint), need.value,
+                                        C.byref(hint_len), fbytes, C.byref(h)))
+        return Server(h, device), hint.tobytes()[: hint_len.value], bytes(fbytes)
+
+    @staticmethod
+    def setup_from_matrix(seed_mu: bytes, D: np.ndarray, mat_elem_bit_len: int, *, pub_mat_a: Optional[np.ndarray] = None,
+                          device: Optional[Device] = None) -> Tuple["Server", np.ndarray]:
+        """The matrix half of Server::setup (reference server.rs:59-67) from an already encoded DB matrix D (N x C).
+        Returns (Server, hint) with hint the 1774 x C matrix whose to_bytes image is `hint_bytes`."""
+        lib = _native.load()
+        D = _u32_host(D)
+        if D.ndim != 2:
+            raise ValueError("D must be N x C")
+        N, Cc = D.shape
+        device = device or Device(0)
+        hint = np.empty((LWE_DIMENSION, Cc), dtype=np.uint32)
+        a_ptr = None
+        if pub_mat_a is not None:
+            pub_mat_a = _u32_host(pub_mat_a)
+            if pub_mat_a.shape != (LWE_DIMENSION, N):
+                raise ChalametPIRError(2, lib.cpir_strerror(2).decode())  # IncompatibleDimensionForMatrixMultiplication
+            a_ptr = _ptr(pub_mat_a)
+        h = C.c_void_p()
+        _check(lib.cpir_server_setup(device._h, _seed_arg(seed_mu), a_ptr, _ptr(D), N, Cc, mat_elem_bit_len, _ptr(hint), C.byref(h)))
+        return Server(h, device), hint
+
+    @staticmethod
+    def from_compressed(compressed: np.ndarray, decompressed_num_cols: int, mat_elem_bit_len: int, *,
+                        device: Optional[Device] = None) -> "Server":
+        """From the reference's own Server fields (server.rs:16-21): compressed transposed matrix C x ceil(N/cf), N, b."""
+        lib = _native.load()
+        compressed = _u32_host(compressed)
+        device = device or Device(0)
+        cf = lib.cpir_compression_factor(mat_elem_bit_len)
+        if cf == 0:
+            raise ChalametPIRError(19, lib.cpir_strerror(19).decode())
+        if compressed.ndim != 2 or compressed.shape[1] != -(-decompressed_num_cols // cf):
+            raise ChalametPIRError(4, lib.cpir_strerror(4).decode())
+        h = C.c_void_p()
+        _check(lib.cpir_server_from_compressed(device._h, _ptr(compressed), compressed.shape[0], decompressed_num_cols, mat_elem_bit_len,
+                                               C.byref(h)))
+        return Server(h, device)
+
+    @staticmethod
+    def from_device_matrix(D_dev, num_slots: int, num_cols: int, mat_elem_bit_len: int, *, device: Device, ldd: Optional[int] = None,
+                           slot_offset: int = 0, total_slots: Optional[int] = None, stream=None) -> "Server":
+        """Pack a (shard of the) encoded DB that already sits in HBM (torch tensor, num_slots x num_cols)."""
+        lib = _native.load()
+        h = C.c_void_p()
+        _check(lib.cpir_server_from_device_matrix(device._h, _tensor_ptr(D_dev), ldd or num_cols, num_slots, num_cols, mat_elem_bit_len,
+                                                  slot_offset, total_slots if total_slots is not None else num_slots,
+                                                  _stream_ptr(stream), C.byref(h)))
+        return Server(h, device)
+
+    def clone(self) -> "Server":
+        """#[derive(Clone)] (reference server.rs:15): shares the immutable device-resident DB."""
+        return Server(C.c_void_p(self._lib.cpir_server_retain(self._h)), self.device)
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.cpir_server_release(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- properties ---------------------------------------------------------------------------------------------------
+    @property
+    def decompressed_num_cols(self) -> int:  # server.rs:19
+        return int(self.layout.num_slots)
+
+    @property
+    def mat_elem_bit_len(self) -> int:  # server.rs:20
+        return int(self.layout.mat_elem_bit_len)
+
+    @property
+    def response_len(self) -> int:
+        return int(self.layout.num_cols)
+
+    def export_compressed(self) -> np.ndarray:
+        """compressed_transposed_parsed_db_mat_d in the reference's layout (C x ceil(N/cf)) (server.rs:18)"""
+        out = np.empty((self.layout.num_cols, self.layout.words_per_row), dtype=np.uint32)
+        _check(self._lib.cpir_server_export_compressed(self._h, _ptr(out), out.size))
+        return out
+
+    # ---- respond ------------------------------------------------------------------------------------------------------
+    def respond(self, query: bytes) -> bytes:
+        """Server::respond(&self, query: &[u8]) -> Result<Vec<u8>, ChalametPIRError>   (reference server.rs:184-190)"""
+        cap = 8 + 4 * self.layout.num_cols
+        out = (C.c_uint8 * cap)()
+        n = C.c_size_t()
+        qbuf = (C.c_uint8 * max(len(query), 1)).from_buffer_copy(query if len(query) else b"\0")
+        _check(self._lib.cpir_server_respond_bytes(self._h, C.addressof(qbuf), len(query), C.addressof(out), cap, C.byref(n)))
+        return bytes(out[: n.value])
+
+    def respond_array(self, q: np.ndarray) -> np.ndarray:
+        """respond on the element array of a 1 x N query (query[8..] of the wire image)"""
+        q = _u32_host(q)
+        rows, cols = (1, q.shape[0]) if q.ndim == 1 else q.shape
+        r = np.empty(self.layout.num_cols, dtype=np.uint32)
+        _check(self._lib.cpir_server_respond(self._h, _ptr(q), rows, cols, _ptr(r)))
+        return r
+
+    def respond_device(self, q_dev, r_dev, stream=None) -> None:
+        """enqueue respond on device tensors: q_dev total_slots x u32, r_dev C x u32 (partial response for a shard)"""
+        _check(self._lib.cpir_server_respond_device(self._h, _tensor_ptr(q_dev), _tensor_ptr(r_dev), None, _stream_ptr(stream)))
+
+    def respond_batch_device(self, q_dev, batch: int, r_dev, stream=None) -> None:
+        _check(self._lib.cpir_server_respond_batch_device(self._h, _tensor_ptr(q_dev), batch, _tensor_ptr(r_dev), None, _stream_ptr(stream)))

@@ -1,0 +1,257 @@
+/*
+ * chalamet_hip.h -- C ABI of libchalamet_hip.so: the MI355X (gfx950) replacement for the `gpu` feature of
+ * chalametpir_server (reference: itzmeanjan/ChalametPIR v0.7.0).
+ *
+ * This is the drop-in boundary.  Everything a Rust FFI shim for `chalametpir_server::Server::{setup,respond}`
+ * would bind is declared here with plain pointers and sizes; no C++/torch types cross it.  Each entry point cites
+ * the reference interface it replaces (paths relative to the reference checkout):
+ *   server.rs    = chalametpir_server/src/server.rs
+ *   gpu_utils.rs = chalametpir_server/src/gpu/gpu_utils.rs
+ *   matrix.rs    = chalametpir_common/src/matrix.rs
+ *   error.rs     = chalametpir_common/src/error.rs
+ *
+ * Conventions
+ *   - every function returns a cpir_status (0 = ok); outputs go through pointers;
+ *   - matrices are row-major u32, (r,c) -> elems[r*cols + c]                         (matrix.rs:26-31,1013-1029)
+ *   - "wire bytes" are Matrix::to_bytes images: [rows u32 LE][cols u32 LE][elems LE]  (matrix.rs:947-1010)
+ *   - all element counts are 64-bit (the reference sizes buffers in u32: matrix.rs:50,71,546,988,1048)
+ *   - `stream` arguments are hipStream_t passed as void* (NULL = the handle's own stream)
+ *   - host-pointer entry points are synchronous (return when outputs are written), like the reference's
+ *     fence-waited Vulkan calls (gpu_utils.rs:129-135,213-219); *_device entry points only enqueue.
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry point returns
+ *     CPIR_ERR_NO_DEVICE / CPIR_ERR_HIP.
+ */
+#ifndef CHALAMET_HIP_H
+#define CHALAMET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPIR_LWE_DIMENSION 1774u  /* params.rs:1  */
+#define CPIR_SEED_BYTE_LEN 32u    /* params.rs:5  */
+#define CPIR_MIN_ELEM_BIT_LEN 4u  /* params.rs:14 */
+#define CPIR_MAX_ELEM_BIT_LEN 14u /* params.rs:17 */
+
+/* Status codes.  1..19 map one-to-one onto the ChalametPIRError variants this path can raise (error.rs:24-49);
+ * 64.. replace the thirteen Vulkan* variants (error.rs:10-22) that the reference's GPU plugin raises. */
+typedef enum cpir_status {
+  CPIR_OK = 0,
+  CPIR_ERR_INVALID_MATRIX_DIMENSION = 1,             /* InvalidMatrixDimension                       error.rs:25 */
+  CPIR_ERR_INCOMPATIBLE_DIM_MATMUL = 2,              /* IncompatibleDimensionForMatrixMultiplication error.rs:26 */
+  CPIR_ERR_INVALID_NUMBER_OF_ELEMENTS = 4,           /* InvalidNumberOfElementsInMatrix              error.rs:28 */
+  CPIR_ERR_INCOMPATIBLE_DIM_ROWVEC_X_TRANSPOSED = 5, /* IncompatibleDimensionForRowVectorTransposedMatrixMultiplication error.rs:29 */
+  CPIR_ERR_FAILED_TO_DESERIALIZE_MATRIX = 7,         /* FailedToDeserializeMatrixFromBytes           error.rs:31 */
+  CPIR_ERR_EMPTY_KV_DATABASE = 8,                    /* EmptyKVDatabase                              error.rs:34 */
+  CPIR_ERR_EXHAUSTED_ATTEMPTS_3WISE = 9,             /* ExhaustedAllAttemptsToBuild3WiseXorFilter    error.rs:35 */
+  CPIR_ERR_EXHAUSTED_ATTEMPTS_4WISE = 10,            /* ExhaustedAllAttemptsToBuild4WiseXorFilter    error.rs:36 */
+  CPIR_ERR_KV_DATABASE_SIZE_TOO_LARGE = 14,          /* KVDatabaseSizeTooLarge                       error.rs:42 */
+  CPIR_ERR_UNSUPPORTED_ARITY = 17,                   /* UnsupportedArityForBinaryFuseFilter          error.rs:47 */
+  CPIR_ERR_IMPOSSIBLE_ELEMENT_BIT_LENGTH = 19,       /* ImpossibleEncodedDBMatrixElementBitLength    error.rs:49 */
+  CPIR_ERR_NO_DEVICE = 64,        /* ~ VulkanLibraryNotFound / VulkanPhysicalDeviceNotFound   (gpu_utils.rs:26,43,59) */
+  CPIR_ERR_HIP = 65,              /* any failing HIP runtime call; ~ VulkanCommandBufferExecutionFailed (gpu_utils.rs:129-135) */
+  CPIR_ERR_OUT_OF_DEVICE_MEMORY = 66, /* ~ VulkanBufferCreationFailed (gpu_utils.rs:102,116,153) */
+  CPIR_ERR_BUFFER_TOO_SMALL = 67, /* caller-provided output buffer too small (no reference analogue: Rust returns Vec) */
+  CPIR_ERR_INVALID_ARGUMENT = 68, /* NULL pointer / nonsensical size on the C side (unrepresentable in the Rust API) */
+  CPIR_ERR_SHARD_RANGE = 69       /* shard boundaries not aligned to the packing unit */
+} cpir_status;
+
+/* Static description of a status; never NULL. (Display impl, error.rs:51-100) */
+const char* cpir_strerror(int status);
+/* Text of the last failing HIP call on the calling thread ("" if none). */
+const char* cpir_last_hip_error(void);
+/* Library version string, e.g. "chalamet_hip 0.1.0 (gfx950)". */
+const char* cpir_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device context: replaces gpu_utils::setup_gpu() -> (Device, Queue, MemoryAllocator, CmdBufAllocator)
+ * (gpu_utils.rs:25-79).  Ref-counted; servers keep their device alive.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct cpir_device cpir_device;
+
+int cpir_device_count(int* count);
+int cpir_device_open(int ordinal, cpir_device** out);
+void cpir_device_close(cpir_device* dev);
+int cpir_device_ordinal(const cpir_device* dev, int* ordinal);
+int cpir_device_synchronize(cpir_device* dev);
+
+/* ------------------------------------------------------------------------------------------------
+ * Shape helpers (host-only arithmetic, no device needed).
+ * ------------------------------------------------------------------------------------------------ */
+/* compression factor of the packed DB for an element bit length: 2 (11..14), 3 (9..10), 4 (4..8); 0 = invalid
+ * (matrix.rs:103-167) */
+uint32_t cpir_compression_factor(uint32_t mat_elem_bit_len);
+/* Server::find_encoded_db_matrix_element_bit_length (server.rs:193-218) */
+int cpir_find_encoded_db_matrix_element_bit_length(uint64_t db_entry_count, uint32_t* mat_elem_bit_len);
+/* Filter shape for n keys: N = num_fingerprints (binary_fuse_filter.rs:52-67,261-276,519-538) */
+int cpir_filter_shape(uint32_t arity, uint64_t db_entry_count, uint32_t* segment_length,
+                      uint32_t* segment_count_length, uint64_t* num_fingerprints);
+/* C = cols of D for the longest value (matrix.rs:694-700) */
+uint64_t cpir_encoded_num_cols(uint64_t max_value_byte_len, uint32_t mat_elem_bit_len);
+/* Matrix::generate_from_seed (matrix.rs:541-558): TurboSHAKE128(seed || 0x1F) squeezed into rows*cols LE u32.
+ * Host-side, sequential by construction of the sponge. */
+int cpir_generate_from_seed(uint64_t rows, uint64_t cols, const uint8_t seed[CPIR_SEED_BYTE_LEN], uint32_t* out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Low-level device operations on caller-owned DEVICE pointers (what gpu_utils::mat_x_mat / mat_transpose and
+ * the two GLSL kernels provide, plus the respond mat-vec the reference only has on the CPU).
+ * The caller (e.g. a torch process) owns memory and stream; these only enqueue work.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* gpu_utils::mat_x_mat + shaders/mat_x_mat.glsl (gpu_utils.rs:156-220) == impl Mul for &Matrix (matrix.rs:1040-1059):
+ *   M[r][c] (+)= sum_k A[r][k] *wrap D[k][c],  A rows x inner (leading dim lda), D inner x cols (ldd), M rows x cols (ldm).
+ * rhs_max_bits: an upper bound on the bit width of every D entry (<= 16 selects the packed 16-bit dot-product
+ * kernel, 32 the general u32 kernel; results are identical whenever the bound is true).
+ * accumulate != 0 adds into M (used for K-sharded / row-block pipelined hints), else M is overwritten. */
+int cpir_op_mat_x_mat(cpir_device* dev, const uint32_t* A, uint64_t lda, const uint32_t* D, uint64_t ldd, uint32_t* M,
+                      uint64_t ldm, uint64_t rows, uint64_t inner, uint64_t cols, uint32_t rhs_max_bits, int accumulate,
+                      void* stream);
+
+/* Layout of the device-resident packed database ("DtC").  The logical content is exactly
+ * Matrix::transpose (matrix.rs:517-527) followed by Matrix::row_wise_compress (matrix.rs:98-205):
+ *   word(c, w) = sum_{j<cf} (D[cf*w + j][c] & (2^b - 1)) << (j * 32/cf),  missing tail fields = 0,
+ * stored row-major with the row stride padded to `words_per_row_padded` (zero words) and rows padded to
+ * `rows_padded` (zero rows) so every 16-byte load is aligned and no kernel needs a ragged tail. */
+typedef struct cpir_dtc_layout {
+  uint64_t num_slots;            /* N: filter slots = rows of D = decompressed columns of D^T (server.rs:66) */
+  uint32_t num_cols;             /* C: columns of D = rows of D^T = response length */
+  uint32_t mat_elem_bit_len;     /* b */
+  uint32_t compression_factor;   /* cf */
+  uint64_t words_per_row;        /* W = ceil(N / cf): the reference's compressed width */
+  uint64_t words_per_row_padded; /* row stride in u32 words, multiple of CPIR_DTC_WORD_ALIGN */
+  uint32_t rows_padded;          /* >= C, multiple of CPIR_DTC_ROW_ALIGN */
+  uint64_t total_words;          /* rows_padded * words_per_row_padded */
+} cpir_dtc_layout;
+#define CPIR_DTC_WORD_ALIGN 1024u
+#define CPIR_DTC_ROW_ALIGN 16u
+
+int cpir_dtc_layout_for(uint64_t num_slots, uint32_t num_cols, uint32_t mat_elem_bit_len, cpir_dtc_layout* out);
+
+/* gpu_utils::mat_transpose + shaders/mat_transpose.glsl (gpu_utils.rs:222-281) FUSED with the CPU
+ * Matrix::row_wise_compress the reference runs after reading the transpose back (server.rs:151-156):
+ * D (N x C, leading dim ldd, device) -> packed DtC (device, `layout->total_words` u32, fully written incl. padding).
+ * If `or_of_entries` (device u32) is non-NULL the bitwise OR of all D entries is OR-ed into it (lets the caller prove
+ * the rhs_max_bits bound it passes to cpir_op_mat_x_mat). */
+int cpir_op_transpose_compress(cpir_device* dev, const uint32_t* D, uint64_t ldd, const cpir_dtc_layout* layout,
+                               uint32_t* dtc, uint32_t* or_of_entries, void* stream);
+
+/* Inverse direction for import/export of the reference's own compressed matrix (C x W, row-major, as held in
+ * Server.compressed_transposed_parsed_db_mat_d, server.rs:18): pad/normalise into the device layout, and strip. */
+int cpir_op_dtc_import(cpir_device* dev, const uint32_t* compressed_rowmajor, const cpir_dtc_layout* layout, uint32_t* dtc,
+                       void* stream);
+int cpir_op_dtc_export(cpir_device* dev, const uint32_t* dtc, const cpir_dtc_layout* layout, uint32_t* compressed_rowmajor,
+                       void* stream);
+
+/* Matrix::row_vector_x_compressed_transposed_matrix (matrix.rs:328-485), the respond hot loop:
+ *   r[c] = sum_{n<N} q[n] *wrap field_{n mod cf}(word(c, n / cf)),  c < C.
+ * q: N u32 (device), r: C u32 (device), scratch: cpir_respond_scratch_words(layout) u32 (device).
+ * q_slot_offset/q_len describe a shard: this DtC holds slots [q_slot_offset, q_slot_offset + layout->num_slots) of a
+ * larger database and `q` points at the FULL query (q_len entries); pass 0 / layout->num_slots when unsharded. */
+uint64_t cpir_respond_scratch_words(const cpir_dtc_layout* layout);
+int cpir_op_respond(cpir_device* dev, const uint32_t* dtc, const cpir_dtc_layout* layout, const uint32_t* q,
+                    uint64_t q_len, uint64_t q_slot_offset, uint32_t* r, uint32_t* scratch, void* stream);
+/* Same contraction for `batch` queries in one pass over the database (q: batch x q_len, r: batch x C, row-major).
+ * Semantically `batch` independent cpir_op_respond calls. */
+uint64_t cpir_respond_batch_scratch_words(const cpir_dtc_layout* layout, uint32_t batch);
+int cpir_op_respond_batch(cpir_device* dev, const uint32_t* dtc, const cpir_dtc_layout* layout, const uint32_t* q,
+                          uint64_t q_len, uint64_t q_slot_offset, uint32_t batch, uint32_t* r, uint32_t* scratch,
+                          void* stream);
+
+/* Counter-based synthetic data (benchmarks / spot-checkable tests): out[i] = hi32(mix(seed, index0+i)) & mask. */
+int cpir_op_synth_fill(cpir_device* dev, uint32_t* out, uint64_t count, uint64_t seed, uint64_t index0, uint32_t mask,
+                       void* stream);
+/* Tuning knobs of the respond kernel (benchmark harness only; defaults are the measured best):
+ *   "respond.rows_per_unit" in {4, 8, 16}, "respond.nontemporal" {0,1}, "respond.blocks_per_cu" 0..8 (0 = occupancy API),
+ *   "respond.xcd_split" {0,1}.  Process-wide; results are bit-identical for every setting. */
+int cpir_tuning_set(const char* key, int value);
+/* Name of the dominant kernel last launched by cpir_op_respond for this layout (for matching rocprof traces). */
+const char* cpir_respond_kernel_name(const cpir_dtc_layout* layout);
+
+/* ------------------------------------------------------------------------------------------------
+ * Server handle: the device-resident replacement of `struct Server` (server.rs:15-21).
+ * Immutable after setup, ref-counted: Clone = cpir_server_retain, Drop = cpir_server_release.
+ * cpir_server_respond* are thread-safe and re-entrant on one handle (the reference's respond(&self) is called
+ * concurrently from many tokio tasks on an Arc<Server>: chalametpir_server/examples/server.rs:45,55,85).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct cpir_server cpir_server;
+
+/* The matrix half of Server::setup (server.rs:59-67 CPU build, server.rs:117-156 gpu build), from the encoded DB:
+ *   A = generate_from_seed(1774, N, seed_mu)   (pass pub_mat_a = NULL), or caller-supplied A (1774 x N, host)
+ *   hint = A * D            -> hint_out: 1774 x C u32 (host), i.e. hint_bytes without the 8-byte header
+ *   server = compress(transpose(D)) resident in HBM.
+ * D: N x C row-major u32 on the host.  mat_elem_bit_len as chosen by cpir_find_encoded_db_matrix_element_bit_length.
+ * The XOF expansion of A is pipelined in row blocks with H2D and the device matmul. */
+int cpir_server_setup(cpir_device* dev, const uint8_t seed_mu[CPIR_SEED_BYTE_LEN], const uint32_t* pub_mat_a,
+                      const uint32_t* D, uint64_t N, uint32_t C, uint32_t mat_elem_bit_len, uint32_t* hint_out,
+                      cpir_server** out);
+
+/* Full Server::setup::<ARITY>(seed_mu, db) (server.rs:47-78 / 103-167) from a key-value database handed over as flat
+ * arrays (the Rust shim flattens its HashMap<&[u8], &[u8]>): binary-fuse-filter construction, row encoding, hint,
+ * resident packed DB.  filter_seed_material: 32*max_attempts bytes of candidate filter seeds (the reference draws them
+ * from an OS-seeded ChaCha20, binary_fuse_filter.rs:100-106; NULL = draw from the OS here too).
+ * hint_bytes_out / filter_param_bytes_out receive the exact wire images the reference returns
+ * (hint: 8 + 4*1774*C bytes; filter params: 68 bytes, binary_fuse_filter.rs:462-486). */
+typedef struct cpir_kv_db {
+  uint64_t num_pairs;
+  const uint8_t* keys;      /* concatenated key bytes */
+  const uint64_t* key_off;  /* num_pairs + 1 offsets  */
+  const uint8_t* values;    /* concatenated value bytes */
+  const uint64_t* val_off;  /* num_pairs + 1 offsets  */
+} cpir_kv_db;
+#define CPIR_FILTER_PARAM_BYTE_LEN 68u
+int cpir_server_setup_kv(cpir_device* dev, uint32_t arity, const uint8_t seed_mu[CPIR_SEED_BYTE_LEN], const cpir_kv_db* db,
+                         const uint8_t* filter_seed_material, uint32_t max_attempts, uint8_t* hint_bytes_out,
+                         size_t hint_bytes_cap, size_t* hint_bytes_len, uint8_t filter_param_bytes_out[CPIR_FILTER_PARAM_BYTE_LEN],
+                         cpir_server** out);
+/* Host-only first half of Server::setup: Matrix::from_kv_database::<ARITY> (matrix.rs:633-648, binary_fuse_filter.rs:40-456,
+ * serialization.rs:22-116).  Writes D (N x C row-major, D_cap_words >= N*C from cpir_setup_kv_shape) and the 68-byte
+ * filter parameters.  No device involved. */
+int cpir_encode_kv_database(uint32_t arity, const cpir_kv_db* db, uint32_t mat_elem_bit_len, const uint8_t* filter_seed_material,
+                            uint32_t max_attempts, uint8_t filter_param_bytes_out[CPIR_FILTER_PARAM_BYTE_LEN], uint32_t* D_out,
+                            uint64_t D_cap_words, uint64_t* N, uint32_t* C);
+/* Sizes needed before calling cpir_server_setup_kv. */
+int cpir_setup_kv_shape(uint32_t arity, const cpir_kv_db* db, uint32_t* mat_elem_bit_len, uint64_t* N, uint32_t* C,
+                        size_t* hint_bytes_len);
+
+/* Build a server from matrices that already live on the device (multi-GPU shards, benchmarks):
+ * D_dev is N_shard x C (ldd) on `dev`; the shard holds global slots [slot_offset, slot_offset + N_shard) of a
+ * database with `total_slots` slots; slot_offset must be a multiple of the compression factor. */
+int cpir_server_from_device_matrix(cpir_device* dev, const uint32_t* D_dev, uint64_t ldd, uint64_t N_shard, uint32_t C,
+                                   uint32_t mat_elem_bit_len, uint64_t slot_offset, uint64_t total_slots, void* stream,
+                                   cpir_server** out);
+/* Build a server from the reference's own in-memory representation: compressed transposed matrix (C x ceil(N/cf), host),
+ * decompressed_num_cols = N, mat_elem_bit_len (the three fields of struct Server, server.rs:16-21). */
+int cpir_server_from_compressed(cpir_device* dev, const uint32_t* compressed, uint32_t C, uint64_t N, uint32_t mat_elem_bit_len,
+                                cpir_server** out);
+/* Copy the packed DB back in the reference's representation (C x ceil(N/cf) u32, host). */
+int cpir_server_export_compressed(const cpir_server* srv, uint32_t* compressed_out, uint64_t out_words);
+
+cpir_server* cpir_server_retain(cpir_server* srv);  /* #[derive(Clone)] (server.rs:15) */
+void cpir_server_release(cpir_server* srv);         /* Drop */
+int cpir_server_layout(const cpir_server* srv, cpir_dtc_layout* out);
+int cpir_server_shard(const cpir_server* srv, uint64_t* slot_offset, uint64_t* total_slots);
+const uint32_t* cpir_server_dtc_device_ptr(const cpir_server* srv);
+
+/* Server::respond(&self, query: &[u8]) -> Result<Vec<u8>, _> on wire bytes (server.rs:184-190):
+ * from_bytes validation (matrix.rs:973-1010) -> mat-vec -> to_bytes. response_cap >= 8 + 4*C. */
+int cpir_server_respond_bytes(const cpir_server* srv, const uint8_t* query, size_t query_len, uint8_t* response,
+                              size_t response_cap, size_t* response_len);
+/* Same on raw element arrays: q = query[8..] (q_rows x q_cols u32, host), r_out: C u32 (host).
+ * q_rows/q_cols are the header fields; anything but 1 x N is rejected as matrix.rs:329-331 does. */
+int cpir_server_respond(const cpir_server* srv, const uint32_t* q, uint32_t q_rows, uint64_t q_cols, uint32_t* r_out);
+/* Device-resident variant: q_dev (total_slots u32) and r_dev (C u32) on the server's device; enqueues on `stream`
+ * (NULL = default stream of the handle) and returns without synchronising.  For a shard, r_dev receives the shard's
+ * PARTIAL response; the caller sum-reduces partials across shards (u32 wrap-around add). `scratch_dev` must hold
+ * cpir_respond_scratch_words() u32, or NULL to use a per-stream scratch owned by the handle. */
+int cpir_server_respond_device(const cpir_server* srv, const uint32_t* q_dev, uint32_t* r_dev, uint32_t* scratch_dev,
+                               void* stream);
+int cpir_server_respond_batch_device(const cpir_server* srv, const uint32_t* q_dev, uint32_t batch, uint32_t* r_dev,
+                                     uint32_t* scratch_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHALAMET_HIP_H */

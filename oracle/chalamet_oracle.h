@@ -1,0 +1,233 @@
+/*
+ * chalamet_oracle.h -- CPU ORACLE for the ChalametPIR server hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's `cpu_baseline` leg may load it; the shipped HIP path
+ * (chalametpir_amd/, include/chalamet_hip.h) never links, imports or calls anything here.
+ *
+ * It is a plain-C restatement of the reference's (itzmeanjan/ChalametPIR v0.7.0, Rust) CPU
+ * algorithms for `Server::setup` / `Server::respond`; every function cites the reference
+ * file:line it follows (paths relative to the reference checkout):
+ *   matrix.rs        = chalametpir_common/src/matrix.rs
+ *   bff.rs           = chalametpir_common/src/binary_fuse_filter.rs
+ *   serialization.rs = chalametpir_common/src/serialization.rs
+ *   server.rs        = chalametpir_server/src/server.rs
+ *   client.rs        = chalametpir_client/src/client.rs
+ *
+ * PINNING STATUS (read DESIGN.md "Oracle"): the reference is Rust; there is no cargo/rustc in
+ * the build image, so the reference itself cannot be run here and oracle/_ref does not exist.
+ * The reference's own tests hold NO fixed golden vectors (all are OS-seeded property tests).
+ * The oracle is therefore pinned by (1) a one-for-one restatement of every reference property
+ * test on this path (tests/test_oracle_*.py), (2) the byte sizes the reference README states for
+ * the 2^20 x (32 B, 1 kB) database (hint 6 670 248 B, query 4 718 600 / 4 521 992 B, response
+ * 3 768 B, filter 68 B), (3) RFC 9861 known-answer vectors for the third-party XOF
+ * (`turboshake = "=0.4.1"`, not vendored in the reference), and (4) an end-to-end
+ * client-decodes-the-value restatement of integrations/src/test_pir.rs.  It is NOT pinned by
+ * outputs of the reference binary: by the task's definition that is "parity unpinned" with
+ * respect to reference-produced vectors.
+ *
+ * All element counts are 64-bit (the reference computes rows*cols in u32 and cannot run
+ * BASELINE configs 4-5).
+ */
+#ifndef CHALAMET_ORACLE_H
+#define CHALAMET_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Error codes: one per ChalametPIRError variant used on this path (error.rs:7-48). */
+enum {
+  OR_OK = 0,
+  OR_ERR_INVALID_MATRIX_DIMENSION = 1,                 /* error.rs:25 */
+  OR_ERR_INCOMPATIBLE_DIM_MATMUL = 2,                  /* error.rs:26 */
+  OR_ERR_INCOMPATIBLE_DIM_MATADD = 3,                  /* error.rs:27 */
+  OR_ERR_INVALID_NUMBER_OF_ELEMENTS = 4,               /* error.rs:28 */
+  OR_ERR_INCOMPATIBLE_DIM_ROWVEC_X_TRANSPOSED = 5,     /* error.rs:29 */
+  OR_ERR_INVALID_DIMENSION_FOR_VECTOR = 6,             /* error.rs:30 */
+  OR_ERR_FAILED_TO_DESERIALIZE_MATRIX = 7,             /* error.rs:31 */
+  OR_ERR_EMPTY_KV_DATABASE = 8,                        /* error.rs:34 */
+  OR_ERR_EXHAUSTED_ATTEMPTS_3WISE = 9,                 /* error.rs:35 */
+  OR_ERR_EXHAUSTED_ATTEMPTS_4WISE = 10,                /* error.rs:36 */
+  OR_ERR_ROW_NOT_DECODABLE = 11,                       /* error.rs:37 */
+  OR_ERR_DECODED_ROW_NOT_PREPENDED_WITH_DIGEST = 12,   /* error.rs:38 */
+  OR_ERR_FAILED_TO_DESERIALIZE_FILTER = 13,            /* error.rs:39 */
+  OR_ERR_KV_DATABASE_SIZE_TOO_LARGE = 14,              /* error.rs:42 */
+  OR_ERR_INVALID_HINT_MATRIX = 15,                     /* error.rs:43 */
+  OR_ERR_ARITHMETIC_OVERFLOW_ADDING_QUERY_INDICATOR = 16, /* error.rs:46 */
+  OR_ERR_UNSUPPORTED_ARITY = 17,                       /* error.rs:47 */
+  OR_ERR_INVALID_RESPONSE_VECTOR = 18,                 /* error.rs:48 */
+  OR_ERR_IMPOSSIBLE_ELEMENT_BIT_LENGTH = 19,           /* error.rs:49 */
+  OR_ERR_BUFFER_TOO_SMALL = 100                        /* oracle-only: caller buffer too small */
+};
+
+#define OR_LWE_DIMENSION 1774u          /* params.rs:1  */
+#define OR_SEED_BYTE_LEN 32u            /* params.rs:5  */
+#define OR_HASHED_KEY_BYTE_LEN 32u      /* params.rs:6  */
+#define OR_MAX_ATTEMPT_COUNT 100u       /* params.rs:10 */
+#define OR_MIN_CIPHER_TEXT_BIT_LEN 4u   /* params.rs:14 */
+#define OR_MAX_CIPHER_TEXT_BIT_LEN 14u  /* params.rs:17 */
+
+/* ---- third-party XOF: TurboSHAKE128 (RFC 9861), the reference's `turboshake =0.4.1` dep ---- */
+typedef struct {
+  uint64_t s[25];
+  unsigned pos;       /* absorb: bytes absorbed in current block; squeeze: bytes already read */
+  int squeezing;
+} or_turboshake128;
+void or_ts128_init(or_turboshake128* st);
+void or_ts128_absorb(or_turboshake128* st, const uint8_t* in, size_t len);
+void or_ts128_finalize(or_turboshake128* st, uint8_t domain_sep); /* reference uses 0x1F */
+void or_ts128_squeeze(or_turboshake128* st, uint8_t* out, size_t len);
+/* one-shot */
+void or_turboshake128_hash(const uint8_t* msg, size_t mlen, uint8_t domain_sep, uint8_t* out, size_t olen);
+
+/* ---- Matrix (matrix.rs) : row-major u32, (r,c) -> elems[r*cols + c] (matrix.rs:26-31,1013-1029) ---- */
+
+/* compression factor for an element bit length: 2 (b 11..14), 3 (b 9..10), 4 (b 4..8); 0 if b invalid.
+ * matrix.rs:103-167 */
+unsigned or_compression_factor(unsigned mat_elem_bit_len);
+
+/* matrix.rs:541-558  A = TurboSHAKE128(seed || D=0x1F) squeezed into rows*cols LE u32 */
+int or_generate_from_seed(uint64_t rows, uint64_t cols, const uint8_t seed[32], uint32_t* out);
+
+/* matrix.rs:1040-1059  res[r][c] = sum_k lhs[r][k] *w rhs[k][c]  (wrapping), OpenMP over outputs */
+int or_mul(const uint32_t* lhs, uint64_t lrows, uint64_t lcols,
+           const uint32_t* rhs, uint64_t rrows, uint64_t rcols, uint32_t* out);
+
+/* matrix.rs:1070-1086 */
+int or_add(const uint32_t* lhs, uint64_t lrows, uint64_t lcols,
+           const uint32_t* rhs, uint64_t rrows, uint64_t rcols, uint32_t* out);
+
+/* matrix.rs:517-527  out[c][r] = in[r][c] */
+int or_transpose(const uint32_t* in, uint64_t rows, uint64_t cols, uint32_t* out);
+
+/* matrix.rs:498-510 */
+int or_identity(uint64_t rows, uint32_t* out);
+
+/* matrix.rs:98-205   out is rows x ceil(cols/cf) */
+int or_row_wise_compress(const uint32_t* in, uint64_t rows, uint64_t cols, unsigned mat_elem_bit_len, uint32_t* out);
+
+/* matrix.rs:207-316  in is rows x ceil(num_cols/cf); out is rows x num_cols */
+int or_row_wise_decompress(const uint32_t* in, uint64_t rows, uint64_t in_cols, unsigned mat_elem_bit_len,
+                           uint64_t num_cols, uint32_t* out);
+
+/* matrix.rs:328-485  respond mat-vec: q is q_rows x q_cols (must be 1 x decompressed_num_cols),
+ * rhs is the compressed transposed DB (rhs_rows x rhs_cols), out is 1 x rhs_rows. OpenMP over outputs. */
+int or_row_vector_x_compressed_transposed_matrix(const uint32_t* q, uint64_t q_rows, uint64_t q_cols,
+                                                 const uint32_t* rhs, uint64_t rhs_rows, uint64_t rhs_cols,
+                                                 uint64_t decompressed_num_cols, unsigned mat_elem_bit_len,
+                                                 uint32_t* out);
+
+/* matrix.rs:947-971  [rows u32 LE][cols u32 LE][rows*cols u32 LE]; returns byte length via *out_len. */
+size_t or_matrix_num_bytes(uint64_t rows, uint64_t cols);
+int or_matrix_to_bytes(const uint32_t* elems, uint32_t rows, uint32_t cols, uint8_t* out, size_t out_cap);
+/* matrix.rs:973-1010  validates and returns dims; *elems_off = 8 on success */
+int or_matrix_from_bytes(const uint8_t* bytes, size_t len, uint32_t* rows, uint32_t* cols);
+
+/* ---- Server (server.rs) ---- */
+
+/* server.rs:193-218 */
+int or_find_encoded_db_matrix_element_bit_length(uint64_t db_entry_count, unsigned* bit_len);
+
+/* server.rs:184-190  respond on wire bytes against a compressed transposed DB. */
+int or_server_respond(const uint32_t* dtc, uint64_t dtc_rows, uint64_t dtc_cols, uint64_t decompressed_num_cols,
+                      unsigned mat_elem_bit_len, const uint8_t* query, size_t query_len,
+                      uint8_t* response, size_t response_cap, size_t* response_len);
+
+/* server.rs:59-67 from an already-encoded D (N x C): hint = A(seed) * D, DtC = compress(transpose(D)).
+ * hint is 1774 x C, dtc is C x ceil(N/cf). (A is regenerated internally from seed_mu.) */
+int or_server_setup_from_matrix(const uint8_t seed_mu[32], const uint32_t* D, uint64_t N, uint64_t C,
+                                unsigned mat_elem_bit_len, uint32_t* hint, uint32_t* dtc);
+
+/* ---- Binary fuse filter (bff.rs) ---- */
+typedef struct {
+  uint8_t seed[32];
+  uint32_t arity;
+  uint32_t segment_length;
+  uint32_t segment_count_length;
+  uint64_t num_fingerprints;
+  uint64_t filter_size;
+  uint64_t mat_elem_bit_len;
+} or_bff;
+
+/* bff.rs:519-538 */
+uint32_t or_bff_segment_length(uint32_t arity, uint32_t size);
+double or_bff_size_factor(uint32_t arity, uint32_t size);
+/* bff.rs:52-67 / 261-276: shape of the filter for db_size keys */
+int or_bff_shape(uint32_t arity, uint64_t db_size, uint32_t* segment_length, uint32_t* segment_count_length,
+                 uint64_t* num_fingerprints);
+/* bff.rs:553-601 */
+uint64_t or_murmur64(uint64_t h);
+uint64_t or_mix(uint64_t key, uint64_t seed);
+void or_hash_of_key(const uint8_t* key, size_t key_len, uint64_t out[4]);
+uint64_t or_mix256(const uint64_t key[4], const uint8_t seed[32]);
+/* bff.rs:605-635 */
+void or_hash_batch_3(uint64_t hash, uint32_t segment_length, uint32_t segment_count_length, uint32_t h[3]);
+void or_hash_batch_4(uint64_t hash, uint32_t segment_length, uint32_t segment_count_length, uint32_t h[4]);
+/* bff.rs:462-513  68-byte parameter blob */
+#define OR_BFF_BYTE_LEN 68u
+void or_bff_to_bytes(const or_bff* f, uint8_t out[OR_BFF_BYTE_LEN]);
+int or_bff_from_bytes(const uint8_t* bytes, size_t len, or_bff* f);
+
+/* A key-value database handed over as flat arrays (the reference takes HashMap<&[u8], &[u8]>; its
+ * iteration order and the OS-seeded filter seed make D non-reproducible run to run, bff.rs:100-112,
+ * so the oracle takes an explicit key order and an explicit sequence of candidate filter seeds). */
+typedef struct {
+  uint64_t num_pairs;
+  const uint8_t* keys;        /* concatenated key bytes   */
+  const uint64_t* key_off;    /* num_pairs+1 offsets      */
+  const uint8_t* values;      /* concatenated value bytes */
+  const uint64_t* val_off;    /* num_pairs+1 offsets      */
+} or_kv_db;
+
+/* matrix.rs:633-648,687-755,819-894 + bff.rs:40-235,249-456.
+ * filter_seeds: max_attempts candidate 32-byte seeds tried in order (reference draws them from ChaCha20/OS).
+ * On success: *out_filter filled, D (num_fingerprints x cols) written to `mat` (caller sized via
+ * or_bff_shape + or_encoded_num_cols), and *attempts_used set. */
+uint64_t or_encoded_num_cols(uint64_t max_value_byte_len, unsigned mat_elem_bit_len); /* matrix.rs:694-700 */
+int or_from_kv_database(uint32_t arity, const or_kv_db* db, unsigned mat_elem_bit_len,
+                        const uint8_t* filter_seeds, uint32_t max_attempts,
+                        or_bff* out_filter, uint32_t* mat, uint64_t mat_rows, uint64_t mat_cols,
+                        uint32_t* attempts_used);
+/* matrix.rs:661-673,768-805,907-945 (test-only in the reference): recover a value straight from D */
+int or_recover_value(const uint32_t* mat, uint64_t mat_rows, uint64_t mat_cols, const or_bff* filter,
+                     const uint8_t* key, size_t key_len, uint8_t* value, size_t value_cap, size_t* value_len);
+
+/* ---- row codec (serialization.rs) ---- */
+/* serialization.rs:22-116 */
+void or_encode_kv_as_row(const uint8_t* key, size_t key_len, const uint8_t* value, size_t value_len,
+                         unsigned mat_elem_bit_len, uint64_t num_cols, uint32_t* row);
+/* serialization.rs:132-184  out receives hashed-key(32) || value; out_cap >= num_cols*b/8 */
+int or_decode_kv_from_row(const uint32_t* row, uint64_t num_cols, unsigned mat_elem_bit_len,
+                          uint8_t* out, size_t out_cap, size_t* out_len);
+
+/* ---- Client (client.rs), for the end-to-end check only ---- */
+/* client.rs:95-194: b = s*A + e (+ indicator at the key's filter slots); c = s*M.
+ * secret (1774) and error (N) are ternary vectors {0,1,0xFFFFFFFF} supplied by the caller
+ * (the reference samples them from an OS-seeded ChaCha8, matrix.rs:572-619). */
+int or_client_query(const uint32_t* A /*1774 x N*/, const uint32_t* hint /*1774 x C*/, uint64_t N, uint64_t C,
+                    const or_bff* filter, const uint8_t* key, size_t key_len,
+                    const uint32_t* secret_s, const uint32_t* error_e,
+                    uint32_t* query_b /*N*/, uint32_t* secret_c /*C*/);
+/* client.rs:209-275 */
+int or_client_process_response(const or_bff* filter, const uint8_t* key, size_t key_len,
+                               const uint32_t* secret_c, const uint32_t* response, uint64_t C,
+                               uint8_t* value, size_t value_cap, size_t* value_len);
+/* matrix.rs:572-619 mapping of one u32 draw to {0,1,-1}; returns 0 if the draw must be rejected */
+int or_ternary_from_u32(uint32_t val, uint32_t* out);
+
+/* ---- synthetic inputs shared by tests/bench (not in the reference) ---- */
+/* counter-based generator: splitmix64 finaliser of (seed, index); identical to the device generator
+ * in chalametpir_amd/csrc/synth.hip so tiles can be regenerated on either side. */
+uint64_t or_synth_u64(uint64_t seed, uint64_t index);
+void or_synth_fill_u32(uint32_t* out, uint64_t count, uint64_t seed, uint64_t index0, uint32_t mask);
+
+int or_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
