@@ -1,0 +1,312 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the ChalametPIR server hot path on MI355X.
+
+Metric (BASELINE.json): `server_respond` queries/sec + achieved HBM GB/s on the 2^20-key x 1 kB database (3-wise filter:
+N = 1 179 648 slots, C = 940 columns, b = 9 bits, 3 fields per packed u32), and `server_setup` wall seconds.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one batch of `--queries-per-step` distinct synthetic queries; every query is an independent
+Server::respond: one full pass of the respond kernel over the packed database resident in HBM (inputs already in HBM
+when the timed region starts).  For N > 1 (one process per GPU, launched by torch.distributed.run) the database is
+sharded along the filter-slot axis, every rank streams its shard, and the per-shard partial responses of the step's
+queries are sum-reduced with ONE RCCL all-reduce per step (u32 wrap-around, bit-exact for any order).  Total work is
+fixed as N grows => "scaling": "strong".
+
+Rank 0 prints ONE JSON line.  `roofline` describes the respond kernel against the HBM roof (8 TB/s,
+/opt/skills/guides/MI355X_MICROARCH.md); `cpu_baseline` is the test oracle's restatement of the reference CPU path
+(oracle/, kind "port": the Rust reference cannot be built in this image) timed on this box's host cores on the same
+database and queries, and it doubles as a full-size bit-exact parity check of the GPU results.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip table); 6290 GB/s is the measured copy ceiling
+
+CONFIGS = {
+    # name: (n keys, arity, value bytes)      -- BASELINE.json configs[1..4]
+    "cfg2": (1 << 20, 3, 1024),
+    "cfg3": (1 << 20, 4, 1024),
+    "cfg4": (1 << 22, 3, 1024),
+    "cfg5": (1 << 20, 3, 8192),
+    "cfg1": (1 << 16, 3, 1024),
+    "tiny": (1 << 12, 3, 64),
+}
+
+SEED_D, SEED_Q = 0xD, 0x1000
+SEED_MU = bytes(range(32))
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--queries-per-step", type=int, default=16)
+    ap.add_argument("--query-pool", type=int, default=64, help="distinct queries cycled through (no query-side caching)")
+    ap.add_argument("--no-setup", action="store_true", help="skip the server_setup timing (needs A: 8.4 GB at cfg2, ~10 s of host XOF)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
+    ap.add_argument("--tune", default="", help="comma list key=value for cpir_tuning_set, e.g. respond.rows_per_unit=16")
+    ap.add_argument("--sweep", action="store_true", help="time every respond kernel variant (stderr table) before the run")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import chalametpir_amd as cp
+    from chalametpir_amd.distributed import ShardedServer, shard_range
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = cp.Device(local_rank)
+    for kv in filter(None, args.tune.split(",")):
+        k, v = kv.split("=")
+        cp.tuning_set(k, int(v))
+
+    n_keys, arity, value_bytes = CONFIGS[args.config]
+    b = cp.find_encoded_db_matrix_element_bit_length(n_keys)
+    _, _, N = cp.filter_shape(arity, n_keys)
+    C = cp.encoded_num_cols(value_bytes, b)
+    cf = 2 if b >= 11 else (3 if b >= 9 else 4)
+    W = -(-N // cf)
+    mask = (1 << b) - 1
+    stream = torch.cuda.current_stream()
+
+    # ---- this rank's shard of the synthetic encoded DB, generated in HBM, packed, and D freed ---------------------------
+    lo, hi = shard_range(N, cf, rank, world)
+    t0 = time.time()
+    D_dev = torch.empty(((hi - lo), C), dtype=torch.int32, device="cuda")
+    if hi > lo:
+        device.synth_fill(D_dev, (hi - lo) * C, SEED_D, index0=lo * C, mask=mask, stream=stream)
+    sharded = ShardedServer.from_device_matrix(D_dev, lo, hi, C, b, N, device, stream=stream)
+    torch.cuda.synchronize()
+    del D_dev
+    torch.cuda.empty_cache()
+    pack_seconds = time.time() - t0
+
+    pool = args.query_pool
+    q_pool = torch.empty((pool, N), dtype=torch.int32, device="cuda")
+    for i in range(pool):
+        device.synth_fill(q_pool, N, SEED_Q + i, offset_words=i * N, stream=stream)
+    qps_step = args.queries_per_step
+    r_step = torch.zeros((qps_step, C), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+
+    step_counter = [0]
+
+    def run_step():
+        base = (step_counter[0] * qps_step) % pool
+        step_counter[0] += 1
+        for j in range(qps_step):
+            sharded.respond_partial_device(q_pool[(base + j) % pool], r_step[j], stream=stream)
+        if world > 1:
+            dist.all_reduce(r_step)  # int32 sum == u32 wrap-around sum; one collective for the step's queries
+
+    if args.sweep and rank == 0:
+        sweep(cp, torch, run_step, qps_step)
+
+    for _ in range(args.warmup):
+        run_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t_begin = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        run_step()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_begin
+    kernel_region_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the respond kernels run on
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    n_queries = args.steps * qps_step
+    qps = n_queries / elapsed
+    # algorithmic bytes of ONE respond launch on this rank: packed shard read once + the query slice + the response
+    W_shard = -(-(hi - lo) // cf) if hi > lo else 0
+    launch_bytes = 4 * C * W_shard + 4 * (hi - lo) + 4 * C
+    full_bytes = 4 * C * W + 4 * N + 4 * C
+    launch_us = kernel_region_ms * 1e3 / n_queries
+    achieved = launch_bytes / (launch_us * 1e-6) / 1e9 if launch_us > 0 else 0.0
+
+    result = {
+        "metric": "server_respond_queries_per_sec",
+        "value": round(qps, 2),
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.config}: 2^{n_keys.bit_length() - 1} keys, 32 B key / {value_bytes} B value, {arity}-wise XOR BFF; "
+                        f"encoded DB N={N} x C={C}, b={b}, {cf} fields/u32, packed D^T {4 * C * W / 1e9:.3f} GB",
+            "queries_per_step": qps_step,
+            "query_pool": pool,
+            "sharding": f"N split over {world} GPU(s), one all-reduce of {qps_step}x{C} u32 per step" if world > 1 else "single GPU",
+        },
+        "achieved_hbm_GBps_whole_job": round(full_bytes * qps / 1e9, 1),
+        "algorithmic_bytes_per_query": full_bytes,
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "respond_kernel",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "traffic": None,
+            "launch_us": round(launch_us, 2),
+            "bytes_per_launch": launch_bytes,
+            "mall_resident": bool(launch_bytes <= 256 * (1 << 20)),
+        },
+        "pack_seconds": round(pack_seconds, 3),
+    }
+
+    if rank == 0 and world == 1:
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(sharded.local, q_pool, r_step, N, C, b, full_bytes, args.cpu_seconds, torch, stream)
+        if not args.no_setup:
+            result.update(setup_timing(cp, device, torch, sharded, N, C, b, mask, stream))
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    return 0
+
+
+def sweep(cp, torch, run_step, qps_step):
+    """time each respond kernel variant (one process, interleaved rounds) -- tuning aid, output on stderr"""
+    variants = [(R, nt, bpc) for R in (4, 8, 16) for nt in (0, 1) for bpc in (0, 2, 4)]
+    best = {}
+    for rnd in range(3):
+        for R, nt, bpc in variants:
+            cp.tuning_set("respond.rows_per_unit", R)
+            cp.tuning_set("respond.nontemporal", nt)
+            cp.tuning_set("respond.blocks_per_cu", bpc)
+            run_step()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                run_step()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / (3 * qps_step)
+            best[(R, nt, bpc)] = min(best.get((R, nt, bpc), 1e30), us)
+    for k, us in sorted(best.items(), key=lambda kv: kv[1]):
+        log(f"sweep R={k[0]:2d} nt={k[1]} blocks/CU={k[2]}: {us:8.1f} us/query")
+    R, nt, bpc = min(best, key=best.get)
+    cp.tuning_set("respond.rows_per_unit", R)
+    cp.tuning_set("respond.nontemporal", nt)
+    cp.tuning_set("respond.blocks_per_cu", bpc)
+    log(f"sweep: using R={R} nt={nt} blocks/CU={bpc}")
+
+
+def cpu_baseline(server, q_pool, r_step, N, C, b, full_bytes, budget_s, torch, stream):
+    """Oracle (C restatement of the reference's rayon CPU path, matrix.rs:328-485) on this box's host cores, same DB and
+    queries; every CPU result is compared bit-for-bit with the GPU result of the same query."""
+    from oracle import oracle as orc  # checker / baseline only
+
+    dtc = server.export_compressed()
+    orc.lib()
+    n_done, t_total, mismatches = 0, 0.0, 0
+    i = 0
+    while t_total < budget_s and n_done < 400:
+        q = q_pool[i % q_pool.shape[0]]
+        qh = q.cpu().numpy().view(np.uint32)
+        t0 = time.perf_counter()
+        want = orc.row_vector_x_compressed_transposed_matrix(qh, dtc, N, b)[0]
+        t_total += time.perf_counter() - t0
+        server.respond_device(q, r_step[0], stream=stream)
+        torch.cuda.synchronize()
+        got = r_step[0].cpu().numpy().view(np.uint32)
+        mismatches += int(not np.array_equal(got, want))
+        n_done += 1
+        i += 1
+    cpu_qps = n_done / t_total
+    return {
+        "value": round(cpu_qps, 3),
+        "unit": "queries/s",
+        "cores": orc.num_threads(),
+        "kind": "port",
+        "sample": f"{n_done} full-size queries on the same packed DB ({full_bytes / 1e9:.3f} GB/query), OpenMP over the C outputs like the reference's rayon loop",
+        "GBps": round(full_bytes * cpu_qps / 1e9, 1),
+        "gpu_results_bit_exact": mismatches == 0,
+        "queries_compared": n_done,
+    }
+
+
+def setup_timing(cp, device, torch, sharded, N, C, b, mask, stream):
+    """server_setup wall seconds from (seed_mu, encoded D on the host): XOF expansion of A (host) || D upload + pack,
+    hint matmul, hint download -- Server::setup minus the KV encoder (reference server.rs:59-67)."""
+    D_dev = torch.empty((N, C), dtype=torch.int32, device="cuda")
+    device.synth_fill(D_dev, N * C, SEED_D, mask=mask, stream=stream)
+    torch.cuda.synchronize()
+    D_host = D_dev.cpu().numpy().view(np.uint32)
+    del D_dev
+    torch.cuda.empty_cache()
+    t0 = time.perf_counter()
+    srv, hint = cp.Server.setup_from_matrix(SEED_MU, D_host, b, device=device)
+    wall = time.perf_counter() - t0
+    phases = srv.setup_timings()
+    # cheap integrity check: both servers hold the same packed DB => same response
+    q = torch.empty(N, dtype=torch.int32, device="cuda")
+    device.synth_fill(q, N, 0xABCDEF, stream=stream)
+    r1 = torch.empty(C, dtype=torch.int32, device="cuda")
+    r2 = torch.empty(C, dtype=torch.int32, device="cuda")
+    srv.respond_device(q, r1, stream=stream)
+    sharded.local.respond_device(q, r2, stream=stream)
+    torch.cuda.synchronize()
+    same = bool(torch.equal(r1, r2))
+    macs = 1774 * N * C
+    return {
+        "server_setup_wall_sec": round(wall, 3),
+        "server_setup_phases_sec": {k: round(v, 4) for k, v in phases.items()},
+        "server_setup_note": "setup(seed_mu, encoded D on host): A expanded by TurboSHAKE128 on one host core (sequential sponge) "
+                             "overlapped with D upload + transpose/pack; then one hint matmul launch",
+        "hint_matmul_TMACs_per_s": round(macs / max(phases["hint_matmul"], 1e-9) / 1e12, 2),
+        "setup_db_matches_bench_db": same,
+        "hint_checksum": int(hint.sum(dtype=np.uint64) & 0xFFFFFFFFFFFFFFFF),
+    }
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -7,6 +7,7 @@ usable every compute entry point returns CPIR_ERR_NO_DEVICE / CPIR_ERR_HIP, surf
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
 import subprocess
 
@@ -90,6 +91,7 @@ SIGNATURES = {
                                                  C.POINTER(vp)]),
     "cpir_server_from_compressed": (C.c_int, [vp, u32p, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(vp)]),
     "cpir_server_export_compressed": (C.c_int, [vp, u32p, C.c_uint64]),
+    "cpir_server_setup_timings": (C.c_int, [vp, C.POINTER(C.c_double)]),
     "cpir_server_retain": (vp, [vp]),
     "cpir_server_release": (None, [vp]),
     "cpir_server_layout": (C.c_int, [vp, C.POINTER(DtcLayout)]),
@@ -112,10 +114,31 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
+def _preload_torch_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so (same SONAME
+    as the system ROCm ones).  If this library pulled in the system runtime first and torch then loaded its bundled HSA
+    runtime, the process would hold two runtimes and torch would report "No HIP GPUs are available"; device pointers and
+    streams could not be shared either.  So when torch is installed its bundled runtime is loaded first and
+    libchalamet_hip.so binds to it by SONAME.  Without torch (a C / Rust host) the system ROCm runtime is used.
+    CPIR_HIP_RUNTIME=system skips the preload."""
+    if os.environ.get("CPIR_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """dlopen libchalamet_hip.so and type every entry point.  Raises if the library is not built: fail loudly."""
     global _lib
     if _lib is None:
+        _preload_torch_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `make -C {CSRC_DIR}` (or __graft_entry__.build()). "

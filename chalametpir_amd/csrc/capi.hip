@@ -1,6 +1,7 @@
 // capi.hip -- the extern "C" boundary of libchalamet_hip.so (include/chalamet_hip.h): device context, the device-resident
 // Server handle, and the host-side orchestration of Server::setup / Server::respond
 // (reference chalametpir_server/src/server.rs:47-78, 103-167, 184-190).
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <memory>
@@ -39,6 +40,7 @@ struct Server {
   uint32_t* dtc = nullptr;  // device, layout.total_words u32
   uint64_t slot_offset = 0;
   uint64_t total_slots = 0;
+  double setup_timings[CPIR_SETUP_TIMING_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
 
   // pool of per-call resources so respond(&self) is re-entrant (reference: Arc<Server> shared by many tokio tasks)
   std::mutex mu;
@@ -46,6 +48,10 @@ struct Server {
   std::vector<std::unique_ptr<RespondSlot>> slots;
   static constexpr size_t kMaxSlots = 8;
 };
+
+static double now_seconds() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 static void device_retain(Device* d) { d->refs.fetch_add(1); }
 static void device_release(Device* d) {
@@ -178,6 +184,8 @@ class PublicMatrixUpload {
     return CPIR_OK;
   }
 
+  double xof_seconds() const { return xof_seconds_; }
+
   // wait until all of A is in HBM
   int finish(const uint32_t** A_dev) {
     join();
@@ -203,7 +211,9 @@ class PublicMatrixUpload {
     for (uint64_t r0 = 0; r0 < rows; r0 += rows_per_block_, buf ^= 1) {
       const uint64_t rb = (rows - r0 < rows_per_block_) ? rows - r0 : rows_per_block_;
       if (used[buf]) CPIR_HIP_TRY(hipEventSynchronize(ev_[buf]));  // staging buffer free again?
+      const double t0 = now_seconds();
       xof.squeeze(reinterpret_cast<uint8_t*>(pinned_[buf]), (size_t)rb * N_ * 4);  // matrix.rs:546-555: row-major LE u32
+      xof_seconds_ += now_seconds() - t0;
       CPIR_HIP_TRY(hipMemcpyAsync(A_dev_ + r0 * N_, pinned_[buf], (size_t)rb * N_ * 4, hipMemcpyHostToDevice, copy_stream_));
       CPIR_HIP_TRY(hipEventRecord(ev_[buf], copy_stream_));
       used[buf] = true;
@@ -221,6 +231,7 @@ class PublicMatrixUpload {
   uint8_t seed_[32];
   std::thread worker_;
   int status_ = CPIR_OK;
+  double xof_seconds_ = 0;
 };
 
 struct DevBuf {  // scoped device allocation
@@ -246,23 +257,36 @@ static int setup_from_host_matrix(Device* dev, PublicMatrixUpload& upA, const ui
 #define TRY_(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_last_hip_error(_e, #e, __FILE__, __LINE__); \
     return fail(_e == hipErrorOutOfMemory ? CPIR_ERR_OUT_OF_DEVICE_MEMORY : CPIR_ERR_HIP); } } while (0)
   TRY_(hipMalloc(&srv->dtc, (size_t)L.total_words * 4));
+  double t0 = now_seconds();
   TRY_(hipMemcpyAsync(D_dev.p, D, (size_t)N * C * 4, hipMemcpyHostToDevice, stream));
+  TRY_(hipStreamSynchronize(stream));
+  srv->setup_timings[2] = now_seconds() - t0;
+  t0 = now_seconds();
   TRY_(hipMemsetAsync(flag.p, 0, 4, stream));
   int st = launch_transpose_compress(dev, (const uint32_t*)D_dev.p, C, L, srv->dtc, (uint32_t*)flag.p, stream);
   if (st != CPIR_OK) return fail(st);
   uint32_t ored = 0;
   TRY_(hipMemcpyAsync(&ored, flag.p, 4, hipMemcpyDeviceToHost, stream));
   TRY_(hipStreamSynchronize(stream));
+  srv->setup_timings[3] = now_seconds() - t0;
   // the hint uses the UNMASKED entries of D (server.rs:61 multiplies before any masking); the packed-16 kernel is
   // exact only if every entry is < 2^16, which holds for every encoded DB (entries < 2^b <= 2^14) and is verified here
   const uint32_t rhs_bits = (ored >> 16) ? 32u : 16u;
   const uint32_t* A_dev = nullptr;
+  t0 = now_seconds();
   st = upA.finish(&A_dev);
   if (st != CPIR_OK) return fail(st);
+  srv->setup_timings[4] = now_seconds() - t0;
+  srv->setup_timings[1] = upA.xof_seconds();
+  t0 = now_seconds();
   st = launch_mat_x_mat(dev, A_dev, N, (const uint32_t*)D_dev.p, C, (uint32_t*)M_dev.p, C, CPIR_LWE_DIMENSION, N, C, rhs_bits, 0, stream);
   if (st != CPIR_OK) return fail(st);
+  TRY_(hipStreamSynchronize(stream));
+  srv->setup_timings[5] = now_seconds() - t0;
+  t0 = now_seconds();
   TRY_(hipMemcpyAsync(hint_out, M_dev.p, (size_t)CPIR_LWE_DIMENSION * C * 4, hipMemcpyDeviceToHost, stream));
   TRY_(hipStreamSynchronize(stream));
+  srv->setup_timings[6] = now_seconds() - t0;
 #undef TRY_
   *out = srv;
   return CPIR_OK;
@@ -462,11 +486,13 @@ int cpir_server_setup(cpir_device* dev, const uint8_t seed_mu[CPIR_SEED_BYTE_LEN
   *out = nullptr;
   if (N == 0 || C == 0) return CPIR_ERR_INVALID_MATRIX_DIMENSION;
   if (compression_factor(b) == 0) return CPIR_ERR_IMPOSSIBLE_ELEMENT_BIT_LENGTH;  // matrix.rs:99-101
+  const double t_begin = now_seconds();
   PublicMatrixUpload upA(dev, N);
   static const uint8_t zero_seed[32] = {0};
   CPIR_TRY(upA.start(seed_mu ? seed_mu : zero_seed, pub_mat_a));  // server.rs:59 (runs concurrently with the D work)
   Server* srv = nullptr;
   CPIR_TRY(setup_from_host_matrix(dev, upA, D, N, C, b, hint_out, &srv));
+  srv->setup_timings[7] = now_seconds() - t_begin;
   *out = static_cast<cpir_server*>(srv);
   return CPIR_OK;
 }
@@ -523,6 +549,7 @@ int cpir_server_setup_kv(cpir_device* dev, uint32_t arity, const uint8_t seed_mu
 
   // N is known from the key count alone, so the (sequential, seconds-long) XOF expansion of A starts right away and
   // overlaps the (also sequential) filter construction and row encoding below
+  const double t_begin = now_seconds();
   PublicMatrixUpload upA(dev, N);
   CPIR_TRY(upA.start(seed_mu, nullptr));
 
@@ -532,6 +559,7 @@ int cpir_server_setup_kv(cpir_device* dev, uint32_t arity, const uint8_t seed_mu
   uint32_t C2 = 0;
   CPIR_TRY(encode_kv_database(arity, *db, b, filter_seed_material, max_attempts, &filter, &D, &N2, &C2));  // server.rs:54
   if (N2 != N || C2 != C) return CPIR_ERR_INVALID_ARGUMENT;
+  const double t_encode = now_seconds() - t_begin;
 
   Server* srv = nullptr;
   // hint_bytes = Matrix::to_bytes(hint): [rows][cols][elems] (matrix.rs:947-971, server.rs:62)
@@ -541,6 +569,8 @@ int cpir_server_setup_kv(cpir_device* dev, uint32_t arity, const uint8_t seed_mu
   memcpy(hint_bytes_out + 4, &hc, 4);
   *hint_bytes_len = need;
   filter.to_bytes(filter_param_bytes_out);  // server.rs:63
+  srv->setup_timings[0] = t_encode;
+  srv->setup_timings[7] = now_seconds() - t_begin;
   *out = static_cast<cpir_server*>(srv);
   return CPIR_OK;
 }
@@ -608,6 +638,12 @@ int cpir_server_export_compressed(const cpir_server* srv, uint32_t* compressed_o
   CPIR_TRY(launch_dtc_export(srv->dev, srv->dtc, L, (uint32_t*)tmp.p, srv->dev->stream));
   CPIR_HIP_TRY(hipMemcpyAsync(compressed_out, tmp.p, (size_t)words * 4, hipMemcpyDeviceToHost, srv->dev->stream));
   CPIR_HIP_TRY(hipStreamSynchronize(srv->dev->stream));
+  return CPIR_OK;
+}
+
+int cpir_server_setup_timings(const cpir_server* srv, double out[CPIR_SETUP_TIMING_COUNT]) {
+  if (!srv || !out) return CPIR_ERR_INVALID_ARGUMENT;
+  memcpy(out, srv->setup_timings, sizeof(srv->setup_timings));
   return CPIR_OK;
 }
 

@@ -40,7 +40,7 @@ struct Device {
   std::atomic<int> refs{1};
   int ordinal = 0;
   int num_cus = 0;
-  hipStream_t stream = nullptr;  // the handle's own stream (used when the caller passes NULL)
+  hipStream_t stream = nullptr;  // the handle's own stream: used by the synchronous host-pointer entry points
 };
 
 // RAII "make this device current for the calling thread"
@@ -56,9 +56,9 @@ struct DeviceGuard {
   }
 };
 
-inline hipStream_t pick_stream(const Device* dev, void* stream) {
-  return stream ? reinterpret_cast<hipStream_t>(stream) : dev->stream;
-}
+// `stream` arguments of the C ABI are hipStream_t values; NULL is HIP's legacy default (null) stream -- which is also
+// what torch.cuda.current_stream().cuda_stream is when no stream context is active -- never "some other stream".
+inline hipStream_t pick_stream(const Device*, void* stream) { return reinterpret_cast<hipStream_t>(stream); }
 
 // ---- kernel launchers (defined in the .hip files) ---------------------------------------------
 // respond.hip

@@ -303,6 +303,14 @@ class Server:
     def response_len(self) -> int:
         return int(self.layout.num_cols)
 
+    SETUP_PHASES = ("encode", "xof_expand_A", "D_h2d", "transpose_compress", "wait_for_A", "hint_matmul", "hint_d2h", "total")
+
+    def setup_timings(self) -> dict:
+        """wall-clock split (seconds) of the setup call that built this server"""
+        out = (C.c_double * 8)()
+        _check(self._lib.cpir_server_setup_timings(self._h, out))
+        return dict(zip(self.SETUP_PHASES, [float(x) for x in out]))
+
     def export_compressed(self) -> np.ndarray:
         """compressed_transposed_parsed_db_mat_d in the reference's layout (C x ceil(N/cf)) (server.rs:18)"""
         out = np.empty((self.layout.num_cols, self.layout.words_per_row), dtype=np.uint32)

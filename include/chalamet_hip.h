@@ -15,7 +15,7 @@
  *   - matrices are row-major u32, (r,c) -> elems[r*cols + c]                         (matrix.rs:26-31,1013-1029)
  *   - "wire bytes" are Matrix::to_bytes images: [rows u32 LE][cols u32 LE][elems LE]  (matrix.rs:947-1010)
  *   - all element counts are 64-bit (the reference sizes buffers in u32: matrix.rs:50,71,546,988,1048)
- *   - `stream` arguments are hipStream_t passed as void* (NULL = the handle's own stream)
+ *   - `stream` arguments are hipStream_t passed as void* (NULL = HIP's default (null) stream, as in any HIP call)
  *   - host-pointer entry points are synchronous (return when outputs are written), like the reference's
  *     fence-waited Vulkan calls (gpu_utils.rs:129-135,213-219); *_device entry points only enqueue.
  *   - there is NO CPU fallback: without a usable HIP device every compute entry point returns
@@ -229,6 +229,14 @@ int cpir_server_from_compressed(cpir_device* dev, const uint32_t* compressed, ui
 /* Copy the packed DB back in the reference's representation (C x ceil(N/cf) u32, host). */
 int cpir_server_export_compressed(const cpir_server* srv, uint32_t* compressed_out, uint64_t out_words);
 
+/* Wall-clock split of the setup call that built this server, in seconds (0 for phases that did not run):
+ *   [0] encode (filter construction + row encoding, host)   [1] XOF expansion of A (host thread, overlapped)
+ *   [2] D host->device                                       [3] transpose+compress kernel
+ *   [4] wait for A after D was ready (un-overlapped XOF/H2D)  [5] hint matmul kernel
+ *   [6] hint device->host                                     [7] total wall time of the call */
+#define CPIR_SETUP_TIMING_COUNT 8
+int cpir_server_setup_timings(const cpir_server* srv, double out[CPIR_SETUP_TIMING_COUNT]);
+
 cpir_server* cpir_server_retain(cpir_server* srv);  /* #[derive(Clone)] (server.rs:15) */
 void cpir_server_release(cpir_server* srv);         /* Drop */
 int cpir_server_layout(const cpir_server* srv, cpir_dtc_layout* out);
@@ -243,7 +251,7 @@ int cpir_server_respond_bytes(const cpir_server* srv, const uint8_t* query, size
  * q_rows/q_cols are the header fields; anything but 1 x N is rejected as matrix.rs:329-331 does. */
 int cpir_server_respond(const cpir_server* srv, const uint32_t* q, uint32_t q_rows, uint64_t q_cols, uint32_t* r_out);
 /* Device-resident variant: q_dev (total_slots u32) and r_dev (C u32) on the server's device; enqueues on `stream`
- * (NULL = default stream of the handle) and returns without synchronising.  For a shard, r_dev receives the shard's
+ * (NULL = HIP's default stream) and returns without synchronising.  For a shard, r_dev receives the shard's
  * PARTIAL response; the caller sum-reduces partials across shards (u32 wrap-around add). `scratch_dev` must hold
  * cpir_respond_scratch_words() u32, or NULL to use a per-stream scratch owned by the handle. */
 int cpir_server_respond_device(const cpir_server* srv, const uint32_t* q_dev, uint32_t* r_dev, uint32_t* scratch_dev,

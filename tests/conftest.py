@@ -1,0 +1,39 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """the CPU oracle (test infrastructure; compiled with gcc on first use)"""
+    from oracle import oracle
+
+    oracle.lib()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def native():
+    """the product's C ABI library; built on demand here so a fresh checkout can run the CPU suite"""
+    from chalametpir_amd import _native
+
+    if not os.path.exists(_native.LIB_PATH):
+        _native.build()
+    return _native.load()
+
+
+@pytest.fixture(scope="session")
+def device(native):
+    """cpir_device 0; GPU tests FAIL (not skip) if the HIP library cannot open a device"""
+    import chalametpir_amd as cp
+
+    return cp.Device(0)

@@ -1,0 +1,227 @@
+"""GPU parity: the HIP respond path (through the C ABI) vs the CPU oracle, bit-exact.
+
+Restates row_vector_compressed_transposed_matrix_multiplication_works (reference matrix.rs:1319-1376) and adds what the
+reference cannot test (it has no GPU respond): every element bit length, every N mod cf, ragged row counts, the wire
+format and its error behaviour (matrix.rs:973-1010, 329-331), re-entrancy, shards and batches."""
+import threading
+
+import numpy as np
+import pytest
+
+from _cases import ALL_BITS, cf_of, random_db_matrix, random_query, unwire, wire
+
+pytestmark = pytest.mark.gpu
+
+
+def make_server(cp, orc, device, rng, N, C, b):
+    D = random_db_matrix(rng, N, C, b)
+    dtc = orc.row_wise_compress(orc.transpose(D), b)  # server.rs:64-67 on the oracle
+    srv = cp.Server.from_compressed(dtc, N, b, device=device)
+    return srv, dtc
+
+
+@pytest.mark.parametrize("b", ALL_BITS)
+def test_respond_matches_oracle_every_bit_length_and_tail(b, orc, device):
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(1000 + b)
+    cf = cf_of(b)
+    for tail in range(cf):  # N mod cf covers every tail-word case (matrix.rs:360-375, 399-421, 446-475)
+        for base, C in ((cf * 5, 3), (cf * 1024 * 2, 17), (cf * 1500, 40)):
+            N = base + tail
+            srv, dtc = make_server(cp, orc, device, rng, N, C, b)
+            for _ in range(2):
+                q = random_query(rng, N)
+                want = orc.row_vector_x_compressed_transposed_matrix(q, dtc, N, b)[0]
+                got = srv.respond_array(q)
+                assert np.array_equal(got, want), (b, N, C)
+
+
+def test_all_ones_matrix_gives_sum_of_query(orc, device):
+    """reference property test matrix.rs:1319-1376: all-ones DB -> every output = wrapping sum of q"""
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(7)
+    for _ in range(12):
+        N, C, b = int(rng.integers(1, 1025)), int(rng.integers(1, 1025)), int(rng.integers(4, 15))
+        ones = np.ones((N, C), dtype=np.uint32)
+        dtc = orc.row_wise_compress(orc.transpose(ones), b)
+        srv = cp.Server.from_compressed(dtc, N, b, device=device)
+        q = orc.generate_from_seed(1, N, rng.bytes(32))[0]
+        got = srv.respond_array(q)
+        assert np.array_equal(got, np.full(C, q.sum(dtype=np.uint32), dtype=np.uint32))
+
+
+def test_single_slot_and_single_column(orc, device):
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(3)
+    for N, C, b in ((1, 1, 4), (1, 5, 9), (2, 1, 14), (3, 1, 10)):
+        srv, dtc = make_server(cp, orc, device, rng, N, C, b)
+        q = random_query(rng, N)
+        assert np.array_equal(srv.respond_array(q), orc.row_vector_x_compressed_transposed_matrix(q, dtc, N, b)[0])
+
+
+def test_import_ignores_garbage_beyond_n_and_above_b_bits(orc, device):
+    """the reference masks every field with 2^b-1 and bounds-checks the query index in the last word
+    (matrix.rs:352-357, 360-375); a compressed matrix carrying garbage there must give the same answer"""
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(11)
+    for b in (4, 9, 12):
+        cf = cf_of(b)
+        N, C = cf * 700 + 1, 9
+        D = random_db_matrix(rng, N, C, b)
+        dtc = orc.row_wise_compress(orc.transpose(D), b)
+        dirty = dtc.copy()
+        slot = 32 // cf
+        high = (((1 << slot) - 1) ^ ((1 << b) - 1)) if slot > b else 0
+        junk = 0
+        for j in range(cf):
+            junk |= high << (j * slot)
+        dirty |= np.uint32(junk & 0xFFFFFFFF)
+        dirty[:, -1] |= np.uint32(0xFFFFFFFF << slot & 0xFFFFFFFF)  # fields beyond N in the last word
+        q = random_query(rng, N)
+        want = orc.row_vector_x_compressed_transposed_matrix(q, dirty, N, b)[0]
+        assert np.array_equal(want, orc.row_vector_x_compressed_transposed_matrix(q, dtc, N, b)[0])
+        srv = cp.Server.from_compressed(dirty, N, b, device=device)
+        assert np.array_equal(srv.respond_array(q), want)
+
+
+def test_respond_wire_format_and_errors(orc, device):
+    """Server::respond on bytes (server.rs:184-190): same bytes as the oracle, same error variants as the reference"""
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(5)
+    N, C, b = 3001, 23, 10
+    srv, dtc = make_server(cp, orc, device, rng, N, C, b)
+    q = random_query(rng, N)
+    query = wire(q)
+    got = srv.respond(query)
+    assert got == orc.server_respond(dtc, N, b, query)
+    assert len(got) == 8 + 4 * C and unwire(got).shape == (1, C)
+
+    def variant(fn):
+        with pytest.raises(cp.ChalametPIRError) as e:
+            fn()
+        return e.value.variant
+
+    # Matrix::from_bytes failures (matrix.rs:978-999)
+    assert variant(lambda: srv.respond(b"")) == "FailedToDeserializeMatrixFromBytes"
+    assert variant(lambda: srv.respond(query[:8])) == "FailedToDeserializeMatrixFromBytes"
+    assert variant(lambda: srv.respond(query[:-1])) == "FailedToDeserializeMatrixFromBytes"
+    assert variant(lambda: srv.respond(query + b"\0\0\0\0")) == "FailedToDeserializeMatrixFromBytes"
+    assert variant(lambda: srv.respond(wire(np.zeros((0, 5), dtype=np.uint32)) + b"\0" * 4)) == "FailedToDeserializeMatrixFromBytes"
+    # dimension failures (matrix.rs:329-331)
+    assert variant(lambda: srv.respond(wire(random_query(rng, N - 1)))) == "IncompatibleDimensionForRowVectorTransposedMatrixMultiplication"
+    assert variant(lambda: srv.respond(wire(q.reshape(-1, 1)))) == "IncompatibleDimensionForRowVectorTransposedMatrixMultiplication"
+    # the same inputs produce the same codes on the oracle
+    for bad in (b"", query[:8], query[:-1], wire(random_query(rng, N - 1)), wire(q.reshape(-1, 1))):
+        with pytest.raises(orc.OracleError) as oe:
+            orc.server_respond(dtc, N, b, bad)
+        with pytest.raises(cp.ChalametPIRError) as pe:
+            srv.respond(bad)
+        assert oe.value.code == pe.value.code
+
+
+def test_invalid_bit_length_rejected(device):
+    import chalametpir_amd as cp
+
+    for b in (0, 3, 15, 16, 32):
+        with pytest.raises(cp.ChalametPIRError) as e:
+            cp.Server.from_compressed(np.zeros((2, 2), dtype=np.uint32), 4, b, device=device)
+        assert e.value.variant == "ImpossibleEncodedDBMatrixElementBitLength"  # matrix.rs:99-101
+
+
+def test_respond_is_reentrant_and_clone_shares_db(orc, device):
+    """respond(&self) is called concurrently on an Arc<Server> (reference examples/server.rs:45,55,85)"""
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(9)
+    N, C, b = 3 * 4096 + 2, 64, 9
+    srv, dtc = make_server(cp, orc, device, rng, N, C, b)
+    clone = srv.clone()
+    queries = [random_query(rng, N) for _ in range(24)]
+    wants = [orc.row_vector_x_compressed_transposed_matrix(q, dtc, N, b)[0] for q in queries]
+    results = [None] * len(queries)
+
+    def work(i):
+        s = srv if i % 2 == 0 else clone
+        for _ in range(3):
+            results[i] = s.respond_array(queries[i])
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(queries))]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    for got, want in zip(results, wants):
+        assert np.array_equal(got, want)
+    srv.close()
+    assert np.array_equal(clone.respond_array(queries[0]), wants[0])  # the clone keeps the DB alive
+
+
+def test_every_kernel_variant_is_bit_identical(orc, device):
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(21)
+    N, C, b = 3 * 1024 * 20 + 1, 100, 9
+    srv, dtc = make_server(cp, orc, device, rng, N, C, b)
+    q = random_query(rng, N)
+    want = orc.row_vector_x_compressed_transposed_matrix(q, dtc, N, b)[0]
+    try:
+        for R in (4, 8, 16):
+            for nt in (0, 1):
+                for xs in (0, 1):
+                    for bpc in (0, 1, 3):
+                        cp.tuning_set("respond.rows_per_unit", R)
+                        cp.tuning_set("respond.nontemporal", nt)
+                        cp.tuning_set("respond.xcd_split", xs)
+                        cp.tuning_set("respond.blocks_per_cu", bpc)
+                        assert np.array_equal(srv.respond_array(q), want), (R, nt, xs, bpc)
+    finally:
+        cp.tuning_set("respond.rows_per_unit", 8)
+        cp.tuning_set("respond.nontemporal", 0)
+        cp.tuning_set("respond.xcd_split", 1)
+        cp.tuning_set("respond.blocks_per_cu", 0)
+
+
+def test_device_entry_points_shards_and_batches(orc, device):
+    """device-pointer ABI used by the multi-GPU path: shard partials sum (wrap-around) to the full response, and a batch
+    equals independent responds"""
+    import torch
+
+    import chalametpir_amd as cp
+    from chalametpir_amd.distributed import shard_range
+
+    rng = np.random.default_rng(31)
+    for b in (9, 12, 6):
+        cf = cf_of(b)
+        N, C = cf * 1024 * 5 + cf * 100 + 1, 37
+        D = random_db_matrix(rng, N, C, b)
+        dtc_full = orc.row_wise_compress(orc.transpose(D), b)
+        q = random_query(rng, N)
+        want = orc.row_vector_x_compressed_transposed_matrix(q, dtc_full, N, b)[0]
+        q_dev = torch.from_numpy(q.view(np.int32)).cuda()
+        total = np.zeros(C, dtype=np.uint32)
+        world = 3
+        for rank in range(world):
+            lo, hi = shard_range(N, cf, rank, world)
+            if hi <= lo:
+                continue
+            D_dev = torch.from_numpy(np.ascontiguousarray(D[lo:hi]).view(np.int32)).cuda()
+            srv = cp.Server.from_device_matrix(D_dev, hi - lo, C, b, device=device, slot_offset=lo, total_slots=N)
+            r_dev = torch.empty(C, dtype=torch.int32, device="cuda")
+            srv.respond_device(q_dev, r_dev, stream=torch.cuda.current_stream())
+            torch.cuda.synchronize()
+            total += r_dev.cpu().numpy().view(np.uint32)
+        assert np.array_equal(total, want), b
+
+        # batch of 7 (4 + 2 + 1 passes) on the unsharded server
+        srv = cp.Server.from_compressed(dtc_full, N, b, device=device)
+        Q = np.stack([random_query(rng, N) for _ in range(7)])
+        Q_dev = torch.from_numpy(Q.view(np.int32)).cuda()
+        R_dev = torch.empty((7, C), dtype=torch.int32, device="cuda")
+        srv.respond_batch_device(Q_dev, 7, R_dev, stream=torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        got = R_dev.cpu().numpy().view(np.uint32)
+        for i in range(7):
+            assert np.array_equal(got[i], orc.row_vector_x_compressed_transposed_matrix(Q[i], dtc_full, N, b)[0]), (b, i)

@@ -1,0 +1,212 @@
+"""GPU parity of the offline path: transpose+compress, the hint matmul, Server::setup from a matrix and from a KV database,
+and the end-to-end "client decodes the right value" property (reference integrations/src/test_pir.rs:12-142)."""
+import numpy as np
+import pytest
+
+from _cases import ALL_BITS, cf_of, random_db_matrix, random_query, unwire, wire
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint32).view(np.int32)).cuda()
+
+
+def _host(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+@pytest.mark.parametrize("b", ALL_BITS)
+def test_transpose_compress_matches_oracle(b, orc, device):
+    """gpu_utils::mat_transpose + Matrix::row_wise_compress (reference gpu_utils.rs:222-281, matrix.rs:98-205, 517-527)"""
+    import torch
+
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(200 + b)
+    cf = cf_of(b)
+    for N, C in ((cf * 64 + 1, 5), (cf * 300 + cf - 1, 66), (1, 1), (cf * 2048, 130), (777, 64)):
+        D = random_db_matrix(rng, N, C, 16)  # entries wider than b: compress must mask them (matrix.rs:121)
+        want = orc.row_wise_compress(orc.transpose(D), b)
+        srv = cp.Server.from_device_matrix(_dev(D), N, C, b, device=device)
+        assert np.array_equal(srv.export_compressed(), want), (b, N, C)
+        # padding of the device layout is zero and the OR flag reports the widest entry
+        L = srv.layout
+        dtc = torch.empty(L.total_words, dtype=torch.int32, device="cuda")
+        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        device.transpose_compress(_dev(D), L, dtc, or_of_entries=flag, stream=torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        img = _host(dtc).reshape(L.rows_padded, L.words_per_row_padded)
+        assert np.array_equal(img[:C, : L.words_per_row], want)
+        assert not img[C:].any() and not img[:, L.words_per_row:].any()
+        assert int(_host(flag)[0]) == int(np.bitwise_or.reduce(D, axis=None))
+
+
+def test_compress_then_decompress_round_trip(orc, device):
+    """row_wise_compressed_matrix_can_be_decompressed (reference matrix.rs:1520-1604), with the GPU doing the compress"""
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(77)
+    for b in (5, 9, 10, 13):
+        N, C = int(rng.integers(1000, 5000)), int(rng.integers(10, 200))
+        D = random_db_matrix(rng, N, C, b)
+        srv = cp.Server.from_device_matrix(_dev(D), N, C, b, device=device)
+        back = orc.row_wise_decompress(srv.export_compressed(), b, N)
+        assert np.array_equal(back, orc.transpose(D))
+
+
+def test_mat_x_mat_identity_property(orc, device):
+    """matrix_multiplication_is_correct (reference matrix.rs:1275-1317): A*I = A and I*A = A for random dims 1..1024"""
+    import torch
+
+    rng = np.random.default_rng(41)
+    seed = rng.bytes(32)
+    for _ in range(10):
+        rows, cols = int(rng.integers(1, 1025)), int(rng.integers(1, 1025))
+        A = orc.generate_from_seed(rows, cols, seed)
+        for lhs, rhs, bits in ((A, orc.identity(cols), 16), (A, orc.identity(cols), 32), (orc.identity(rows), A, 32)):
+            M = torch.empty((lhs.shape[0], rhs.shape[1]), dtype=torch.int32, device="cuda")
+            device.mat_x_mat(_dev(lhs), _dev(rhs), M, lhs.shape[0], lhs.shape[1], rhs.shape[1], rhs_max_bits=bits,
+                             stream=torch.cuda.current_stream())
+            torch.cuda.synchronize()
+            assert np.array_equal(_host(M), A), (rows, cols, bits)
+
+
+def test_mat_x_mat_matches_oracle_random(orc, device):
+    """impl Mul for &Matrix (reference matrix.rs:1040-1059) on random operands: packed-16 and general kernels, split-K,
+    ragged edges, accumulate mode"""
+    import torch
+
+    rng = np.random.default_rng(43)
+    for rows, inner, cols, bits in ((1774, 2000, 940, 9), (64, 70001, 128, 14), (65, 33, 129, 16), (3, 5000, 7, 32),
+                                    (200, 4096, 300, 32), (1, 1, 1, 16), (130, 100000, 20, 10)):
+        A = random_query(rng, rows * inner).reshape(rows, inner)
+        D = rng.integers(0, 1 << bits, size=(inner, cols), dtype=np.uint64).astype(np.uint32)
+        want = orc.mul(A, D)
+        M = torch.empty((rows, cols), dtype=torch.int32, device="cuda")
+        device.mat_x_mat(_dev(A), _dev(D), M, rows, inner, cols, rhs_max_bits=bits, stream=torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        assert np.array_equal(_host(M), want), (rows, inner, cols, bits)
+        # accumulate: K split in two halves must add up to the same product (this is how N-shards combine)
+        h = inner // 2
+        if h:
+            M.zero_()
+            device.mat_x_mat(_dev(A[:, :h]), _dev(D[:h]), M, rows, h, cols, rhs_max_bits=bits, accumulate=True)
+            device.mat_x_mat(_dev(A[:, h:]), _dev(D[h:]), M, rows, inner - h, cols, rhs_max_bits=bits, accumulate=True)
+            device.synchronize()
+            torch.cuda.synchronize()
+            assert np.array_equal(_host(M), want), ("accumulate", rows, inner, cols, bits)
+
+
+def test_mat_x_mat_dimension_errors(device):
+    import torch
+
+    import chalametpir_amd as cp
+
+    t = torch.zeros(16, dtype=torch.int32, device="cuda")
+    with pytest.raises(cp.ChalametPIRError) as e:
+        device.mat_x_mat(t, t, t, 0, 4, 4)
+    assert e.value.variant == "InvalidMatrixDimension"  # Matrix::new, matrix.rs:45-55
+
+
+@pytest.mark.parametrize("b,N,C", [(9, 3 * 1100 + 1, 97), (10, 5000, 64), (12, 2049, 33), (7, 4097, 130)])
+def test_setup_from_matrix_matches_oracle(b, N, C, orc, device):
+    """Server::setup minus the encoder (reference server.rs:59-67): hint = A(seed)*D and the resident packed DB"""
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(b * 1000 + N)
+    seed = rng.bytes(32)
+    D = random_db_matrix(rng, N, C, b)
+    want_hint, want_dtc = orc.server_setup_from_matrix(seed, D, b)
+    srv, hint = cp.Server.setup_from_matrix(seed, D, b, device=device)
+    assert np.array_equal(hint, want_hint)
+    assert np.array_equal(srv.export_compressed(), want_dtc)
+    assert (srv.decompressed_num_cols, srv.mat_elem_bit_len, srv.response_len) == (N, b, C)
+    q = random_query(rng, N)
+    assert srv.respond(wire(q)) == orc.server_respond(want_dtc, N, b, wire(q))
+    # caller-supplied A takes the same path as the seed-expanded A
+    A = orc.generate_from_seed(1774, N, seed)
+    srv2, hint2 = cp.Server.setup_from_matrix(seed, D, b, pub_mat_a=A, device=device)
+    assert np.array_equal(hint2, want_hint)
+
+
+def test_setup_uses_unmasked_entries_for_the_hint(orc, device):
+    """the reference multiplies A by D before any masking (server.rs:61) but masks when compressing (matrix.rs:121):
+    entries >= 2^16 must flip the hint product to the general kernel and still match"""
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(99)
+    N, C, b = 1500, 20, 9
+    D = random_query(rng, N * C).reshape(N, C)  # full-range u32
+    seed = rng.bytes(32)
+    want_hint, want_dtc = orc.server_setup_from_matrix(seed, D, b)
+    srv, hint = cp.Server.setup_from_matrix(seed, D, b, device=device)
+    assert np.array_equal(hint, want_hint)
+    assert np.array_equal(srv.export_compressed(), want_dtc)
+
+
+def _random_kv(rng, n, max_val=64):
+    keys = {}
+    while len(keys) < n:
+        keys[rng.bytes(int(rng.integers(16, 33)))] = None
+    return {k: rng.bytes(int(rng.integers(1, max_val + 1))) for k in keys}
+
+
+@pytest.mark.parametrize("arity", [3, 4])
+def test_keyword_pir_end_to_end(arity, orc, device):
+    """test_keyword_pir_with_{3,4}_wise_xor_filter (reference integrations/src/test_pir.rs:12-142): full Server::setup on a
+    KV database -> client query -> Server::respond -> client decodes exactly the stored value.  The client is the
+    oracle's restatement of chalametpir_client (client.rs:95-194, 209-275); the server is the HIP path."""
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(500 + arity)
+    for n in (300, 2000):
+        db = _random_kv(rng, n)
+        seed = rng.bytes(32)
+        fseeds = rng.bytes(32 * 100)
+        srv, hint_bytes, filter_bytes = cp.Server.setup(seed, db, arity, device=device, filter_seed_material=fseeds)
+        # the same setup on the oracle gives the same bytes
+        keys, vals = list(db.keys()), list(db.values())
+        b = orc.find_encoded_db_matrix_element_bit_length(n)
+        D, filt, _ = orc.from_kv_database(arity, keys, vals, b, fseeds)
+        want_hint, want_dtc = orc.server_setup_from_matrix(seed, D, b)
+        assert filter_bytes == filt.to_bytes() and len(filter_bytes) == 68
+        assert hint_bytes == wire(want_hint)
+        assert np.array_equal(srv.export_compressed(), want_dtc)
+        # client side
+        filt2 = orc.Filter.from_bytes(filter_bytes)
+        hint = unwire(hint_bytes)
+        assert hint.shape[0] == 1774  # Client::setup check, client.rs:47-49
+        N = filt2.num_fingerprints
+        A = orc.generate_from_seed(1774, N, seed)
+        done = 0
+        for key in keys[:200]:
+            s = orc.ternary_vector(1774, rng)
+            e = orc.ternary_vector(N, rng)
+            try:
+                qb, sc = orc.client_query(A, hint, filt2, key, s, e)
+            except orc.OracleError as err:
+                assert err.code == orc.ERR_ARITHMETIC_OVERFLOW_ADDING_QUERY_INDICATOR  # retried in the reference (test_pir.rs:66-70)
+                continue
+            resp = unwire(srv.respond(wire(qb)))
+            assert orc.client_process_response(filt2, key, sc, resp) == db[key]
+            done += 1
+            if done == 10:
+                break
+        assert done == 10
+
+
+def test_setup_error_behaviour(device):
+    import chalametpir_amd as cp
+
+    with pytest.raises(cp.ChalametPIRError) as e:
+        cp.Server.setup(bytes(32), {}, 3, device=device)
+    assert e.value.variant == "EmptyKVDatabase"  # server.rs:48-51
+    with pytest.raises(cp.ChalametPIRError) as e:
+        cp.Server.setup(bytes(32), {b"apple": b"red"}, 5, device=device)
+    assert e.value.variant == "UnsupportedArityForBinaryFuseFilter"
+    # a one-entry database is valid (reference test matrix.rs:1430-1446)
+    srv, hint, fb = cp.Server.setup(bytes(32), {b"apple": b"red"}, 3, device=device)
+    assert len(fb) == 68 and srv.mat_elem_bit_len == 14
