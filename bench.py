@@ -118,11 +118,20 @@ def main() -> int:
 
     step_counter = [0]
 
-    def run_step():
+    if pool % qps_step != 0:
+        raise SystemExit("--query-pool must be a multiple of --queries-per-step")
+    # every query of a step is an independent pass over the database (batch_fusion = 0): the batch entry point is only
+    # used to enqueue the step's launches from C instead of one Python/ctypes round trip per query
+    cp.tuning_set("respond.batch_fusion", 0)
+
+    def run_step(events=None):
         base = (step_counter[0] * qps_step) % pool
         step_counter[0] += 1
-        for j in range(qps_step):
-            sharded.respond_partial_device(q_pool[(base + j) % pool], r_step[j], stream=stream)
+        if events:
+            events[0].record(stream)
+        sharded.respond_partial_device(q_pool[base:base + qps_step], r_step, batch=qps_step, stream=stream)
+        if events:
+            events[1].record(stream)
         if world > 1:
             dist.all_reduce(r_step)  # int32 sum == u32 wrap-around sum; one collective for the step's queries
 
@@ -135,18 +144,17 @@ def main() -> int:
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # HIP events on the stream the respond kernels are launched on, bracketing the kernel launches of every timed step
+    step_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t_begin = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        run_step()
-    ev1.record(stream)
+    for k in range(args.steps):
+        run_step(step_events[k])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_begin
-    kernel_region_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the respond kernels run on
+    kernel_region_ms = sum(a.elapsed_time(b) for a, b in step_events)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -214,7 +222,7 @@ def main() -> int:
 
 def sweep(cp, torch, run_step, qps_step):
     """time each respond kernel variant (one process, interleaved rounds) -- tuning aid, output on stderr"""
-    variants = [(R, nt, bpc) for R in (4, 8, 16) for nt in (0, 1) for bpc in (0, 2, 4)]
+    variants = [(R, nt, bpc) for R in (4, 8, 16) for nt in (0, 1) for bpc in (1, 2, 3, 4, 0)]
     best = {}
     for rnd in range(3):
         for R, nt, bpc in variants:

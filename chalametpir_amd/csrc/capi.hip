@@ -452,11 +452,18 @@ int cpir_op_respond(cpir_device* dev, const uint32_t* dtc, const cpir_dtc_layout
 // any batch size: issued as passes of 4 / 2 / 1 queries, each pass streaming the database once
 static int respond_batched(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                            uint64_t q_slot_offset, uint32_t batch, uint32_t* r, uint32_t* scratch, hipStream_t stream) {
+  const bool fuse = respond_batch_fusion();
   uint32_t done = 0;
   while (done < batch) {
     const uint32_t left = batch - done;
-    const uint32_t step = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
-    CPIR_TRY(launch_respond(dev, dtc, L, q + (uint64_t)done * q_len, q_len, q_slot_offset, step, r + (uint64_t)done * L.num_cols, scratch, stream));
+    const uint32_t step = !fuse ? 1 : (left >= 4 ? 4 : (left >= 2 ? 2 : 1));
+    // one memset for the first pass; every pass zeroes the output rows of the pass that follows it on the stream
+    const uint32_t after = left - step;
+    const uint32_t next_step = !fuse ? (after ? 1 : 0) : (after >= 4 ? 4 : (after >= 2 ? 2 : after));
+    uint32_t* r_here = r + (uint64_t)done * L.num_cols;
+    CPIR_TRY(launch_respond(dev, dtc, L, q + (uint64_t)done * q_len, q_len, q_slot_offset, step, r_here, scratch, stream,
+                            /*r_is_zero=*/done != 0, next_step ? r_here + (uint64_t)step * L.num_cols : nullptr,
+                            next_step * L.num_cols));
     done += step;
   }
   return CPIR_OK;

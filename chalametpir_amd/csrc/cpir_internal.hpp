@@ -63,9 +63,13 @@ inline hipStream_t pick_stream(const Device*, void* stream) { return reinterpret
 // ---- kernel launchers (defined in the .hip files) ---------------------------------------------
 // respond.hip
 uint64_t respond_scratch_words(const cpir_dtc_layout& L, uint32_t batch);
+// r_is_zero: the caller guarantees r is already zero on `stream` (skips the memset); zero_next/zero_count: a buffer this
+// launch zeroes for the launch that FOLLOWS it on the same stream (must not overlap r).
 int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
-                   uint64_t q_slot_offset, uint32_t batch, uint32_t* r, uint32_t* scratch, hipStream_t stream);
+                   uint64_t q_slot_offset, uint32_t batch, uint32_t* r, uint32_t* scratch, hipStream_t stream,
+                   bool r_is_zero = false, uint32_t* zero_next = nullptr, uint32_t zero_count = 0);
 const char* respond_kernel_name(const cpir_dtc_layout& L);
+bool respond_batch_fusion();
 
 // pack.hip
 int launch_transpose_compress(const Device* dev, const uint32_t* D, uint64_t ldd, const cpir_dtc_layout& L, uint32_t* dtc,

@@ -47,6 +47,8 @@ struct RespondArgs {
   uint32_t chunks_total;   // words_per_row_padded / 1024
   uint32_t nx;             // K-axis split by blockIdx % nx (8 or 1)
   uint32_t q_scalar;       // q not 16-byte loadable -> guarded scalar loads everywhere
+  uint32_t* zero_next;     // output of the NEXT launch on this stream, zeroed here so a run of launches needs one memset
+  uint32_t zero_count;
 };
 
 template <int CF>
@@ -85,6 +87,9 @@ __global__ void __launch_bounds__(kThreads) respond_kernel(const RespondArgs a) 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+
+  if (blockIdx.x == 0 && a.zero_next)
+    for (uint32_t i = tid; i < a.zero_count; i += kThreads) a.zero_next[i] = 0;
 
   // ---- static partition of the (row group, chunk) units over the persistent grid --------------------------------
   const uint32_t nx = a.nx;
@@ -202,9 +207,10 @@ __global__ void __launch_bounds__(kThreads) respond_kernel(const RespondArgs a) 
 // ---- tuning state (benchmark harness can override; defaults chosen from measurements) ----------------
 struct Tuning {
   int rows_per_unit = 8;   // R in {4, 8, 16}
-  int nontemporal = 0;     // streamed DB loads with the nt cache policy
-  int blocks_per_cu = 0;   // 0 = ask the occupancy API
+  int nontemporal = 1;     // streamed DB loads with the nt cache policy (read once per query; keeps q in L2)
+  int blocks_per_cu = 2;   // resident 256-thread blocks per CU; 0 = ask the occupancy API (7 for R = 8)
   int xcd_split = 1;       // split the K axis by blockIdx % 8
+  int batch_fusion = 1;    // respond_batch: 1 = passes of 4/2/1 queries share one DB stream, 0 = one pass per query
 };
 Tuning g_tuning;
 std::mutex g_tuning_mu;
@@ -247,10 +253,17 @@ extern "C" int cpir_tuning_set(const char* key, int value) {
     g_tuning.blocks_per_cu = value;
   } else if (!strcmp(key, "respond.xcd_split")) {
     g_tuning.xcd_split = value ? 1 : 0;
+  } else if (!strcmp(key, "respond.batch_fusion")) {
+    g_tuning.batch_fusion = value ? 1 : 0;
   } else {
     return CPIR_ERR_INVALID_ARGUMENT;
   }
   return CPIR_OK;
+}
+
+bool respond_batch_fusion() {
+  std::lock_guard<std::mutex> lk(g_tuning_mu);
+  return g_tuning.batch_fusion != 0;
 }
 
 uint64_t respond_scratch_words(const cpir_dtc_layout&, uint32_t) {
@@ -262,7 +275,8 @@ uint64_t respond_scratch_words(const cpir_dtc_layout&, uint32_t) {
 const char* respond_kernel_name(const cpir_dtc_layout&) { return "respond_kernel"; }
 
 int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
-                   uint64_t q_slot_offset, uint32_t batch, uint32_t* r, uint32_t* /*scratch*/, hipStream_t stream) {
+                   uint64_t q_slot_offset, uint32_t batch, uint32_t* r, uint32_t* /*scratch*/, hipStream_t stream,
+                   bool r_is_zero, uint32_t* zero_next, uint32_t zero_count) {
   if (!dtc || !q || !r || batch == 0) return CPIR_ERR_INVALID_ARGUMENT;
   const uint32_t cf = L.compression_factor;
   if (cf != compression_factor(L.mat_elem_bit_len) || cf == 0) return CPIR_ERR_IMPOSSIBLE_ELEMENT_BIT_LENGTH;
@@ -319,7 +333,9 @@ int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout
     if (grid == 0) grid = 1, a.nx = 1;
   }
 
-  CPIR_HIP_TRY(hipMemsetAsync(r, 0, (size_t)batch * L.num_cols * sizeof(uint32_t), stream));
+  a.zero_next = zero_next;
+  a.zero_count = zero_next ? zero_count : 0;
+  if (!r_is_zero) CPIR_HIP_TRY(hipMemsetAsync(r, 0, (size_t)batch * L.num_cols * sizeof(uint32_t), stream));
   hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(kThreads), 0, stream, a);
   CPIR_HIP_TRY(hipGetLastError());
   return CPIR_OK;

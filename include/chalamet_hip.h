@@ -165,7 +165,9 @@ int cpir_op_synth_fill(cpir_device* dev, uint32_t* out, uint64_t count, uint64_t
                        void* stream);
 /* Tuning knobs of the respond kernel (benchmark harness only; defaults are the measured best):
  *   "respond.rows_per_unit" in {4, 8, 16}, "respond.nontemporal" {0,1}, "respond.blocks_per_cu" 0..8 (0 = occupancy API),
- *   "respond.xcd_split" {0,1}.  Process-wide; results are bit-identical for every setting. */
+ *   "respond.xcd_split" {0,1}, "respond.batch_fusion" {0,1} (0: every query of a batch call streams the database on its
+ *   own, i.e. a batch call is only a cheaper way to enqueue independent responds).
+ * Process-wide; results are bit-identical for every setting. */
 int cpir_tuning_set(const char* key, int value);
 /* Name of the dominant kernel last launched by cpir_op_respond for this layout (for matching rocprof traces). */
 const char* cpir_respond_kernel_name(const cpir_dtc_layout* layout);

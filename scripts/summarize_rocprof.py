@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (kernel stats + FETCH_SIZE / WRITE_SIZE counter passes) into a short summary.
+Usage: summarize_rocprof.py <prof dir> <tag>   -> prints the summary and writes <prof dir>/summary.json"""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def find(root, pattern):
+    return sorted(glob.glob(os.path.join(root, "**", pattern), recursive=True))
+
+
+def kernel_stats(root):
+    rows = []
+    for f in find(root, "*kernel_stats.csv"):
+        with open(f) as fh:
+            rows += list(csv.DictReader(fh))
+    return rows
+
+
+def counters(root):
+    """-> {kernel_name: {counter: [values per dispatch]}}"""
+    out = {}
+    for f in find(root, "*counter_collection.csv"):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                k = r.get("Kernel_Name") or r.get("Kernel Name") or ""
+                c = r.get("Counter_Name") or r.get("Counter Name") or ""
+                v = float(r.get("Counter_Value") or r.get("Counter Value") or 0)
+                out.setdefault(k, {}).setdefault(c, []).append(v)
+    return out
+
+
+def main():
+    root, tag = sys.argv[1], sys.argv[2]
+    summary = {"tag": tag, "kernels": [], "respond": {}}
+    print(f"== rocprofv3 summary [{tag}] ==")
+    stats = kernel_stats(os.path.join(root, "trace"))
+    stats.sort(key=lambda r: -float(r.get("TotalDurationNs", r.get("Total Duration (ns)", 0)) or 0))
+    print("-- kernel stats (rocprofv3 --kernel-trace --stats) --")
+    for r in stats[:12]:
+        name = r.get("Name", "")
+        calls = int(float(r.get("Calls", 0)))
+        avg = float(r.get("AverageNs", r.get("Average (ns)", 0)) or 0)
+        tot = float(r.get("TotalDurationNs", r.get("Total Duration (ns)", 0)) or 0)
+        pct = r.get("Percentage", "")
+        print(f"{calls:7d} calls  avg {avg / 1e3:10.2f} us  total {tot / 1e6:10.3f} ms  {pct:>7}%  {name[:110]}")
+        summary["kernels"].append({"name": name, "calls": calls, "avg_us": avg / 1e3, "total_ms": tot / 1e6})
+        if "respond_kernel" in name and "avg_us" not in summary["respond"]:
+            summary["respond"].update({"name": name, "calls": calls, "avg_us": avg / 1e3})
+    for label, sub, ctr in (("fetch", "pmc_fetch", "FETCH_SIZE"), ("write", "pmc_write", "WRITE_SIZE")):
+        c = counters(os.path.join(root, sub))
+        for k, d in c.items():
+            if "respond_kernel" in k and ctr in d:
+                vals = d[ctr]
+                mean = sum(vals) / len(vals)
+                # FETCH_SIZE / WRITE_SIZE are reported in KiB-like units of 1024 B by rocprofv3's derived metric
+                summary["respond"][ctr + "_mean_raw"] = mean
+                summary["respond"][ctr + "_dispatches"] = len(vals)
+                print(f"-- {ctr}: respond_kernel mean over {len(vals)} dispatches = {mean:.1f} (raw units; x1024 = bytes => {mean * 1024 / 1e9:.4f} GB)")
+    with open(os.path.join(root, "summary.json"), "w") as fh:
+        json.dump(summary, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()
