@@ -64,6 +64,8 @@ def main() -> int:
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
     ap.add_argument("--tune", default="", help="comma list key=value for cpir_tuning_set, e.g. respond.rows_per_unit=16")
     ap.add_argument("--sweep", action="store_true", help="time every respond kernel variant (stderr table) before the run")
+    ap.add_argument("--verify", action="store_true",
+                    help="rank 0 re-derives the step's responses with the CPU oracle from the full synthetic DB (small configs only)")
     args = ap.parse_args()
 
     import torch
@@ -79,9 +81,17 @@ def main() -> int:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    # test hooks: CPIR_BENCH_SHARE_DEVICE=1 puts every rank on GPU 0 and CPIR_BENCH_BACKEND=gloo swaps the collective, so the
+    # multi-rank path can be exercised on a one-GPU box (RCCL refuses two ranks on one device); never used for reported numbers
+    if os.environ.get("CPIR_BENCH_SHARE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("CPIR_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
     device = cp.Device(local_rank)
     for kv in filter(None, args.tune.split(",")):
         k, v = kv.split("=")
@@ -205,7 +215,21 @@ def main() -> int:
         },
         "pack_seconds": round(pack_seconds, 3),
     }
+    # HBM traffic per launch cannot be sampled from inside this process (PMC counters need rocprofv3 around it); the last
+    # committed counter pass for this exact workload (scripts/profile_gpu.sh -> profiles/respond_traffic.json) is quoted.
+    traffic_file = os.path.join(ROOT, "profiles", "respond_traffic.json")
+    if world == 1 and args.config == "cfg2" and os.path.exists(traffic_file):
+        try:
+            with open(traffic_file) as fh:
+                tr = json.load(fh)
+            if int(tr.get("algorithmic_bytes_per_launch", 0)) == launch_bytes:
+                result["roofline"]["traffic"] = int(tr["traffic_bytes_per_launch"])
+                result["roofline"]["traffic_source"] = "profiles/respond_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"
+        except (OSError, ValueError, KeyError):
+            pass
 
+    if args.verify:
+        result["verified_vs_oracle"] = verify(run_step, step_counter, r_step, qps_step, pool, N, C, b, mask, rank, torch)
     if rank == 0 and world == 1:
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sharded.local, q_pool, r_step, N, C, b, full_bytes, args.cpu_seconds, torch, stream)
@@ -218,6 +242,26 @@ def main() -> int:
     if rank == 0:
         print(json.dumps(result), flush=True)
     return 0
+
+
+def verify(run_step, step_counter, r_step, qps_step, pool, N, C, b, mask, rank, torch):
+    """One more step; rank 0 rebuilds the FULL synthetic DB and the step's queries on the host with the oracle's copy of the
+    generator, and checks the (all-reduced) responses bit for bit."""
+    base = (step_counter[0] * qps_step) % pool
+    run_step()
+    torch.cuda.synchronize()
+    if rank != 0:
+        return None
+    from oracle import oracle as orc  # checker only
+
+    D = orc.synth_fill_u32(N * C, SEED_D, 0, mask).reshape(N, C)
+    dtc = orc.row_wise_compress(orc.transpose(D), b)
+    got = r_step.cpu().numpy().view(np.uint32)
+    ok = True
+    for j in range(qps_step):
+        q = orc.synth_fill_u32(N, SEED_Q + base + j)
+        ok &= bool(np.array_equal(got[j], orc.row_vector_x_compressed_transposed_matrix(q, dtc, N, b)[0]))
+    return ok
 
 
 def sweep(cp, torch, run_step, qps_step):

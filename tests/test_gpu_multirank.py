@@ -1,0 +1,35 @@
+"""The multi-rank path of bench.py (N-sharded database + one integer all-reduce per step) run as 2 and 3 processes on the
+single GPU of the test box: every rank uses the real HIP kernels on its shard; the collective is gloo (RCCL refuses two
+ranks on one device).  Rank 0 verifies the reduced responses against the oracle on the full synthetic database."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("world,config", [(2, "tiny"), (3, "cfg1")])
+def test_bench_multirank_on_one_gpu(world, config):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", CPIR_BENCH_BACKEND="gloo", CPIR_BENCH_SHARE_DEVICE="1", OMP_NUM_THREADS="8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--config", config, "--steps", "2",
+           "--warmup", "1", "--no-setup", "--no-cpu-baseline", "--verify", "--queries-per-step", "8", "--query-pool", "16"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == world and out["verified_vs_oracle"] is True and out["scaling"] == "strong"
+    assert out["value"] > 0
+
+
+def test_bench_single_rank_verify():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "cfg1", "--steps", "2", "--warmup", "1", "--no-setup",
+           "--no-cpu-baseline", "--verify"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["verified_vs_oracle"] is True and out["roofline"]["bound"] == "hbm"
