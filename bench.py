@@ -54,8 +54,8 @@ def log(*a):
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--queries-per-step", type=int, default=16)
     ap.add_argument("--query-pool", type=int, default=64, help="distinct queries cycled through (no query-side caching)")
@@ -64,6 +64,8 @@ def main() -> int:
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
     ap.add_argument("--tune", default="", help="comma list key=value for cpir_tuning_set, e.g. respond.rows_per_unit=16")
     ap.add_argument("--sweep", action="store_true", help="time every respond kernel variant (stderr table) before the run")
+    ap.add_argument("--enqueue", default="batch", choices=["batch", "python"],
+                    help="how a step's launches are enqueued: one C call for the step (default) or one ctypes call per query")
     ap.add_argument("--verify", action="store_true",
                     help="rank 0 re-derives the step's responses with the CPU oracle from the full synthetic DB (small configs only)")
     args = ap.parse_args()
@@ -139,7 +141,11 @@ def main() -> int:
         step_counter[0] += 1
         if events:
             events[0].record(stream)
-        sharded.respond_partial_device(q_pool[base:base + qps_step], r_step, batch=qps_step, stream=stream)
+        if args.enqueue == "batch":
+            sharded.respond_partial_device(q_pool[base:base + qps_step], r_step, batch=qps_step, stream=stream)
+        else:
+            for j in range(qps_step):
+                sharded.respond_partial_device(q_pool[base + j], r_step[j], stream=stream)
         if events:
             events[1].record(stream)
         if world > 1:
