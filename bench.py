@@ -107,9 +107,10 @@ def main() -> int:
     W = -(-N // cf)
     mask = (1 << b) - 1
     stream = torch.cuda.current_stream()
+    full_layout = cp.dtc_layout_for(N, C, b)  # packing of the resident DB (dense64 where offered)
 
     # ---- this rank's shard of the synthetic encoded DB, generated in HBM, packed, and D freed ---------------------------
-    lo, hi = shard_range(N, cf, rank, world)
+    lo, hi = shard_range(N, full_layout.slots_per_chunk, rank, world)
     t0 = time.time()
     D_dev = torch.empty(((hi - lo), C), dtype=torch.int32, device="cuda")
     if hi > lo:
@@ -184,6 +185,10 @@ def main() -> int:
     full_bytes = 4 * C * W + 4 * N + 4 * C
     launch_us = kernel_region_ms * 1e3 / n_queries
     achieved = launch_bytes / (launch_us * 1e-6) / 1e9 if launch_us > 0 else 0.0
+    # bytes the launch really has to move with the packing in use (device rows incl. zero padding + q slice + response)
+    shard_words = int(sharded.local.layout.total_words) if sharded.local is not None else 0
+    moved_bytes = 4 * shard_words + 4 * (hi - lo) + 4 * C
+    packing = "dense64" if full_layout.packing == 1 else "reference"
 
     result = {
         "metric": "server_respond_queries_per_sec",
@@ -217,6 +222,9 @@ def main() -> int:
             "traffic": None,
             "launch_us": round(launch_us, 2),
             "bytes_per_launch": launch_bytes,
+            "packing": f"{packing} ({full_layout.fields_per_word} fields per {'u64' if full_layout.packing == 1 else 'u32'})",
+            "moved_bytes_per_launch": moved_bytes,
+            "moved_GBps": round(moved_bytes / (launch_us * 1e-6) / 1e9, 1) if launch_us > 0 else 0.0,
             "mall_resident": bool(launch_bytes <= 256 * (1 << 20)),
         },
         "pack_seconds": round(pack_seconds, 3),
@@ -228,7 +236,7 @@ def main() -> int:
         try:
             with open(traffic_file) as fh:
                 tr = json.load(fh)
-            if int(tr.get("algorithmic_bytes_per_launch", 0)) == launch_bytes:
+            if int(tr.get("algorithmic_bytes_per_launch", 0)) == launch_bytes and tr.get("packing", "reference") == packing:
                 result["roofline"]["traffic"] = int(tr["traffic_bytes_per_launch"])
                 result["roofline"]["traffic_source"] = "profiles/respond_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"
         except (OSError, ValueError, KeyError):

@@ -19,6 +19,8 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "chalamet_hip.h")
 LWE_DIMENSION = 1774
 SEED_BYTE_LEN = 32
 FILTER_PARAM_BYTE_LEN = 68
+PACK_REFERENCE = 0
+PACK_DENSE64 = 1
 
 u8p = C.POINTER(C.c_uint8)
 u32p = C.c_void_p  # device or host u32 pointers are passed as raw addresses
@@ -37,6 +39,10 @@ class DtcLayout(C.Structure):
         ("words_per_row_padded", C.c_uint64),
         ("rows_padded", C.c_uint32),
         ("total_words", C.c_uint64),
+        ("packing", C.c_uint32),
+        ("fields_per_word", C.c_uint32),
+        ("chunk_words", C.c_uint32),
+        ("slots_per_chunk", C.c_uint64),
     ]
 
 
@@ -71,6 +77,7 @@ SIGNATURES = {
     "cpir_op_mat_x_mat": (C.c_int, [vp, u32p, C.c_uint64, u32p, C.c_uint64, u32p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
                                     C.c_uint32, C.c_int, vp]),
     "cpir_dtc_layout_for": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(DtcLayout)]),
+    "cpir_dtc_layout_for_packing": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(DtcLayout)]),
     "cpir_op_transpose_compress": (C.c_int, [vp, u32p, C.c_uint64, C.POINTER(DtcLayout), u32p, u32p, vp]),
     "cpir_op_dtc_import": (C.c_int, [vp, u32p, C.POINTER(DtcLayout), u32p, vp]),
     "cpir_op_dtc_export": (C.c_int, [vp, u32p, C.POINTER(DtcLayout), u32p, vp]),

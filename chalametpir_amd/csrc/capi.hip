@@ -397,6 +397,9 @@ int cpir_find_encoded_db_matrix_element_bit_length(uint64_t n, uint32_t* b) { re
 int cpir_filter_shape(uint32_t arity, uint64_t n, uint32_t* sl, uint32_t* scl, uint64_t* nf) { return filter_shape(arity, n, sl, scl, nf); }
 uint64_t cpir_encoded_num_cols(uint64_t max_value_byte_len, uint32_t b) { return encoded_num_cols(max_value_byte_len, b); }
 int cpir_dtc_layout_for(uint64_t N, uint32_t C, uint32_t b, cpir_dtc_layout* out) { return dtc_layout_for(N, C, b, out); }
+int cpir_dtc_layout_for_packing(uint64_t N, uint32_t C, uint32_t b, uint32_t packing, cpir_dtc_layout* out) {
+  return dtc_layout_for_packing(N, C, b, packing, out);
+}
 
 int cpir_generate_from_seed(uint64_t rows, uint64_t cols, const uint8_t seed[CPIR_SEED_BYTE_LEN], uint32_t* out) {
   if (!seed || !out) return CPIR_ERR_INVALID_ARGUMENT;

@@ -104,6 +104,10 @@ int find_bit_len(uint64_t n, uint32_t* b);
 int filter_shape(uint32_t arity, uint64_t n, uint32_t* seg_len, uint32_t* seg_count_len, uint64_t* num_fp);
 uint64_t encoded_num_cols(uint64_t max_value_byte_len, uint32_t b);
 int dtc_layout_for(uint64_t N, uint32_t C, uint32_t b, cpir_dtc_layout* out);
+int dtc_layout_for_packing(uint64_t N, uint32_t C, uint32_t b, uint32_t packing, cpir_dtc_layout* out);
+uint32_t dense_fields_per_word64(uint32_t b);
+void set_default_dense(bool on);
+int check_layout(const cpir_dtc_layout& L);
 
 // host_encoder.cpp : binary fuse filter + row codec (Matrix::from_kv_database)
 struct Filter {

@@ -1,4 +1,5 @@
 // host_shapes.cpp -- host-only shape arithmetic of the server path (no device needed).
+#include <atomic>
 #include <cmath>
 
 #include "cpir_internal.hpp"
@@ -59,7 +60,20 @@ uint64_t encoded_num_cols(uint64_t max_value_byte_len, uint32_t b) {
   return (256 + 8 * max_value_byte_len + 8 + b - 1) / b;
 }
 
-int dtc_layout_for(uint64_t N, uint32_t C, uint32_t b, cpir_dtc_layout* out) {
+// fields per u64 of the dense packing, or 0 where dense64 is not offered: it must be denser than the reference packing
+// (floor(64/b) > 2*cf: b in {4,5,6,7,9,11,12}), and b in {4,5,6} is left out for now -- 10..16 fields per u64 need a
+// narrower per-lane share to stay within the register file (respond.hip), and those bit lengths only occur above 2^26 keys
+uint32_t dense_fields_per_word64(uint32_t b) {
+  const uint32_t cf = compression_factor(b);
+  if (cf == 0 || b < 7) return 0;
+  const uint32_t k = 64 / b;
+  return k > 2 * cf ? k : 0;
+}
+
+static std::atomic<int> g_default_dense{1};
+void set_default_dense(bool on) { g_default_dense.store(on ? 1 : 0); }
+
+int dtc_layout_for_packing(uint64_t N, uint32_t C, uint32_t b, uint32_t packing, cpir_dtc_layout* out) {
   if (!out) return CPIR_ERR_INVALID_ARGUMENT;
   const uint32_t cf = compression_factor(b);
   if (cf == 0) return CPIR_ERR_IMPOSSIBLE_ELEMENT_BIT_LENGTH;  // matrix.rs:99-101
@@ -70,12 +84,42 @@ int dtc_layout_for(uint64_t N, uint32_t C, uint32_t b, cpir_dtc_layout* out) {
   out->mat_elem_bit_len = b;
   out->compression_factor = cf;
   out->words_per_row = (N + cf - 1) / cf;
-  out->words_per_row_padded = (out->words_per_row + CPIR_DTC_WORD_ALIGN - 1) / CPIR_DTC_WORD_ALIGN * CPIR_DTC_WORD_ALIGN;
+  out->packing = packing;
+  if (packing == CPIR_PACK_REFERENCE) {
+    out->fields_per_word = cf;
+    out->chunk_words = 1024;
+  } else if (packing == CPIR_PACK_DENSE64) {
+    const uint32_t k = dense_fields_per_word64(b);
+    if (k == 0) return CPIR_ERR_INVALID_ARGUMENT;
+    out->fields_per_word = k;
+    out->chunk_words = 2048;
+  } else {
+    return CPIR_ERR_INVALID_ARGUMENT;
+  }
+  out->slots_per_chunk = (uint64_t)out->fields_per_word * 1024;
+  const uint64_t chunks = (N + out->slots_per_chunk - 1) / out->slots_per_chunk;
+  out->words_per_row_padded = chunks * out->chunk_words;
   const uint64_t rp = ((uint64_t)C + CPIR_DTC_ROW_ALIGN - 1) / CPIR_DTC_ROW_ALIGN * CPIR_DTC_ROW_ALIGN;
   if (rp > 0xffffffffull) return CPIR_ERR_INVALID_MATRIX_DIMENSION;
   out->rows_padded = (uint32_t)rp;
   out->total_words = rp * out->words_per_row_padded;
   return CPIR_OK;
+}
+
+int dtc_layout_for(uint64_t N, uint32_t C, uint32_t b, cpir_dtc_layout* out) {
+  const bool dense = g_default_dense.load() && dense_fields_per_word64(b) != 0;
+  return dtc_layout_for_packing(N, C, b, dense ? CPIR_PACK_DENSE64 : CPIR_PACK_REFERENCE, out);
+}
+
+// a layout handed in through the C ABI must be exactly what the library would have produced for its shape
+int check_layout(const cpir_dtc_layout& L) {
+  cpir_dtc_layout want;
+  CPIR_TRY(dtc_layout_for_packing(L.num_slots, L.num_cols, L.mat_elem_bit_len, L.packing, &want));
+  const bool same = want.compression_factor == L.compression_factor && want.words_per_row == L.words_per_row &&
+                    want.words_per_row_padded == L.words_per_row_padded && want.rows_padded == L.rows_padded &&
+                    want.total_words == L.total_words && want.fields_per_word == L.fields_per_word &&
+                    want.chunk_words == L.chunk_words && want.slots_per_chunk == L.slots_per_chunk;
+  return same ? CPIR_OK : CPIR_ERR_INVALID_ARGUMENT;
 }
 
 }  // namespace cpir

@@ -123,13 +123,138 @@ __global__ void __launch_bounds__(kThreads) dtc_export_kernel(const uint32_t* __
   }
 }
 
-int check_layout(const cpir_dtc_layout& L) {
-  const uint32_t cf = compression_factor(L.mat_elem_bit_len);
-  if (cf == 0) return CPIR_ERR_IMPOSSIBLE_ELEMENT_BIT_LENGTH;
-  cpir_dtc_layout want;
-  CPIR_TRY(dtc_layout_for(L.num_slots, L.num_cols, L.mat_elem_bit_len, &want));
-  if (memcmp(&want, &L, sizeof(L)) != 0) return CPIR_ERR_INVALID_ARGUMENT;
-  return CPIR_OK;
+// ---- dense64 packing -----------------------------------------------------------------------------------------------------
+// slot (local to this DtC) -> (u64 word of the row, bit offset) -- the private permutation documented at cpir_dtc_layout
+__device__ __forceinline__ void dense_locate(uint64_t slot, uint32_t K, uint32_t B, uint64_t* word64, uint32_t* bit) {
+  const uint64_t per_chunk = (uint64_t)K * 1024;
+  const uint64_t chunk = slot / per_chunk;
+  const uint32_t within = (uint32_t)(slot % per_chunk);
+  const uint32_t j = within >> 10, p = within & 1023;
+  const uint32_t m = ((p >> 1) & 1) * 512 + 2 * (p >> 2) + (p & 1);
+  *word64 = chunk * 1024 + m;
+  *bit = j * B;
+}
+
+// inverse: (chunk, u64 word m of the chunk, field j) -> local slot
+__device__ __forceinline__ uint64_t dense_slot(uint64_t chunk, uint32_t m, uint32_t j, uint32_t K) {
+  const uint32_t L = m >> 9, r = m & 511;
+  const uint32_t p = 4 * (r >> 1) + 2 * L + (r & 1);
+  return chunk * K * 1024 + (uint64_t)j * 1024 + p;
+}
+
+// One block = 64 positions p of one chunk (all K field planes) x 32 columns of D.
+template <int B, bool VEC>
+__global__ void __launch_bounds__(kThreads) transpose_compress_dense_kernel(const uint32_t* __restrict__ D, uint64_t ldd, uint64_t N,
+                                                                             uint32_t C, uint32_t* __restrict__ dtc,
+                                                                             uint64_t row_stride, uint32_t rows_padded,
+                                                                             uint32_t* __restrict__ or_of_entries) {
+  constexpr int K = 64 / B;
+  constexpr int kCols = 32;
+  __shared__ uint16_t tile[K * 64][kCols + 2];
+
+  const int tid = threadIdx.x;
+  const uint64_t chunk = blockIdx.x >> 4;
+  const uint32_t p0 = (blockIdx.x & 15) * 64;
+  const uint32_t c0 = blockIdx.y * kCols;
+  constexpr uint32_t mask = (1u << B) - 1u;
+  uint32_t seen = 0;
+
+  // ---- load: 8 lanes x 4 columns cover the 32 tile columns of one D row; 32 rows of D per pass ----------------------
+  const int lc = (tid & 7) * 4;
+  const int lr = tid >> 3;
+#pragma unroll 2
+  for (int rr = lr; rr < K * 64; rr += kThreads / 8) {
+    const uint32_t j = rr >> 6, pp = rr & 63;
+    const uint64_t n = chunk * K * 1024 + (uint64_t)j * 1024 + p0 + pp;
+    uint32_t v[4] = {0, 0, 0, 0};
+    if (n < N) {
+      const uint32_t* src = D + n * ldd + c0 + lc;
+      if (VEC && c0 + lc + 3 < C) {
+        const uint4 t = *reinterpret_cast<const uint4*>(src);
+        v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (c0 + lc + i < C) v[i] = src[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      seen |= v[i];
+      tile[rr][lc + i] = (uint16_t)(v[i] & mask);
+    }
+  }
+  __syncthreads();
+
+  // ---- store: a wave writes, per column, two 256-byte runs of u64 words (L = 0 and L = 1 halves of the chunk) --------
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const uint32_t L = lane >> 5, mm = lane & 31;
+  const uint32_t t = (p0 >> 2) + (mm >> 1), e = mm & 1;
+  const uint32_t pp = 4 * t + 2 * L + e - p0;
+  const uint32_t m = L * 512 + 2 * t + e;
+  uint64_t* out64 = reinterpret_cast<uint64_t*>(dtc);
+  const uint64_t stride64 = row_stride / 2;
+#pragma unroll
+  for (int i = 0; i < kCols / 4; i++) {
+    const int cl = wave * (kCols / 4) + i;
+    const uint32_t c = c0 + cl;
+    if (c < rows_padded) {
+      uint64_t word = 0;
+#pragma unroll
+      for (int j = 0; j < K; j++) word |= (uint64_t)tile[j * 64 + pp][cl] << (j * B);
+      out64[(uint64_t)c * stride64 + chunk * 1024 + m] = word;
+    }
+  }
+
+  if (or_of_entries) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) seen |= __shfl_xor(seen, off, 64);
+    if (lane == 0 && seen) atomicOr(or_of_entries, seen);
+  }
+}
+
+// reference compressed matrix (C x W) -> dense64 device layout; fields >= N and bits >= b are dropped as in normalise_word
+__global__ void __launch_bounds__(kThreads) dtc_import_dense_kernel(const uint32_t* __restrict__ src, uint64_t W, uint64_t N, uint32_t C,
+                                                                     uint32_t b, uint32_t cf, uint32_t K, uint64_t* __restrict__ dtc64,
+                                                                     uint64_t stride64, uint32_t rows_padded) {
+  const uint32_t mask = (1u << b) - 1u, S = 32 / cf;
+  const uint64_t total = (uint64_t)rows_padded * stride64;
+  for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (uint64_t)gridDim.x * kThreads) {
+    const uint64_t c = i / stride64, w64 = i % stride64;
+    uint64_t word = 0;
+    if (c < C) {
+      for (uint32_t j = 0; j < K; j++) {
+        const uint64_t slot = dense_slot(w64 >> 10, (uint32_t)(w64 & 1023), j, K);
+        if (slot < N) {
+          const uint32_t f = (src[c * W + slot / cf] >> ((uint32_t)(slot % cf) * S)) & mask;
+          word |= (uint64_t)f << (j * b);
+        }
+      }
+    }
+    dtc64[i] = word;
+  }
+}
+
+__global__ void __launch_bounds__(kThreads) dtc_export_dense_kernel(const uint64_t* __restrict__ dtc64, uint64_t stride64, uint64_t W,
+                                                                     uint64_t N, uint32_t C, uint32_t b, uint32_t cf, uint32_t K,
+                                                                     uint32_t* __restrict__ dst) {
+  const uint32_t mask = (1u << b) - 1u, S = 32 / cf;
+  const uint64_t total = (uint64_t)C * W;
+  for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (uint64_t)gridDim.x * kThreads) {
+    const uint64_t c = i / W, w = i % W;
+    uint32_t out = 0;
+    for (uint32_t jj = 0; jj < cf; jj++) {
+      const uint64_t slot = w * cf + jj;
+      if (slot < N) {
+        uint64_t w64;
+        uint32_t bit;
+        dense_locate(slot, K, b, &w64, &bit);
+        out |= ((uint32_t)(dtc64[c * stride64 + w64] >> bit) & mask) << (jj * S);
+      }
+    }
+    dst[i] = out;
+  }
 }
 
 uint32_t grid_for(const Device* dev, uint64_t total) {
@@ -146,6 +271,32 @@ int launch_transpose_compress(const Device* dev, const uint32_t* D, uint64_t ldd
   (void)dev;
   if (!D || !dtc || ldd < L.num_cols) return CPIR_ERR_INVALID_ARGUMENT;
   CPIR_TRY(check_layout(L));
+  if (reinterpret_cast<uintptr_t>(dtc) % 16 != 0) return CPIR_ERR_INVALID_ARGUMENT;
+  if (L.packing == CPIR_PACK_DENSE64) {
+    const uint64_t chunks = L.words_per_row_padded / L.chunk_words;
+    if (chunks * 16 > 0x7fffffffull) return CPIR_ERR_INVALID_ARGUMENT;
+    const dim3 grid((unsigned)(chunks * 16), (L.rows_padded + 31) / 32);
+    const bool vec = (ldd % 4 == 0) && (reinterpret_cast<uintptr_t>(D) % 16 == 0);
+#define LAUNCH_DENSE(B_)                                                                                                        \
+  do {                                                                                                                          \
+    if (vec)                                                                                                                    \
+      hipLaunchKernelGGL((transpose_compress_dense_kernel<B_, true>), grid, dim3(kThreads), 0, stream, D, ldd, L.num_slots,     \
+                         L.num_cols, dtc, L.words_per_row_padded, L.rows_padded, or_of_entries);                                 \
+    else                                                                                                                        \
+      hipLaunchKernelGGL((transpose_compress_dense_kernel<B_, false>), grid, dim3(kThreads), 0, stream, D, ldd, L.num_slots,    \
+                         L.num_cols, dtc, L.words_per_row_padded, L.rows_padded, or_of_entries);                                 \
+  } while (0)
+    switch (L.mat_elem_bit_len) {
+      case 7: LAUNCH_DENSE(7); break;
+      case 9: LAUNCH_DENSE(9); break;
+      case 11: LAUNCH_DENSE(11); break;
+      case 12: LAUNCH_DENSE(12); break;
+      default: return CPIR_ERR_INVALID_ARGUMENT;
+    }
+#undef LAUNCH_DENSE
+    CPIR_HIP_TRY(hipGetLastError());
+    return CPIR_OK;
+  }
   const uint32_t cf = L.compression_factor;
   const dim3 grid((unsigned)(L.words_per_row_padded / kTileWords), (L.rows_padded + kTileCols - 1) / kTileCols);
   if (L.words_per_row_padded / kTileWords > 0x7fffffffull) return CPIR_ERR_INVALID_ARGUMENT;
@@ -164,6 +315,14 @@ int launch_transpose_compress(const Device* dev, const uint32_t* D, uint64_t ldd
 int launch_dtc_import(const Device* dev, const uint32_t* compressed, const cpir_dtc_layout& L, uint32_t* dtc, hipStream_t stream) {
   if (!compressed || !dtc) return CPIR_ERR_INVALID_ARGUMENT;
   CPIR_TRY(check_layout(L));
+  if (L.packing == CPIR_PACK_DENSE64) {
+    const uint64_t stride64 = L.words_per_row_padded / 2;
+    hipLaunchKernelGGL(dtc_import_dense_kernel, dim3(grid_for(dev, (uint64_t)L.rows_padded * stride64)), dim3(kThreads), 0, stream,
+                       compressed, L.words_per_row, L.num_slots, L.num_cols, L.mat_elem_bit_len, L.compression_factor,
+                       L.fields_per_word, reinterpret_cast<uint64_t*>(dtc), stride64, L.rows_padded);
+    CPIR_HIP_TRY(hipGetLastError());
+    return CPIR_OK;
+  }
   const uint32_t grid = grid_for(dev, L.total_words);
 #define LAUNCH(CF_)                                                                                                     \
   hipLaunchKernelGGL((dtc_import_kernel<CF_>), dim3(grid), dim3(kThreads), 0, stream, compressed, L.words_per_row,      \
@@ -180,6 +339,13 @@ int launch_dtc_export(const Device* dev, const uint32_t* dtc, const cpir_dtc_lay
   if (!compressed || !dtc) return CPIR_ERR_INVALID_ARGUMENT;
   CPIR_TRY(check_layout(L));
   const uint32_t grid = grid_for(dev, (uint64_t)L.num_cols * L.words_per_row);
+  if (L.packing == CPIR_PACK_DENSE64) {
+    hipLaunchKernelGGL(dtc_export_dense_kernel, dim3(grid), dim3(kThreads), 0, stream, reinterpret_cast<const uint64_t*>(dtc),
+                       L.words_per_row_padded / 2, L.words_per_row, L.num_slots, L.num_cols, L.mat_elem_bit_len,
+                       L.compression_factor, L.fields_per_word, compressed);
+    CPIR_HIP_TRY(hipGetLastError());
+    return CPIR_OK;
+  }
   hipLaunchKernelGGL(dtc_export_kernel, dim3(grid), dim3(kThreads), 0, stream, dtc, L.words_per_row_padded, L.words_per_row,
                      L.num_cols, compressed);
   CPIR_HIP_TRY(hipGetLastError());

@@ -3,27 +3,28 @@
 // Replaces Matrix::row_vector_x_compressed_transposed_matrix (reference chalametpir_common/src/matrix.rs:328-485), which
 // the reference runs on the CPU with rayon over the C outputs (matrix.rs:345/383/429); the reference has no GPU respond.
 //
-//   r[c] = sum_{n < N} q[n] *wrap field_{n mod cf}( DtC[c][n / cf] )            (u32, wrap-around)
+//   r[c] = sum_{n < N} q[n] *wrap f(c, n),     f(c, n) = D[n][c] & (2^b - 1)        (u32, wrap-around)
 //
-// Roofline: HBM read.  Algorithmic bytes per query = 4*C*ceil(N/cf) + 4*N + 4*C.  MFMA does not apply
-// (u32 wrap-around is not an MFMA type) and the VALU work per streamed dword is small, so the design is all about the
-// memory system of an MI355X:
+// Roofline: HBM read.  Algorithmic bytes per query = 4*C*ceil(N/cf) + 4*N + 4*C (the REFERENCE packing).
+// MFMA does not apply (u32 wrap-around is not an MFMA type) and the VALU work per streamed dword is small, so the design
+// is all about the memory system of an MI355X:
 //
-//   * work unit = R database rows x one 1024-word chunk (256 lanes x one 16-byte load per row): every wave-instruction
-//     reads 1 KiB contiguous, every lane keeps R independent 16-byte loads in flight;
-//   * the slice of q a lane needs (4*cf consecutive entries, 48 B for cf = 3) is loaded ONCE per unit into registers and
-//     reused for the R rows, so q traffic (served by L2 / Infinity Cache) is cf/R of the HBM stream;
-//   * exact u32 products without v_mul_lo_u32 (quarter rate): q is split once per unit into 16-bit halves and each
-//     field (< 2^16) goes through two full-rate v_mad_u32_u24:  acc_lo += q_lo*d, acc_hi += q_hi*d,
+//   * work unit = R database rows x one chunk of a row; every lane issues R x (1 or 2) independent 16-byte loads and every
+//     wave-instruction reads 1 KiB contiguous (`nt` policy: the database is read once per query);
+//   * the slice of q a lane needs is loaded ONCE per unit into registers and reused for the R rows, so q traffic (served by
+//     L2 / Infinity Cache) is a fraction 1/R of what a row-at-a-time kernel would pull;
+//   * exact u32 products without v_mul_lo_u32 (quarter rate): every field is < 2^16, so each product is formed from the
+//     16-bit halves of q with the full-rate 24-bit multiplier:  acc_lo += q_lo*d, acc_hi += q_hi*d,
 //     r = acc_lo + (acc_hi << 16)  -- identical mod 2^32;
-//   * persistent grid (CUs x resident blocks), units split evenly so there is no tail wave; the K (chunk) axis is first
-//     split 8 ways by blockIdx % 8 -- blocks that share an XCD (observed round-robin placement; speed only, never
-//     correctness) then share one eighth of q in that XCD's 4 MiB L2;
+//   * persistent grid (CUs x resident blocks), units split evenly so there is no tail wave; the chunk axis is first split
+//     8 ways by blockIdx % 8 -- blocks that share an XCD (observed round-robin placement; speed only, never correctness)
+//     then share one eighth of q in that XCD's 4 MiB L2;
 //   * per-row partial sums leave the block through a wave shuffle + LDS reduce and one u32 atomicAdd per (block, row);
 //     integer atomics make the result independent of arrival order, i.e. still bit-exact.
 //
-// The database rows are padded to 16 rows / 1024 words with zeros (cpir_dtc_layout), so the only ragged edge left is
-// the END OF q in the last chunk, handled by a guarded (wave-uniform) path.
+// Two packings of the fields (cpir_dtc_layout): the reference's cf fields per u32, and dense64 (K = floor(64/b) fields of b
+// bits per u64, e.g. 7 instead of 6 per 8 bytes at b = 9 => 14 % fewer bytes streamed).  Rows are padded to 16 rows / whole
+// chunks with zeros, so the only ragged edge left is the END OF q in the last chunk (guarded, wave-uniform path).
 #include "cpir_internal.hpp"
 
 namespace cpir {
@@ -31,35 +32,22 @@ namespace cpir {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kWordsPerLane = 4;
-constexpr int kChunkWords = kThreads * kWordsPerLane;
-static_assert(kChunkWords == CPIR_DTC_WORD_ALIGN, "chunk must equal the layout's word alignment");
 
 struct RespondArgs {
   const uint32_t* dtc;
   const uint32_t* q;
   uint32_t* r;
-  uint64_t row_stride;     // words
+  uint64_t row_stride;     // u32 words
   uint64_t q_len;          // entries in (each) q
   uint64_t q_slot_offset;  // first global slot held by this DtC
   uint32_t num_cols;       // C: rows of DtC that produce output
   uint32_t groups;         // rows_padded / R
-  uint32_t chunks_total;   // words_per_row_padded / 1024
-  uint32_t nx;             // K-axis split by blockIdx % nx (8 or 1)
+  uint32_t chunks_total;   // row_stride / chunk_words
+  uint32_t nx;             // chunk-axis split by blockIdx % nx (8 or 1)
   uint32_t q_scalar;       // q not 16-byte loadable -> guarded scalar loads everywhere
   uint32_t* zero_next;     // output of the NEXT launch on this stream, zeroed here so a run of launches needs one memset
   uint32_t zero_count;
 };
-
-template <int CF>
-__device__ __forceinline__ uint32_t field(uint32_t w, int j) {
-  constexpr int S = 32 / CF;
-  // unused high bits (cf = 3: bits 30,31) and bits >= b inside a slot are zero by construction of the layout
-  if (j == CF - 1) return w >> (S * (CF - 1));
-  return __builtin_amdgcn_ubfe(w, S * j, S);
-}
-
-__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) { return __umul24(a, b) + c; }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -73,15 +61,100 @@ __device__ __forceinline__ uint4 load16(const uint4* p) {
   }
 }
 
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) { return __umul24(a, b) + c; }
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
 
-template <int CF, int R, int Q, bool NT>
+// ---- packing policies ------------------------------------------------------------------------------------------------------
+// A policy says how one lane's share of a (row, chunk) unit is laid out: kLoads 16-byte pieces of the row, kNQ entries of q,
+// and which q entry multiplies which field.
+
+// The reference's words: cf fields per u32 (matrix.rs:103-167).  Lane t owns words [4t, 4t+4) of the 1024-word chunk and the
+// 4*cf consecutive q entries they cover.
+template <int CF>
+struct RefPack {
+  static constexpr int kLoads = 1;
+  static constexpr int kChunkWords = 1024;
+  static constexpr int kSlotsPerChunk = CF * 1024;
+  static constexpr int kNQ = 4 * CF;
+
+  // index (within this lane's kNQ entries) -> offset from the chunk's first slot
+  __device__ static __forceinline__ uint32_t q_offset(int tid, int i) { return (uint32_t)(CF * 4 * tid + i); }
+
+  __device__ static __forceinline__ uint32_t field(uint32_t w, int j) {
+    constexpr int S = 32 / CF;
+    // unused high bits (cf = 3: bits 30,31) and bits >= b inside a slot are zero by construction of the layout
+    if (j == CF - 1) return w >> (S * (CF - 1));
+    return __builtin_amdgcn_ubfe(w, S * j, S);
+  }
+
+  template <int Q>
+  __device__ static __forceinline__ void mac(const uint4 (&d)[kLoads], const uint32_t (&qlo)[Q][kNQ], const uint32_t (&qhi)[Q][kNQ],
+                                             uint32_t (&alo)[Q], uint32_t (&ahi)[Q]) {
+    const uint32_t wd[4] = {d[0].x, d[0].y, d[0].z, d[0].w};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int j = 0; j < CF; j++) {
+        const uint32_t f = field(wd[k], j);
+#pragma unroll
+        for (int b = 0; b < Q; b++) {
+          alo[b] = mad24(qlo[b][k * CF + j], f, alo[b]);
+          ahi[b] = mad24(qhi[b][k * CF + j], f, ahi[b]);
+        }
+      }
+  }
+};
+
+// dense64: K fields of exactly B bits per u64.  A chunk is 1024 u64 words; lane t owns u64 words {2t, 2t+1} of each 512-word
+// half (two fully coalesced 16-byte loads) and, for every field plane j, the 4 consecutive q entries j*1024 + 4t .. +3
+// (one aligned 16-byte load per plane): field j of word (L, e) multiplies q entry j*4 + 2L + e.
+template <int B>
+struct DensePack {
+  static constexpr int K = 64 / B;
+  static constexpr int kLoads = 2;
+  static constexpr int kChunkWords = 2048;
+  static constexpr int kSlotsPerChunk = K * 1024;
+  static constexpr int kNQ = 4 * K;
+
+  __device__ static __forceinline__ uint32_t q_offset(int tid, int i) { return (uint32_t)((i >> 2) * 1024 + 4 * tid + (i & 3)); }
+
+  __device__ static __forceinline__ uint32_t field(uint32_t lo, uint32_t hi, int j) {
+    const int o = j * B;
+    if (o + B <= 32) return (o + B == 32) ? (lo >> o) : __builtin_amdgcn_ubfe(lo, o, B);
+    if (o >= 32) return (j == K - 1) ? (hi >> (o - 32)) : __builtin_amdgcn_ubfe(hi, o - 32, B);  // bits above K*B are zero
+    return __builtin_amdgcn_alignbit(hi, lo, o) & ((1u << B) - 1u);                               // straddles the dword boundary
+  }
+
+  template <int Q>
+  __device__ static __forceinline__ void mac(const uint4 (&d)[kLoads], const uint32_t (&qlo)[Q][kNQ], const uint32_t (&qhi)[Q][kNQ],
+                                             uint32_t (&alo)[Q], uint32_t (&ahi)[Q]) {
+#pragma unroll
+    for (int L = 0; L < 2; L++) {
+      const uint32_t lo[2] = {d[L].x, d[L].z};
+      const uint32_t hi[2] = {d[L].y, d[L].w};
+#pragma unroll
+      for (int e = 0; e < 2; e++)
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+          const uint32_t f = field(lo[e], hi[e], j);
+#pragma unroll
+          for (int b = 0; b < Q; b++) {
+            alo[b] = mad24(qlo[b][j * 4 + 2 * L + e], f, alo[b]);
+            ahi[b] = mad24(qhi[b][j * 4 + 2 * L + e], f, ahi[b]);
+          }
+        }
+    }
+  }
+};
+
+template <class P, int R, int Q, bool NT>
 __global__ void __launch_bounds__(kThreads) respond_kernel(const RespondArgs a) {
-  constexpr int NQ = kWordsPerLane * CF;  // q entries per lane per chunk
+  constexpr int NQ = P::kNQ;
   __shared__ uint32_t sm[Q][kThreads / 64][R];
 
   const int tid = threadIdx.x;
@@ -108,20 +181,20 @@ __global__ void __launch_bounds__(kThreads) respond_kernel(const RespondArgs a) 
   uint32_t g = (uint32_t)(u_begin / span);
   uint32_t kc = kb + (uint32_t)(u_begin % span);
 
-  uint32_t acc_lo[Q][R], acc_hi[Q][R];
+  uint32_t acc_lo[R][Q], acc_hi[R][Q];
 #pragma unroll
-  for (int b = 0; b < Q; b++)
+  for (int r = 0; r < R; r++)
 #pragma unroll
-    for (int r = 0; r < R; r++) acc_lo[b][r] = acc_hi[b][r] = 0;
+    for (int b = 0; b < Q; b++) acc_lo[r][b] = acc_hi[r][b] = 0;
 
   auto flush = [&](uint32_t grp) {
 #pragma unroll
     for (int b = 0; b < Q; b++)
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        const uint32_t v = wave_sum(acc_lo[b][r] + (acc_hi[b][r] << 16));
+        const uint32_t v = wave_sum(acc_lo[r][b] + (acc_hi[r][b] << 16));
         if (lane == 0) sm[b][wave][r] = v;
-        acc_lo[b][r] = acc_hi[b][r] = 0;
+        acc_lo[r][b] = acc_hi[r][b] = 0;
       }
     __syncthreads();
     if (tid < Q * R) {
@@ -135,18 +208,19 @@ __global__ void __launch_bounds__(kThreads) respond_kernel(const RespondArgs a) 
     __syncthreads();
   };
 
+  const uint64_t stride16 = a.row_stride / 4;
   for (uint64_t u = u_begin; u < u_end; u++) {
-    const uint64_t w0 = (uint64_t)kc * kChunkWords + (uint64_t)tid * kWordsPerLane;
-    const uint64_t qbase = a.q_slot_offset + (uint64_t)CF * w0;
+    const uint64_t slot0 = a.q_slot_offset + (uint64_t)kc * P::kSlotsPerChunk;  // first slot of this chunk
     // wave-uniform: does this chunk reach past the end of q?
-    const bool guarded = a.q_scalar || (a.q_slot_offset + (uint64_t)CF * ((uint64_t)(kc + 1) * kChunkWords) > a.q_len);
+    const bool guarded = a.q_scalar || (slot0 + P::kSlotsPerChunk > a.q_len);
 
-    // ---- the R x 16-byte database loads of this unit (issued first: they are the long-latency HBM stream) -------
-    const uint4* p = reinterpret_cast<const uint4*>(a.dtc + (uint64_t)g * R * a.row_stride + w0);
-    const uint64_t stride16 = a.row_stride / 4;
-    uint4 d[R];
+    // ---- the database loads of this unit (issued first: they are the long-latency HBM stream) ---------------------
+    const uint4* p = reinterpret_cast<const uint4*>(a.dtc + (uint64_t)g * R * a.row_stride + (uint64_t)kc * P::kChunkWords) + tid;
+    uint4 d[R][P::kLoads];
 #pragma unroll
-    for (int r = 0; r < R; r++) d[r] = load16<NT>(p + (uint64_t)r * stride16);
+    for (int r = 0; r < R; r++)
+#pragma unroll
+      for (int l = 0; l < P::kLoads; l++) d[r][l] = load16<NT>(p + (uint64_t)r * stride16 + l * kThreads);
 
     // ---- this lane's slice of q, split into 16-bit halves ---------------------------------------------------------
     uint32_t qlo[Q][NQ], qhi[Q][NQ];
@@ -155,10 +229,9 @@ __global__ void __launch_bounds__(kThreads) respond_kernel(const RespondArgs a) 
       const uint32_t* qb = a.q + (uint64_t)b * a.q_len;
       uint32_t qv[NQ];
       if (!guarded) {
-        const uint4* q4 = reinterpret_cast<const uint4*>(qb + qbase);
 #pragma unroll
-        for (int i = 0; i < CF; i++) {
-          const uint4 t = q4[i];
+        for (int i = 0; i < NQ / 4; i++) {  // q_offset(tid, 4i) is a multiple of 4 for both packings
+          const uint4 t = *reinterpret_cast<const uint4*>(qb + slot0 + P::q_offset(tid, 4 * i));
           qv[4 * i + 0] = t.x;
           qv[4 * i + 1] = t.y;
           qv[4 * i + 2] = t.z;
@@ -166,7 +239,10 @@ __global__ void __launch_bounds__(kThreads) respond_kernel(const RespondArgs a) 
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < NQ; i++) qv[i] = (qbase + i < a.q_len) ? qb[qbase + i] : 0u;
+        for (int i = 0; i < NQ; i++) {
+          const uint64_t n = slot0 + P::q_offset(tid, i);
+          qv[i] = (n < a.q_len) ? qb[n] : 0u;
+        }
       }
 #pragma unroll
       for (int i = 0; i < NQ; i++) {
@@ -177,21 +253,7 @@ __global__ void __launch_bounds__(kThreads) respond_kernel(const RespondArgs a) 
 
     // ---- multiply-accumulate ---------------------------------------------------------------------------------------
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-      const uint32_t wd[4] = {d[r].x, d[r].y, d[r].z, d[r].w};
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-#pragma unroll
-        for (int jf = 0; jf < CF; jf++) {
-          const uint32_t f = field<CF>(wd[k], jf);
-#pragma unroll
-          for (int b = 0; b < Q; b++) {
-            acc_lo[b][r] = mad24(qlo[b][k * CF + jf], f, acc_lo[b][r]);
-            acc_hi[b][r] = mad24(qhi[b][k * CF + jf], f, acc_hi[b][r]);
-          }
-        }
-      }
-    }
+    for (int r = 0; r < R; r++) P::template mac<Q>(d[r], qlo, qhi, acc_lo[r], acc_hi[r]);
 
     // ---- next unit -------------------------------------------------------------------------------------------------
     kc++;
@@ -206,10 +268,10 @@ __global__ void __launch_bounds__(kThreads) respond_kernel(const RespondArgs a) 
 
 // ---- tuning state (benchmark harness can override; defaults chosen from measurements) ----------------
 struct Tuning {
-  int rows_per_unit = 8;   // R in {4, 8, 16}
+  int rows_per_unit = 8;   // R in {4, 8, 16} (reference packing, single query)
   int nontemporal = 1;     // streamed DB loads with the nt cache policy (read once per query; keeps q in L2)
-  int blocks_per_cu = 2;   // resident 256-thread blocks per CU; 0 = ask the occupancy API (7 for R = 8)
-  int xcd_split = 1;       // split the K axis by blockIdx % 8
+  int blocks_per_cu = 2;   // resident 256-thread blocks per CU; 0 = ask the occupancy API
+  int xcd_split = 1;       // split the chunk axis by blockIdx % 8
   int batch_fusion = 1;    // respond_batch: 1 = passes of 4/2/1 queries share one DB stream, 0 = one pass per query
 };
 Tuning g_tuning;
@@ -217,24 +279,43 @@ std::mutex g_tuning_mu;
 
 using KernelFn = void (*)(const RespondArgs);
 
-template <int CF, int Q>
-KernelFn pick_kernel(int R, bool nt) {
-  if constexpr (Q == 1) {
-    if (R == 4) return nt ? respond_kernel<CF, 4, Q, true> : respond_kernel<CF, 4, Q, false>;
-    if (R == 16) return nt ? respond_kernel<CF, 16, Q, true> : respond_kernel<CF, 16, Q, false>;
-    return nt ? respond_kernel<CF, 8, Q, true> : respond_kernel<CF, 8, Q, false>;
+struct Picked {
+  KernelFn fn = nullptr;
+  int R = 0;
+};
+
+template <class P, int Q>
+Picked pick_rows(int R, bool nt) {
+  if constexpr (Q == 1 && P::kLoads == 1) {
+    if (R == 4) return {nt ? respond_kernel<P, 4, 1, true> : respond_kernel<P, 4, 1, false>, 4};
+    if (R == 16) return {nt ? respond_kernel<P, 16, 1, true> : respond_kernel<P, 16, 1, false>, 16};
+    return {nt ? respond_kernel<P, 8, 1, true> : respond_kernel<P, 8, 1, false>, 8};
+  } else if constexpr (Q == 1) {
+    // dense64: two loads per row per lane; R = 8 keeps 16 loads in flight per lane, R = 4 for tuning
+    if (R == 4) return {nt ? respond_kernel<P, 4, 1, true> : respond_kernel<P, 4, 1, false>, 4};
+    return {nt ? respond_kernel<P, 8, 1, true> : respond_kernel<P, 8, 1, false>, 8};
   } else {
-    // batched variants keep Q*R accumulator pairs in registers: R is fixed at 4
-    return nt ? respond_kernel<CF, 4, Q, true> : respond_kernel<CF, 4, Q, false>;
+    // fused batches keep Q*R accumulator pairs in registers
+    constexpr int RB = (P::kLoads == 1) ? 4 : 2;
+    return {nt ? respond_kernel<P, RB, Q, true> : respond_kernel<P, RB, Q, false>, RB};
   }
 }
 
 template <int Q>
-KernelFn pick_kernel_cf(uint32_t cf, int R, bool nt) {
-  switch (cf) {
-    case 2: return pick_kernel<2, Q>(R, nt);
-    case 3: return pick_kernel<3, Q>(R, nt);
-    default: return pick_kernel<4, Q>(R, nt);
+Picked pick_kernel(const cpir_dtc_layout& L, int R, bool nt) {
+  if (L.packing == CPIR_PACK_REFERENCE) {
+    switch (L.compression_factor) {
+      case 2: return pick_rows<RefPack<2>, Q>(R, nt);
+      case 3: return pick_rows<RefPack<3>, Q>(R, nt);
+      default: return pick_rows<RefPack<4>, Q>(R, nt);
+    }
+  }
+  switch (L.mat_elem_bit_len) {  // the bit lengths dense_fields_per_word64() offers
+    case 7: return pick_rows<DensePack<7>, Q>(R, nt);
+    case 9: return pick_rows<DensePack<9>, Q>(R, nt);
+    case 11: return pick_rows<DensePack<11>, Q>(R, nt);
+    case 12: return pick_rows<DensePack<12>, Q>(R, nt);
+    default: return {};
   }
 }
 
@@ -255,6 +336,8 @@ extern "C" int cpir_tuning_set(const char* key, int value) {
     g_tuning.xcd_split = value ? 1 : 0;
   } else if (!strcmp(key, "respond.batch_fusion")) {
     g_tuning.batch_fusion = value ? 1 : 0;
+  } else if (!strcmp(key, "layout.dense")) {
+    set_default_dense(value != 0);
   } else {
     return CPIR_ERR_INVALID_ARGUMENT;
   }
@@ -278,33 +361,23 @@ int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout
                    uint64_t q_slot_offset, uint32_t batch, uint32_t* r, uint32_t* /*scratch*/, hipStream_t stream,
                    bool r_is_zero, uint32_t* zero_next, uint32_t zero_count) {
   if (!dtc || !q || !r || batch == 0) return CPIR_ERR_INVALID_ARGUMENT;
-  const uint32_t cf = L.compression_factor;
-  if (cf != compression_factor(L.mat_elem_bit_len) || cf == 0) return CPIR_ERR_IMPOSSIBLE_ELEMENT_BIT_LENGTH;
   // shape invariants every kernel variant relies on (checked on the host before any launch)
-  if (L.words_per_row_padded == 0 || L.words_per_row_padded % kChunkWords != 0 || L.rows_padded % CPIR_DTC_ROW_ALIGN != 0 ||
-      L.rows_padded < L.num_cols || L.words_per_row_padded < L.words_per_row ||
-      L.words_per_row != (L.num_slots + cf - 1) / cf)
-    return CPIR_ERR_INVALID_ARGUMENT;
-  if (q_slot_offset % cf != 0 || q_slot_offset + L.num_slots > q_len) return CPIR_ERR_SHARD_RANGE;
+  CPIR_TRY(check_layout(L));
+  if (q_slot_offset % L.compression_factor != 0 || q_slot_offset + L.num_slots > q_len) return CPIR_ERR_SHARD_RANGE;
   if (reinterpret_cast<uintptr_t>(dtc) % 16 != 0) return CPIR_ERR_INVALID_ARGUMENT;
-  if (L.words_per_row_padded / kChunkWords > 0xffffffffull) return CPIR_ERR_INVALID_ARGUMENT;
+  if (L.words_per_row_padded / L.chunk_words > 0xffffffffull) return CPIR_ERR_INVALID_ARGUMENT;
 
   Tuning t;
   {
     std::lock_guard<std::mutex> lk(g_tuning_mu);
     t = g_tuning;
   }
-  int R = t.rows_per_unit;
-  KernelFn fn = nullptr;
-  if (batch == 1) {
-    fn = pick_kernel_cf<1>(cf, R, t.nontemporal);
-  } else if (batch == 2) {
-    fn = pick_kernel_cf<2>(cf, R, t.nontemporal), R = 4;
-  } else if (batch == 4) {
-    fn = pick_kernel_cf<4>(cf, R, t.nontemporal), R = 4;
-  } else {
-    return CPIR_ERR_INVALID_ARGUMENT;  // callers split other batch sizes into 4 / 2 / 1
-  }
+  Picked k;
+  if (batch == 1) k = pick_kernel<1>(L, t.rows_per_unit, t.nontemporal);
+  else if (batch == 2) k = pick_kernel<2>(L, t.rows_per_unit, t.nontemporal);
+  else if (batch == 4) k = pick_kernel<4>(L, t.rows_per_unit, t.nontemporal);
+  else return CPIR_ERR_INVALID_ARGUMENT;  // callers split other batch sizes into 4 / 2 / 1
+  if (!k.fn) return CPIR_ERR_INVALID_ARGUMENT;
 
   RespondArgs a;
   a.dtc = dtc;
@@ -314,14 +387,16 @@ int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout
   a.q_len = q_len;
   a.q_slot_offset = q_slot_offset;
   a.num_cols = L.num_cols;
-  a.groups = L.rows_padded / (uint32_t)R;
-  a.chunks_total = (uint32_t)(L.words_per_row_padded / kChunkWords);
+  a.groups = L.rows_padded / (uint32_t)k.R;
+  a.chunks_total = (uint32_t)(L.words_per_row_padded / L.chunk_words);
   a.q_scalar = (reinterpret_cast<uintptr_t>(q) % 16 != 0 || q_slot_offset % 4 != 0 || (batch > 1 && q_len % 4 != 0)) ? 1u : 0u;
+  a.zero_next = zero_next;
+  a.zero_count = zero_next ? zero_count : 0;
 
   int bpc = t.blocks_per_cu;
   if (bpc == 0) {
     int occ = 0;
-    CPIR_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(fn), kThreads, 0));
+    CPIR_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(k.fn), kThreads, 0));
     bpc = occ < 1 ? 1 : (occ > 8 ? 8 : occ);
   }
   const uint64_t units = (uint64_t)a.groups * a.chunks_total;
@@ -333,10 +408,8 @@ int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout
     if (grid == 0) grid = 1, a.nx = 1;
   }
 
-  a.zero_next = zero_next;
-  a.zero_count = zero_next ? zero_count : 0;
   if (!r_is_zero) CPIR_HIP_TRY(hipMemsetAsync(r, 0, (size_t)batch * L.num_cols * sizeof(uint32_t), stream));
-  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(kThreads), 0, stream, a);
+  hipLaunchKernelGGL(k.fn, dim3((unsigned)grid), dim3(kThreads), 0, stream, a);
   CPIR_HIP_TRY(hipGetLastError());
   return CPIR_OK;
 }

@@ -19,16 +19,14 @@ from typing import Optional, Tuple
 
 from .server import Device, Server
 
-SHARD_UNIT_WORDS = 1024  # shards start on a 1024-word chunk boundary of the packed rows (cpir_dtc_layout word alignment)
-
-
-def shard_range(total_slots: int, compression_factor: int, rank: int, world_size: int) -> Tuple[int, int]:
-    """Slots [begin, end) held by `rank`.  Boundaries are multiples of cf*1024 slots so that no packed word, 16-byte
-    query load or 1024-word chunk straddles two shards; the last shard takes the ragged tail.  Shards may be empty when
-    there are fewer chunks than ranks."""
+def shard_range(total_slots: int, slots_per_chunk: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Slots [begin, end) held by `rank`.  Boundaries are multiples of the packing's chunk (`cpir_dtc_layout.slots_per_chunk`:
+    cf*1024 slots for the reference packing, K*1024 for dense64) so that no packed word, 16-byte query load or chunk
+    straddles two shards; the last shard takes the ragged tail.  Shards may be empty when there are fewer chunks than
+    ranks."""
     if not (0 <= rank < world_size):
         raise ValueError("rank out of range")
-    unit = compression_factor * SHARD_UNIT_WORDS
+    unit = int(slots_per_chunk)
     n_units = -(-total_slots // unit)
     lo = (n_units * rank // world_size) * unit
     hi = (n_units * (rank + 1) // world_size) * unit

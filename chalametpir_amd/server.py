@@ -108,9 +108,14 @@ class Device:
         _check(self._lib.cpir_op_synth_fill(self._h, _tensor_ptr(out) + 4 * offset_words, count, seed, index0, mask, _stream_ptr(stream)))
 
 
-def dtc_layout_for(num_slots: int, num_cols: int, mat_elem_bit_len: int) -> DtcLayout:
+def dtc_layout_for(num_slots: int, num_cols: int, mat_elem_bit_len: int, packing: Optional[int] = None) -> DtcLayout:
+    """cpir_dtc_layout of the device-resident packed DB; packing None = the library default (dense64 where offered),
+    0 = reference packing, 1 = dense64"""
     L = DtcLayout()
-    _check(_native.load().cpir_dtc_layout_for(num_slots, num_cols, mat_elem_bit_len, C.byref(L)))
+    if packing is None:
+        _check(_native.load().cpir_dtc_layout_for(num_slots, num_cols, mat_elem_bit_len, C.byref(L)))
+    else:
+        _check(_native.load().cpir_dtc_layout_for_packing(num_slots, num_cols, mat_elem_bit_len, packing, C.byref(L)))
     return L
 
 

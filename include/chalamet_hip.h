@@ -111,28 +111,51 @@ int cpir_op_mat_x_mat(cpir_device* dev, const uint32_t* A, uint64_t lda, const u
                       void* stream);
 
 /* Layout of the device-resident packed database ("DtC").  The logical content is exactly
- * Matrix::transpose (matrix.rs:517-527) followed by Matrix::row_wise_compress (matrix.rs:98-205):
- *   word(c, w) = sum_{j<cf} (D[cf*w + j][c] & (2^b - 1)) << (j * 32/cf),  missing tail fields = 0,
- * stored row-major with the row stride padded to `words_per_row_padded` (zero words) and rows padded to
- * `rows_padded` (zero rows) so every 16-byte load is aligned and no kernel needs a ragged tail. */
+ * Matrix::transpose (matrix.rs:517-527) followed by Matrix::row_wise_compress (matrix.rs:98-205): for every column c of D
+ * (= row c of DtC) the N fields  f(c, n) = D[n][c] & (2^b - 1).  Two physical packings of those fields exist:
+ *
+ *  CPIR_PACK_REFERENCE  the reference's own words:  word(c, w) = sum_{j<cf} f(c, cf*w + j) << (j * 32/cf), cf = 2/3/4
+ *                       fields per u32 (matrix.rs:103-167); a chunk is 1024 u32 words of one row (cf*1024 slots).
+ *  CPIR_PACK_DENSE64    K = floor(64 / b) fields of exactly b bits per u64 (b = 9: 7 per 8 bytes instead of 6), used when
+ *                       it is denser than the reference packing.  A chunk is 1024 u64 words of one row (K*1024 slots);
+ *                       inside a chunk field j of u64 word m holds slot  chunk_base + j*1024 + p(m),  where
+ *                       m = L*512 + 2t + e  <->  p = 4t + 2L + e  (t < 256, L,e in {0,1}): lane t of a workgroup then reads
+ *                       two fully coalesced 16-byte pieces per row and, per field plane j, ONE aligned 16-byte piece of q.
+ *
+ * Either way rows are stored row-major with the row stride padded to whole chunks (zero words) and the row count padded to
+ * CPIR_DTC_ROW_ALIGN (zero rows), so every 16-byte load is aligned and no kernel has a ragged tail.  The packing is private to
+ * the device: cpir_op_dtc_import / _export and cpir_server_from_compressed / _export_compressed convert from / to the
+ * reference's C x ceil(N/cf) matrix bit-exactly. */
+#define CPIR_PACK_REFERENCE 0u
+#define CPIR_PACK_DENSE64 1u
 typedef struct cpir_dtc_layout {
   uint64_t num_slots;            /* N: filter slots = rows of D = decompressed columns of D^T (server.rs:66) */
   uint32_t num_cols;             /* C: columns of D = rows of D^T = response length */
   uint32_t mat_elem_bit_len;     /* b */
-  uint32_t compression_factor;   /* cf */
-  uint64_t words_per_row;        /* W = ceil(N / cf): the reference's compressed width */
-  uint64_t words_per_row_padded; /* row stride in u32 words, multiple of CPIR_DTC_WORD_ALIGN */
+  uint32_t compression_factor;   /* cf of the REFERENCE packing (2/3/4), whatever the device packing is */
+  uint64_t words_per_row;        /* W = ceil(N / cf): the reference's compressed width (import / export shape) */
+  uint64_t words_per_row_padded; /* device row stride in u32 words, multiple of chunk_words */
   uint32_t rows_padded;          /* >= C, multiple of CPIR_DTC_ROW_ALIGN */
-  uint64_t total_words;          /* rows_padded * words_per_row_padded */
+  uint64_t total_words;          /* rows_padded * words_per_row_padded (u32 words of device memory) */
+  uint32_t packing;              /* CPIR_PACK_REFERENCE or CPIR_PACK_DENSE64 */
+  uint32_t fields_per_word;      /* cf (per u32) for the reference packing, K (per u64) for dense64 */
+  uint32_t chunk_words;          /* u32 words of one row per chunk: 1024 (reference) or 2048 (dense64) */
+  uint64_t slots_per_chunk;      /* cf*1024 or K*1024: shard boundaries must be multiples of this */
 } cpir_dtc_layout;
 #define CPIR_DTC_WORD_ALIGN 1024u
 #define CPIR_DTC_ROW_ALIGN 16u
 
+/* Default layout for a database shape: dense64 where it is offered (b in {7, 9, 11, 12}: denser than the reference packing
+ * and within the kernels' register budget), the reference packing otherwise; cpir_tuning_set("layout.dense", 0) forces the reference packing process-wide. */
 int cpir_dtc_layout_for(uint64_t num_slots, uint32_t num_cols, uint32_t mat_elem_bit_len, cpir_dtc_layout* out);
+/* Explicit packing choice (CPIR_ERR_INVALID_ARGUMENT if dense64 is not offered for b). */
+int cpir_dtc_layout_for_packing(uint64_t num_slots, uint32_t num_cols, uint32_t mat_elem_bit_len, uint32_t packing,
+                                cpir_dtc_layout* out);
 
 /* gpu_utils::mat_transpose + shaders/mat_transpose.glsl (gpu_utils.rs:222-281) FUSED with the CPU
  * Matrix::row_wise_compress the reference runs after reading the transpose back (server.rs:151-156):
- * D (N x C, leading dim ldd, device) -> packed DtC (device, `layout->total_words` u32, fully written incl. padding).
+ * D (N x C, leading dim ldd, device) -> packed DtC in `layout->packing` (device, `layout->total_words` u32, fully written
+ * incl. padding).
  * If `or_of_entries` (device u32) is non-NULL the bitwise OR of all D entries is OR-ed into it (lets the caller prove
  * the rhs_max_bits bound it passes to cpir_op_mat_x_mat). */
 int cpir_op_transpose_compress(cpir_device* dev, const uint32_t* D, uint64_t ldd, const cpir_dtc_layout* layout,
@@ -166,7 +189,8 @@ int cpir_op_synth_fill(cpir_device* dev, uint32_t* out, uint64_t count, uint64_t
 /* Tuning knobs of the respond kernel (benchmark harness only; defaults are the measured best):
  *   "respond.rows_per_unit" in {4, 8, 16}, "respond.nontemporal" {0,1}, "respond.blocks_per_cu" 0..8 (0 = occupancy API),
  *   "respond.xcd_split" {0,1}, "respond.batch_fusion" {0,1} (0: every query of a batch call streams the database on its
- *   own, i.e. a batch call is only a cheaper way to enqueue independent responds).
+ *   own, i.e. a batch call is only a cheaper way to enqueue independent responds), "layout.dense" {0,1} (default packing
+ *   chosen by cpir_dtc_layout_for and therefore by every cpir_server_* constructor).
  * Process-wide; results are bit-identical for every setting. */
 int cpir_tuning_set(const char* key, int value);
 /* Name of the dominant kernel last launched by cpir_op_respond for this layout (for matching rocprof traces). */

@@ -31,9 +31,9 @@ def main():
         want_r = orc.row_vector_x_compressed_transposed_matrix(q, orc.row_wise_compress(orc.transpose(D), b), N, b)[0]
         want_m = orc.mul(A, D)
 
-        lo, hi = shard_range(N, cf, rank, world)
+        lo, hi = shard_range(N, cf * 1024, rank, world)
         # shards tile [0, N) without gaps or overlaps and start on packing-unit boundaries
-        bounds = [shard_range(N, cf, r, world) for r in range(world)]
+        bounds = [shard_range(N, cf * 1024, r, world) for r in range(world)]
         assert bounds[0][0] == 0 and bounds[-1][1] == N
         assert all(bounds[i][1] == bounds[i + 1][0] for i in range(world - 1))
         assert all(lo_ % (cf * 1024) == 0 for lo_, _ in bounds)

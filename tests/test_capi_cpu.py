@@ -65,19 +65,41 @@ def test_baseline_config_shapes(native):
         assert cp.filter_shape(arity, n)[2] == N
         assert cp.encoded_num_cols(vb, b) == Cc
         L = cp.dtc_layout_for(N, Cc, b)
-        assert L.words_per_row == -(-N // 3) and L.words_per_row_padded % 1024 == 0 and L.rows_padded % 16 == 0
+        assert L.words_per_row == -(-N // 3) and L.words_per_row_padded % L.chunk_words == 0 and L.rows_padded % 16 == 0
         assert L.total_words == L.rows_padded * L.words_per_row_padded  # 64-bit: cfg 4/5 exceed 2^32 elements
+        ref = cp.dtc_layout_for(N, Cc, b, packing=0)
+        assert (ref.packing, ref.fields_per_word, ref.chunk_words) == (0, 3, 1024)
+        if b == 9:  # dense64: 7 fields per u64 -> 6/7 of the reference packing's bytes
+            assert (L.packing, L.fields_per_word, L.slots_per_chunk) == (1, 7, 7168)
+            assert 0.85 < L.total_words / ref.total_words < 0.87
+        else:  # b = 10: 6 fields per u64 either way, the reference packing stays
+            assert L.packing == 0
 
 
 def test_layout_invariants(native):
     import chalametpir_amd as cp
 
     for N, Cc, b in ((1, 1, 4), (7, 3, 9), (3 * 1024, 16, 10), (3 * 1024 + 1, 17, 10), (12345, 999, 13)):
-        L = cp.dtc_layout_for(N, Cc, b)
+        L = cp.dtc_layout_for(N, Cc, b, packing=0)
         cf = cf_of(b)
         assert (L.num_slots, L.num_cols, L.mat_elem_bit_len, L.compression_factor) == (N, Cc, b, cf)
         assert L.words_per_row == -(-N // cf) <= L.words_per_row_padded < L.words_per_row + 1024
         assert Cc <= L.rows_padded < Cc + 16
+    for b in range(4, 15):  # dense64 is offered exactly for b in {7, 9, 11, 12}
+        L = cp.dtc_layout_for(50_000, 10, b)
+        if b in (7, 9, 11, 12):
+            K = 64 // b
+            assert (L.packing, L.fields_per_word, L.chunk_words, L.slots_per_chunk) == (1, K, 2048, K * 1024)
+            assert L.words_per_row_padded == -(-50_000 // (K * 1024)) * 2048
+        else:
+            assert L.packing == 0
+            with pytest.raises(cp.ChalametPIRError):
+                cp.dtc_layout_for(50_000, 10, b, packing=1)
+    cp.tuning_set("layout.dense", 0)
+    try:
+        assert cp.dtc_layout_for(50_000, 10, 9).packing == 0
+    finally:
+        cp.tuning_set("layout.dense", 1)
     for args, variant in (((0, 3, 9), "InvalidMatrixDimension"), ((5, 0, 9), "InvalidMatrixDimension"),
                           ((5, 3, 3), "ImpossibleEncodedDBMatrixElementBitLength")):
         with pytest.raises(cp.ChalametPIRError) as e:

@@ -14,7 +14,7 @@ def test_shard_range_properties():
     for N in (1, 100, 3071, 3072, 3073, 1_179_648, 4_718_592):
         for cf in (2, 3, 4):
             for world in (1, 2, 3, 4, 8):
-                b = [shard_range(N, cf, r, world) for r in range(world)]
+                b = [shard_range(N, cf * 1024, r, world) for r in range(world)]
                 assert b[0][0] == 0 and b[-1][1] == N
                 for i in range(world):
                     lo, hi = b[i]
@@ -22,9 +22,12 @@ def test_shard_range_properties():
                     if i:
                         assert lo == b[i - 1][1]
     # the bench config splits evenly over 8 GPUs
-    assert [hi - lo for lo, hi in (shard_range(1_179_648, 3, r, 8) for r in range(8))] == [147_456] * 8
+    assert [hi - lo for lo, hi in (shard_range(1_179_648, 3 * 1024, r, 8) for r in range(8))] == [147_456] * 8
+    # dense64 at b = 9: 7 * 1024 slots per chunk, 165 chunks (the last one ragged) over 8 ranks
+    sizes = [hi - lo for lo, hi in (shard_range(1_179_648, 7 * 1024, r, 8) for r in range(8))]
+    assert sum(sizes) == 1_179_648 and max(sizes) - min(sizes) <= 7 * 1024 + 4096
     with pytest.raises(ValueError):
-        shard_range(10, 3, 2, 2)
+        shard_range(10, 3 * 1024, 2, 2)
 
 
 @pytest.mark.parametrize("world", [2, 3])

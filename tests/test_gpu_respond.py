@@ -13,6 +13,17 @@ from _cases import ALL_BITS, cf_of, random_db_matrix, random_query, unwire, wire
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["reference-packing", "dense64-where-offered"])
+def packing(request, native):
+    """every test of this module runs once with the reference packing forced and once with the default (dense64 for
+    b in {7, 9, 11, 12}); results must be bit-identical either way"""
+    import chalametpir_amd as cp
+
+    cp.tuning_set("layout.dense", 0 if request.param.startswith("reference") else 1)
+    yield request.param
+    cp.tuning_set("layout.dense", 1)
+
+
 def make_server(cp, orc, device, rng, N, C, b):
     D = random_db_matrix(rng, N, C, b)
     dtc = orc.row_wise_compress(orc.transpose(D), b)  # server.rs:64-67 on the oracle
@@ -195,7 +206,7 @@ def test_device_entry_points_shards_and_batches(orc, device):
     rng = np.random.default_rng(31)
     for b in (9, 12, 6):
         cf = cf_of(b)
-        N, C = cf * 1024 * 5 + cf * 100 + 1, 37
+        N, C = cf * 1024 * 9 + cf * 100 + 1, 37
         D = random_db_matrix(rng, N, C, b)
         dtc_full = orc.row_wise_compress(orc.transpose(D), b)
         q = random_query(rng, N)
@@ -203,8 +214,9 @@ def test_device_entry_points_shards_and_batches(orc, device):
         q_dev = torch.from_numpy(q.view(np.int32)).cuda()
         total = np.zeros(C, dtype=np.uint32)
         world = 3
+        unit = cp.dtc_layout_for(N, C, b).slots_per_chunk
         for rank in range(world):
-            lo, hi = shard_range(N, cf, rank, world)
+            lo, hi = shard_range(N, unit, rank, world)
             if hi <= lo:
                 continue
             D_dev = torch.from_numpy(np.ascontiguousarray(D[lo:hi]).view(np.int32)).cuda()

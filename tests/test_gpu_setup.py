@@ -8,6 +8,15 @@ from _cases import ALL_BITS, cf_of, random_db_matrix, random_query, unwire, wire
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["reference-packing", "dense64-where-offered"])
+def packing(request, native):
+    import chalametpir_amd as cp
+
+    cp.tuning_set("layout.dense", 0 if request.param.startswith("reference") else 1)
+    yield request.param
+    cp.tuning_set("layout.dense", 1)
+
+
 def _dev(a):
     import torch
 
@@ -39,8 +48,20 @@ def test_transpose_compress_matches_oracle(b, orc, device):
         device.transpose_compress(_dev(D), L, dtc, or_of_entries=flag, stream=torch.cuda.current_stream())
         torch.cuda.synchronize()
         img = _host(dtc).reshape(L.rows_padded, L.words_per_row_padded)
-        assert np.array_equal(img[:C, : L.words_per_row], want)
-        assert not img[C:].any() and not img[:, L.words_per_row:].any()
+        assert not img[C:].any()  # padded rows are zero
+        if L.packing == 0:  # reference packing: the device image IS the reference matrix plus zero padding
+            assert np.array_equal(img[:C, : L.words_per_row], want)
+            assert not img[:, L.words_per_row:].any()
+        else:  # dense64: K fields of b bits per u64; every field lives at the documented (chunk, plane, position)
+            K = L.fields_per_word
+            img64 = img.view(np.uint64)
+            n = np.arange(N, dtype=np.uint64)
+            chunk, within = n // (K * 1024), n % (K * 1024)
+            j, p = within // 1024, within % 1024
+            m = ((p >> 1) & 1) * 512 + 2 * (p >> 2) + (p & 1)
+            got = (img64[:C][:, (chunk * 1024 + m).astype(np.int64)] >> (j * b).astype(np.uint64)) & np.uint64((1 << b) - 1)
+            assert np.array_equal(got.astype(np.uint32), (D & ((1 << b) - 1)).T)
+            assert int(np.count_nonzero(img64[:C])) <= N * C  # nothing but fields: unused positions and top bits stay zero
         assert int(_host(flag)[0]) == int(np.bitwise_or.reduce(D, axis=None))
 
 
