@@ -57,7 +57,7 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
-    ap.add_argument("--queries-per-step", type=int, default=16)
+    ap.add_argument("--queries-per-step", type=int, default=32)
     ap.add_argument("--query-pool", type=int, default=64, help="distinct queries cycled through (no query-side caching)")
     ap.add_argument("--no-setup", action="store_true", help="skip the server_setup timing (needs A: 8.4 GB at cfg2, ~10 s of host XOF)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

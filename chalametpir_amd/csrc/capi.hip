@@ -591,7 +591,7 @@ int cpir_server_from_device_matrix(cpir_device* dev, const uint32_t* D_dev, uint
   *out = nullptr;
   cpir_dtc_layout L;
   CPIR_TRY(dtc_layout_for(N_shard, C, b, &L));
-  if (slot_offset % L.compression_factor != 0 || slot_offset + N_shard > total_slots) return CPIR_ERR_SHARD_RANGE;
+  if (slot_offset + N_shard > total_slots) return CPIR_ERR_SHARD_RANGE;
   DeviceGuard g(dev->ordinal);
   Server* srv = server_new(dev, L, slot_offset, total_slots);
   hipError_t e = hipMalloc(&srv->dtc, (size_t)L.total_words * 4);

@@ -14,8 +14,8 @@
 //   * the slice of q a lane needs is loaded ONCE per unit into registers and reused for the R rows, so q traffic (served by
 //     L2 / Infinity Cache) is a fraction 1/R of what a row-at-a-time kernel would pull;
 //   * exact u32 products without v_mul_lo_u32 (quarter rate): every field is < 2^16, so each product is formed from the
-//     16-bit halves of q with the full-rate 24-bit multiplier:  acc_lo += q_lo*d, acc_hi += q_hi*d,
-//     r = acc_lo + (acc_hi << 16)  -- identical mod 2^32;
+//     16-bit halves of q on the full-rate 16x16+32 multiplier (v_mad_u32_u16, halves picked by op_sel):
+//     acc_lo += q.lo*d, acc_hi += q.hi*d, r = acc_lo + (acc_hi << 16)  -- identical mod 2^32, one VALU op per product;
 //   * persistent grid (CUs x resident blocks), units split evenly so there is no tail wave; the chunk axis is first split
 //     8 ways by blockIdx % 8 -- blocks that share an XCD (observed round-robin placement; speed only, never correctness)
 //     then share one eighth of q in that XCD's 4 MiB L2;
@@ -61,7 +61,21 @@ __device__ __forceinline__ uint4 load16(const uint4* p) {
   }
 }
 
-__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) { return __umul24(a, b) + c; }
+// acc + (16-bit half of q) * (16-bit half of f), wrap-around: ONE full-rate v_mad_u32_u16, the halves picked by op_sel
+// (QH / FH = 1 takes bits 31..16).  This is the whole trick behind exact u32 products on the fast multiplier:
+//   q*f mod 2^32 = q.lo*f + ((q.hi*f) << 16)   for f < 2^16,
+// so two accumulators per output are kept and combined once at the end -- and q never has to be split into separate
+// registers (hipcc, left alone, picks v_mul_u32_u24 with SDWA operands plus a separate add per product).
+// Plain VALU in an asm statement: no memory effects, no wait states to declare.
+template <int QH, int FH>
+__device__ __forceinline__ uint32_t mad16(uint32_t q, uint32_t f, uint32_t c) {
+  uint32_t d;
+  if constexpr (QH == 0 && FH == 0) asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(d) : "v"(q), "v"(f), "v"(c));
+  else if constexpr (QH == 1 && FH == 0) asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(d) : "v"(q), "v"(f), "v"(c));
+  else if constexpr (QH == 0 && FH == 1) asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[0,1,0,0]" : "=v"(d) : "v"(q), "v"(f), "v"(c));
+  else asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,1,0,0]" : "=v"(d) : "v"(q), "v"(f), "v"(c));
+  return d;
+}
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
@@ -93,20 +107,31 @@ struct RefPack {
   }
 
   template <int Q>
-  __device__ static __forceinline__ void mac(const uint4 (&d)[kLoads], const uint32_t (&qlo)[Q][kNQ], const uint32_t (&qhi)[Q][kNQ],
-                                             uint32_t (&alo)[Q], uint32_t (&ahi)[Q]) {
+  __device__ static __forceinline__ void mac(const uint4 (&d)[kLoads], const uint32_t (&qv)[Q][kNQ], uint32_t (&alo)[Q], uint32_t (&ahi)[Q]) {
     const uint32_t wd[4] = {d[0].x, d[0].y, d[0].z, d[0].w};
 #pragma unroll
-    for (int k = 0; k < 4; k++)
-#pragma unroll
-      for (int j = 0; j < CF; j++) {
-        const uint32_t f = field(wd[k], j);
+    for (int k = 0; k < 4; k++) {
+      if constexpr (CF == 2) {
+        // 16-bit slots: the multiplier picks the field straight out of the packed word, no extraction at all
 #pragma unroll
         for (int b = 0; b < Q; b++) {
-          alo[b] = mad24(qlo[b][k * CF + j], f, alo[b]);
-          ahi[b] = mad24(qhi[b][k * CF + j], f, ahi[b]);
+          alo[b] = mad16<0, 0>(qv[b][2 * k], wd[k], alo[b]);
+          ahi[b] = mad16<1, 0>(qv[b][2 * k], wd[k], ahi[b]);
+          alo[b] = mad16<0, 1>(qv[b][2 * k + 1], wd[k], alo[b]);
+          ahi[b] = mad16<1, 1>(qv[b][2 * k + 1], wd[k], ahi[b]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < CF; j++) {
+          const uint32_t f = field(wd[k], j);
+#pragma unroll
+          for (int b = 0; b < Q; b++) {
+            alo[b] = mad16<0, 0>(qv[b][k * CF + j], f, alo[b]);
+            ahi[b] = mad16<1, 0>(qv[b][k * CF + j], f, ahi[b]);
+          }
         }
       }
+    }
   }
 };
 
@@ -131,8 +156,7 @@ struct DensePack {
   }
 
   template <int Q>
-  __device__ static __forceinline__ void mac(const uint4 (&d)[kLoads], const uint32_t (&qlo)[Q][kNQ], const uint32_t (&qhi)[Q][kNQ],
-                                             uint32_t (&alo)[Q], uint32_t (&ahi)[Q]) {
+  __device__ static __forceinline__ void mac(const uint4 (&d)[kLoads], const uint32_t (&qv)[Q][kNQ], uint32_t (&alo)[Q], uint32_t (&ahi)[Q]) {
 #pragma unroll
     for (int L = 0; L < 2; L++) {
       const uint32_t lo[2] = {d[L].x, d[L].z};
@@ -144,8 +168,8 @@ struct DensePack {
           const uint32_t f = field(lo[e], hi[e], j);
 #pragma unroll
           for (int b = 0; b < Q; b++) {
-            alo[b] = mad24(qlo[b][j * 4 + 2 * L + e], f, alo[b]);
-            ahi[b] = mad24(qhi[b][j * 4 + 2 * L + e], f, ahi[b]);
+            alo[b] = mad16<0, 0>(qv[b][j * 4 + 2 * L + e], f, alo[b]);
+            ahi[b] = mad16<1, 0>(qv[b][j * 4 + 2 * L + e], f, ahi[b]);
           }
         }
     }
@@ -214,7 +238,32 @@ __global__ void __launch_bounds__(kThreads) respond_kernel(const RespondArgs a) 
     // wave-uniform: does this chunk reach past the end of q?
     const bool guarded = a.q_scalar || (slot0 + P::kSlotsPerChunk > a.q_len);
 
-    // ---- the database loads of this unit (issued first: they are the long-latency HBM stream) ---------------------
+    // ---- this lane's slice of q (kept whole: the multiplier selects the 16-bit halves) ---------------------------------
+    uint32_t qv[Q][NQ];
+#pragma unroll
+    for (int b = 0; b < Q; b++) {
+      const uint32_t* qb = a.q + (uint64_t)b * a.q_len;
+      if (!guarded) {
+#pragma unroll
+        for (int i = 0; i < NQ / 4; i++) {  // q_offset(tid, 4i) is a multiple of 4 for both packings
+          const uint4 t = *reinterpret_cast<const uint4*>(qb + slot0 + P::q_offset(tid, 4 * i));
+          qv[b][4 * i + 0] = t.x;
+          qv[b][4 * i + 1] = t.y;
+          qv[b][4 * i + 2] = t.z;
+          qv[b][4 * i + 3] = t.w;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NQ; i++) {
+          const uint64_t n = slot0 + P::q_offset(tid, i);
+          qv[b][i] = (n < a.q_len) ? qb[n] : 0u;
+        }
+      }
+    }
+
+    // ---- the database loads of this unit: the long-latency HBM stream.  Issued AFTER the q loads on purpose: vmcnt retires
+    // in issue order, so the (L2-hit) q slice is complete as soon as the first row arrives and row r's math can start
+    // while rows r+1.. are still in flight --------------------------------------------------------------------------
     const uint4* p = reinterpret_cast<const uint4*>(a.dtc + (uint64_t)g * R * a.row_stride + (uint64_t)kc * P::kChunkWords) + tid;
     uint4 d[R][P::kLoads];
 #pragma unroll
@@ -222,38 +271,9 @@ __global__ void __launch_bounds__(kThreads) respond_kernel(const RespondArgs a) 
 #pragma unroll
       for (int l = 0; l < P::kLoads; l++) d[r][l] = load16<NT>(p + (uint64_t)r * stride16 + l * kThreads);
 
-    // ---- this lane's slice of q, split into 16-bit halves ---------------------------------------------------------
-    uint32_t qlo[Q][NQ], qhi[Q][NQ];
-#pragma unroll
-    for (int b = 0; b < Q; b++) {
-      const uint32_t* qb = a.q + (uint64_t)b * a.q_len;
-      uint32_t qv[NQ];
-      if (!guarded) {
-#pragma unroll
-        for (int i = 0; i < NQ / 4; i++) {  // q_offset(tid, 4i) is a multiple of 4 for both packings
-          const uint4 t = *reinterpret_cast<const uint4*>(qb + slot0 + P::q_offset(tid, 4 * i));
-          qv[4 * i + 0] = t.x;
-          qv[4 * i + 1] = t.y;
-          qv[4 * i + 2] = t.z;
-          qv[4 * i + 3] = t.w;
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < NQ; i++) {
-          const uint64_t n = slot0 + P::q_offset(tid, i);
-          qv[i] = (n < a.q_len) ? qb[n] : 0u;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < NQ; i++) {
-        qlo[b][i] = qv[i] & 0xffffu;
-        qhi[b][i] = qv[i] >> 16;
-      }
-    }
-
     // ---- multiply-accumulate ---------------------------------------------------------------------------------------
 #pragma unroll
-    for (int r = 0; r < R; r++) P::template mac<Q>(d[r], qlo, qhi, acc_lo[r], acc_hi[r]);
+    for (int r = 0; r < R; r++) P::template mac<Q>(d[r], qv, acc_lo[r], acc_hi[r]);
 
     // ---- next unit -------------------------------------------------------------------------------------------------
     kc++;
@@ -363,7 +383,7 @@ int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout
   if (!dtc || !q || !r || batch == 0) return CPIR_ERR_INVALID_ARGUMENT;
   // shape invariants every kernel variant relies on (checked on the host before any launch)
   CPIR_TRY(check_layout(L));
-  if (q_slot_offset % L.compression_factor != 0 || q_slot_offset + L.num_slots > q_len) return CPIR_ERR_SHARD_RANGE;
+  if (q_slot_offset + L.num_slots > q_len) return CPIR_ERR_SHARD_RANGE;  // the shard's slots must lie inside the query
   if (reinterpret_cast<uintptr_t>(dtc) % 16 != 0) return CPIR_ERR_INVALID_ARGUMENT;
   if (L.words_per_row_padded / L.chunk_words > 0xffffffffull) return CPIR_ERR_INVALID_ARGUMENT;
 

@@ -244,7 +244,8 @@ int cpir_setup_kv_shape(uint32_t arity, const cpir_kv_db* db, uint32_t* mat_elem
 
 /* Build a server from matrices that already live on the device (multi-GPU shards, benchmarks):
  * D_dev is N_shard x C (ldd) on `dev`; the shard holds global slots [slot_offset, slot_offset + N_shard) of a
- * database with `total_slots` slots; slot_offset must be a multiple of the compression factor. */
+ * database with `total_slots` slots.  Shards are packed independently, so any slot_offset is valid; multiples of
+ * layout.slots_per_chunk (what chalametpir_amd.distributed.shard_range produces) keep the 16-byte query loads aligned. */
 int cpir_server_from_device_matrix(cpir_device* dev, const uint32_t* D_dev, uint64_t ldd, uint64_t N_shard, uint32_t C,
                                    uint32_t mat_elem_bit_len, uint64_t slot_offset, uint64_t total_slots, void* stream,
                                    cpir_server** out);
