@@ -60,6 +60,9 @@ def main() -> int:
     ap.add_argument("--queries-per-step", type=int, default=32)
     ap.add_argument("--query-pool", type=int, default=64, help="distinct queries cycled through (no query-side caching)")
     ap.add_argument("--no-setup", action="store_true", help="skip the server_setup timing (needs A: 8.4 GB at cfg2, ~10 s of host XOF)")
+    ap.add_argument("--setup-kv", action="store_true",
+                    help="also time the FULL Server::setup(seed, kv database) incl. filter construction and row encoding "
+                         "(builds a synthetic n-key database on the host: ~1.1 GB at cfg2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
     ap.add_argument("--tune", default="", help="comma list key=value for cpir_tuning_set, e.g. respond.rows_per_unit=16")
@@ -271,6 +274,8 @@ def main() -> int:
             result["cpu_baseline"] = cpu_baseline(sharded.local, q_pool, r_step, N, C, b, full_bytes, args.cpu_seconds, torch, stream)
         if not args.no_setup:
             result.update(setup_timing(cp, device, torch, sharded, N, C, b, mask, stream))
+        if args.setup_kv:
+            result.update(setup_kv_timing(cp, device, n_keys, arity, value_bytes))
 
     if world > 1:
         dist.barrier()
@@ -394,6 +399,31 @@ def setup_timing(cp, device, torch, sharded, N, C, b, mask, stream):
         "setup_db_matches_bench_db": same,
         "hint_checksum": int(hint.sum(dtype=np.uint64) & 0xFFFFFFFFFFFFFFFF),
     }
+
+
+def setup_kv_timing(cp, device, n_keys, arity, value_bytes):
+    """The reference's `server_setup` bench (integrations/benches/offline_phase.rs:59-72): Server::setup::<ARITY>(seed, db)
+    with the KV database as input -- filter construction + row encoding + A expansion + hint + packed DB all timed."""
+    rng = np.random.default_rng(0xC0FFEE)
+    keys = rng.integers(0, 256, size=n_keys * 32, dtype=np.uint8)
+    keys.reshape(n_keys, 32)[:, :8] = np.arange(n_keys, dtype=np.uint64).view(np.uint8).reshape(n_keys, 8)  # distinct keys
+    values = rng.integers(0, 256, size=n_keys * value_bytes, dtype=np.uint8)
+    key_off = np.arange(n_keys + 1, dtype=np.uint64) * 32
+    val_off = np.arange(n_keys + 1, dtype=np.uint64) * value_bytes
+    t0 = time.perf_counter()
+    srv, hint_bytes, filter_bytes = cp.Server.setup_flat(SEED_MU, keys, key_off, values, val_off, arity, device=device)
+    wall = time.perf_counter() - t0
+    phases = srv.setup_timings()
+    out = {
+        "server_setup_kv_wall_sec": round(wall, 3),
+        "server_setup_kv_phases_sec": {k: round(v, 4) for k, v in phases.items()},
+        "server_setup_kv_note": f"Server::setup::<{arity}>(seed, {n_keys} x (32 B, {value_bytes} B)): BFF construction + row encoding on host "
+                                "threads || TurboSHAKE128 expansion of A on one host thread, then D upload, pack, hint matmul",
+        "hint_bytes": len(hint_bytes),
+        "filter_param_bytes": len(filter_bytes),
+    }
+    srv.close()
+    return out
 
 
 if __name__ == "__main__":

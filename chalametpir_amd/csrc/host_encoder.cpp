@@ -284,25 +284,62 @@ int encode_kv_database(uint32_t arity, const cpir_kv_db& db, uint32_t b, const u
 
   D->assign(num_fp * cols, 0u);  // Matrix::new zero-fills: unused slots stay zero (matrix.rs:702)
   const uint32_t mask = (1u << b) - 1u;
-  std::vector<uint32_t> row(cols);
   uint32_t* mat = D->data();
-  for (uint64_t i = n; i-- > 0;) {  // reverse peel order, matrix.rs:707 / :839
-    const uint64_t hash = order[i];
-    const uint64_t ki = index.get(hash);
-    const Slots s = slots_of(hash, arity, seg_len, seg_count_len);
-    const uint32_t which = found_slot[i];
-    pack_row(&digest_bytes[32 * ki], db.values + db.val_off[ki], (size_t)(db.val_off[ki + 1] - db.val_off[ki]), b, row.data(), cols);
-    uint32_t* dst = mat + (uint64_t)s.h[which] * cols;
-    const uint32_t* o1 = mat + (uint64_t)s.h[(which + 1) % arity] * cols;
-    const uint32_t* o2 = mat + (uint64_t)s.h[(which + 2) % arity] * cols;
-    const uint32_t* o3 = arity == 4 ? mat + (uint64_t)s.h[(which + 3) % arity] * cols : nullptr;
-    for (uint64_t e = 0; e < cols; e++) {
-      // row - f1 - f2 (- f3) - mix(hash, e), reduced to b bits (matrix.rs:727-740 / :862-879); the reference masks
-      // after the second subtraction onwards, which is the same value mod 2^b
-      uint32_t v = row[e] - o1[e] - o2[e];
-      if (o3) v -= o3[e];
-      v -= (uint32_t)mix(hash, e);
-      dst[e] = v & mask;
+
+  // The reference fills D in one sequential pass in reverse peel order (matrix.rs:707-746 / :839-885):
+  //     D[slot_i] = (row_i - D[o1] - D[o2] (- D[o3]) - mix(hash_i, e)) & mask.
+  // Only the subtraction of the OTHER slots' rows carries a dependency, and it is per column.  So it is split in two:
+  //
+  //  pass 1 (parallel over keys): D[slot_i] = (row_i - mix(hash_i, e)) & mask.  Every key owns a distinct slot, the bit
+  //          packing of the 1 kB values and the 940 murmur mixes per key are the expensive part and are independent.
+  //  pass 2 (parallel over COLUMN blocks, sequential in reverse peel order inside a block):
+  //          D[slot_i][e] = (D[slot_i][e] - D[o1][e] - D[o2][e] (- D[o3][e])) & mask.
+  //          When key i is processed every other slot it touches is either unowned (zero) or owned by a key peeled
+  //          later, i.e. already final: a key peeled EARLIER owned a slot of degree 1 at that time, which key i (still
+  //          present then) cannot touch.  Columns never interact, so the blocks need no synchronisation.
+  //  Same values mod 2^b as the reference's single pass.
+  struct Placement {
+    uint32_t dst, o1, o2, o3;
+  };
+  std::vector<Placement> place(n);
+  parallel_for(n, [&](uint64_t lo, uint64_t hi) {
+    std::vector<uint32_t> row(cols);
+    for (uint64_t i = lo; i < hi; i++) {
+      const uint64_t hash = order[i];
+      const uint64_t ki = index.get(hash);
+      const Slots s = slots_of(hash, arity, seg_len, seg_count_len);
+      const uint32_t which = found_slot[i];
+      place[i] = {s.h[which], s.h[(which + 1) % arity], s.h[(which + 2) % arity], arity == 4 ? s.h[(which + 3) % arity] : 0u};
+      pack_row(&digest_bytes[32 * ki], db.values + db.val_off[ki], (size_t)(db.val_off[ki + 1] - db.val_off[ki]), b, row.data(), cols);
+      uint32_t* dst = mat + (uint64_t)s.h[which] * cols;
+      for (uint64_t e = 0; e < cols; e++) dst[e] = (row[e] - (uint32_t)mix(hash, e)) & mask;
+    }
+  });
+  {
+    unsigned hw = std::thread::hardware_concurrency();
+    uint64_t blocks = hw ? std::min<unsigned>(hw, 32) : 4;
+    if (n < 4096) blocks = 1;
+    if (blocks > cols) blocks = cols;
+    auto column_block = [&](uint64_t c0, uint64_t c1) {
+      for (uint64_t i = n; i-- > 0;) {  // reverse peel order, matrix.rs:707 / :839
+        const Placement& p = place[i];
+        uint32_t* dst = mat + (uint64_t)p.dst * cols;
+        const uint32_t* o1 = mat + (uint64_t)p.o1 * cols;
+        const uint32_t* o2 = mat + (uint64_t)p.o2 * cols;
+        if (arity == 4) {
+          const uint32_t* o3 = mat + (uint64_t)p.o3 * cols;
+          for (uint64_t e = c0; e < c1; e++) dst[e] = (dst[e] - o1[e] - o2[e] - o3[e]) & mask;
+        } else {
+          for (uint64_t e = c0; e < c1; e++) dst[e] = (dst[e] - o1[e] - o2[e]) & mask;
+        }
+      }
+    };
+    if (blocks <= 1) {
+      column_block(0, cols);
+    } else {
+      std::vector<std::thread> pool;
+      for (uint64_t t = 0; t < blocks; t++) pool.emplace_back(column_block, cols * t / blocks, cols * (t + 1) / blocks);
+      for (auto& th : pool) th.join();
     }
   }
 

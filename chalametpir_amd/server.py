@@ -174,17 +174,27 @@ def tuning_set(key: str, value: int) -> None:
 class _FlatKvDb:
     """HashMap<&[u8], &[u8]> flattened into the cpir_kv_db arrays (iteration order of the mapping = key order)."""
 
-    def __init__(self, db: Mapping[bytes, bytes]):
-        keys = list(db.keys())
-        vals = [db[k] for k in keys]
-        self.n = len(keys)
-        self.kbuf = np.frombuffer(b"".join(keys) or b"\0", dtype=np.uint8).copy()
-        self.vbuf = np.frombuffer(b"".join(vals) or b"\0", dtype=np.uint8).copy()
-        self.koff = np.zeros(self.n + 1, dtype=np.uint64)
-        self.voff = np.zeros(self.n + 1, dtype=np.uint64)
-        if self.n:
-            np.cumsum([len(k) for k in keys], out=self.koff[1:])
-            np.cumsum([len(v) for v in vals], out=self.voff[1:])
+    def __init__(self, db: Optional[Mapping[bytes, bytes]] = None, *, arrays=None):
+        if arrays is not None:  # (keys u8, key_off u64[n+1], values u8, val_off u64[n+1]) already flat
+            kbuf, koff, vbuf, voff = arrays
+            self.kbuf = np.ascontiguousarray(kbuf, dtype=np.uint8)
+            self.vbuf = np.ascontiguousarray(vbuf, dtype=np.uint8)
+            self.koff = np.ascontiguousarray(koff, dtype=np.uint64)
+            self.voff = np.ascontiguousarray(voff, dtype=np.uint64)
+            self.n = len(self.koff) - 1
+            if len(self.voff) != self.n + 1 or int(self.koff[-1]) > self.kbuf.size or int(self.voff[-1]) > self.vbuf.size:
+                raise ValueError("inconsistent flat key-value arrays")
+        else:
+            keys = list(db.keys())
+            vals = [db[k] for k in keys]
+            self.n = len(keys)
+            self.kbuf = np.frombuffer(b"".join(keys) or b"\0", dtype=np.uint8).copy()
+            self.vbuf = np.frombuffer(b"".join(vals) or b"\0", dtype=np.uint8).copy()
+            self.koff = np.zeros(self.n + 1, dtype=np.uint64)
+            self.voff = np.zeros(self.n + 1, dtype=np.uint64)
+            if self.n:
+                np.cumsum([len(k) for k in keys], out=self.koff[1:])
+                np.cumsum([len(v) for v in vals], out=self.voff[1:])
         self.c = KvDb(self.n, _ptr(self.kbuf), _ptr(self.koff), _ptr(self.vbuf), _ptr(self.voff))
 
 
@@ -213,7 +223,25 @@ class Server:
             raise ChalametPIRError(17, lib.cpir_strerror(17).decode())  # const { assert!(ARITY == 3 || ARITY == 4) }, matrix.rs:638
         if len(db) == 0:
             raise ChalametPIRError(8, lib.cpir_strerror(8).decode())  # EmptyKVDatabase, server.rs:48-51
-        flat = _FlatKvDb(db)
+        return Server._setup_flat(seed_mu, _FlatKvDb(db), arity, device, filter_seed_material, max_attempts)
+
+    @staticmethod
+    def setup_flat(seed_mu: bytes, keys, key_off, values, val_off, arity: int = 3, *, device: Optional[Device] = None,
+                   filter_seed_material: Optional[bytes] = None,
+                   max_attempts: int = SERVER_SETUP_MAX_ATTEMPT_COUNT) -> Tuple["Server", bytes, bytes]:
+        """Server::setup on a database already flattened into the cpir_kv_db arrays (what the Rust shim hands over):
+        keys / values are u8 buffers, key_off / val_off hold num_pairs + 1 offsets.  Keys must be distinct."""
+        lib = _native.load()
+        if arity not in (3, 4):
+            raise ChalametPIRError(17, lib.cpir_strerror(17).decode())
+        flat = _FlatKvDb(arrays=(keys, key_off, values, val_off))
+        if flat.n == 0:
+            raise ChalametPIRError(8, lib.cpir_strerror(8).decode())
+        return Server._setup_flat(seed_mu, flat, arity, device, filter_seed_material, max_attempts)
+
+    @staticmethod
+    def _setup_flat(seed_mu, flat, arity, device, filter_seed_material, max_attempts):
+        lib = _native.load()
         b, N, Cc, need = C.c_uint32(), C.c_uint64(), C.c_uint32(), C.c_size_t()
         _check(lib.cpir_setup_kv_shape(arity, C.byref(flat.c), C.byref(b), C.byref(N), C.byref(Cc), C.byref(need)))
         device = device or Device(0)
