@@ -69,6 +69,9 @@ def main() -> int:
     ap.add_argument("--sweep", action="store_true", help="time every respond kernel variant (stderr table) before the run")
     ap.add_argument("--enqueue", default="batch", choices=["batch", "python"],
                     help="how a step's launches are enqueued: one C call for the step (default) or one ctypes call per query")
+    ap.add_argument("--shard-of", type=int, default=0,
+                    help="tuning aid: run ONE process on rank 0's shard of a K-way split (no collective); the JSON line then "
+                         "describes that shard's kernel only")
     ap.add_argument("--verify", action="store_true",
                     help="rank 0 re-derives the step's responses with the CPU oracle from the full synthetic DB (small configs only)")
     args = ap.parse_args()
@@ -114,6 +117,8 @@ def main() -> int:
 
     # ---- this rank's shard of the synthetic encoded DB, generated in HBM, packed, and D freed ---------------------------
     lo, hi = shard_range(N, full_layout.slots_per_chunk, rank, world)
+    if args.shard_of > 1 and world == 1:
+        lo, hi = shard_range(N, full_layout.slots_per_chunk, 0, args.shard_of)
     t0 = time.time()
     D_dev = torch.empty(((hi - lo), C), dtype=torch.int32, device="cuda")
     if hi > lo:
@@ -186,11 +191,17 @@ def main() -> int:
     W_shard = -(-(hi - lo) // cf) if hi > lo else 0
     launch_bytes = 4 * C * W_shard + 4 * (hi - lo) + 4 * C
     full_bytes = 4 * C * W + 4 * N + 4 * C
-    launch_us = kernel_region_ms * 1e3 / n_queries
+    # ONE respond launch answers the step's queries as that many independent passes over the database (enqueue=batch), or one
+    # query (enqueue=python); bytes and duration below are per LAUNCH, as the kernel trace sees them
+    passes_per_launch = qps_step if args.enqueue == "batch" else 1
+    query_us = kernel_region_ms * 1e3 / n_queries
+    launch_us = query_us * passes_per_launch
+    launch_bytes_q = launch_bytes
+    launch_bytes = launch_bytes_q * passes_per_launch
     achieved = launch_bytes / (launch_us * 1e-6) / 1e9 if launch_us > 0 else 0.0
     # bytes the launch really has to move with the packing in use (device rows incl. zero padding + q slice + response)
     shard_words = int(sharded.local.layout.total_words) if sharded.local is not None else 0
-    moved_bytes = 4 * shard_words + 4 * (hi - lo) + 4 * C
+    moved_bytes = (4 * shard_words + 4 * (hi - lo) + 4 * C) * passes_per_launch
     packing = "dense64" if full_layout.packing == 1 else "reference"
 
     result = {
@@ -225,13 +236,17 @@ def main() -> int:
             "traffic": None,
             "launch_us": round(launch_us, 2),
             "bytes_per_launch": launch_bytes,
+            "passes_per_launch": passes_per_launch,
+            "us_per_query": round(query_us, 2),
             "packing": f"{packing} ({full_layout.fields_per_word} fields per {'u64' if full_layout.packing == 1 else 'u32'})",
             "moved_bytes_per_launch": moved_bytes,
             "moved_GBps": round(moved_bytes / (launch_us * 1e-6) / 1e9, 1) if launch_us > 0 else 0.0,
-            "mall_resident": bool(launch_bytes <= 256 * (1 << 20)),
+            "mall_resident": bool(launch_bytes_q <= 256 * (1 << 20)),
         },
         "pack_seconds": round(pack_seconds, 3),
     }
+    if args.shard_of > 1 and world == 1:
+        result["config"]["sharding"] = f"TUNING RUN: rank 0's shard of a {args.shard_of}-way split, alone, no collective"
     # HBM traffic per launch cannot be sampled from inside this process (PMC counters need rocprofv3 around it); the last
     # committed counter pass for this exact workload (scripts/profile_gpu.sh -> profiles/respond_traffic.json) is quoted.
     traffic_file = os.path.join(ROOT, "profiles", "respond_traffic.json")
@@ -239,8 +254,8 @@ def main() -> int:
         try:
             with open(traffic_file) as fh:
                 tr = json.load(fh)
-            if int(tr.get("algorithmic_bytes_per_launch", 0)) == launch_bytes and tr.get("packing", "reference") == packing:
-                result["roofline"]["traffic"] = int(tr["traffic_bytes_per_launch"])
+            if int(tr.get("algorithmic_bytes_per_pass", 0)) == launch_bytes_q and tr.get("packing", "reference") == packing:
+                result["roofline"]["traffic"] = int(tr["traffic_bytes_per_pass"] * passes_per_launch)
                 result["roofline"]["traffic_source"] = "profiles/respond_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"
         except (OSError, ValueError, KeyError):
             pass

@@ -449,25 +449,21 @@ int cpir_op_respond(cpir_device* dev, const uint32_t* dtc, const cpir_dtc_layout
                     uint64_t q_slot_offset, uint32_t* r, uint32_t* scratch, void* stream) {
   if (!dev || !layout) return CPIR_ERR_INVALID_ARGUMENT;
   DeviceGuard g(dev->ordinal);
-  return launch_respond(dev, dtc, *layout, q, q_len, q_slot_offset, 1, r, scratch, pick_stream(dev, stream));
+  return launch_respond(dev, dtc, *layout, q, q_len, q_slot_offset, 1, 1, r, scratch, pick_stream(dev, stream));
 }
 
-// any batch size: issued as passes of 4 / 2 / 1 queries, each pass streaming the database once
+// Any batch size.  With batch fusion every pass answers 4 queries from one stream of the database (remainder 2 / 1);
+// without it every query is its own pass.  Either way the passes of one kind go into ONE launch.
 static int respond_batched(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                            uint64_t q_slot_offset, uint32_t batch, uint32_t* r, uint32_t* scratch, hipStream_t stream) {
-  const bool fuse = respond_batch_fusion();
+  if (!respond_batch_fusion()) return launch_respond(dev, dtc, L, q, q_len, q_slot_offset, 1, batch, r, scratch, stream);
   uint32_t done = 0;
-  while (done < batch) {
-    const uint32_t left = batch - done;
-    const uint32_t step = !fuse ? 1 : (left >= 4 ? 4 : (left >= 2 ? 2 : 1));
-    // one memset for the first pass; every pass zeroes the output rows of the pass that follows it on the stream
-    const uint32_t after = left - step;
-    const uint32_t next_step = !fuse ? (after ? 1 : 0) : (after >= 4 ? 4 : (after >= 2 ? 2 : after));
-    uint32_t* r_here = r + (uint64_t)done * L.num_cols;
-    CPIR_TRY(launch_respond(dev, dtc, L, q + (uint64_t)done * q_len, q_len, q_slot_offset, step, r_here, scratch, stream,
-                            /*r_is_zero=*/done != 0, next_step ? r_here + (uint64_t)step * L.num_cols : nullptr,
-                            next_step * L.num_cols));
-    done += step;
+  for (uint32_t width : {4u, 2u, 1u}) {
+    const uint32_t passes = (batch - done) / width;
+    if (passes == 0) continue;
+    CPIR_TRY(launch_respond(dev, dtc, L, q + (uint64_t)done * q_len, q_len, q_slot_offset, width, passes,
+                            r + (uint64_t)done * L.num_cols, scratch, stream));
+    done += passes * width;
   }
   return CPIR_OK;
 }
@@ -700,7 +696,7 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
   const size_t qb = (size_t)srv->total_slots * 4, rb = (size_t)srv->layout.num_cols * 4;
   memcpy(s->q_pinned, q, qb);  // the reference copies too (from_bytes .to_vec(), matrix.rs:1001-1007); pinned => true async DMA
   CPIR_HIP_TRY(hipMemcpyAsync(s->q_dev, s->q_pinned, qb, hipMemcpyHostToDevice, s->stream));
-  CPIR_TRY(launch_respond(srv->dev, srv->dtc, srv->layout, s->q_dev, srv->total_slots, srv->slot_offset, 1, s->r_dev, nullptr, s->stream));
+  CPIR_TRY(launch_respond(srv->dev, srv->dtc, srv->layout, s->q_dev, srv->total_slots, srv->slot_offset, 1, 1, s->r_dev, nullptr, s->stream));
   CPIR_HIP_TRY(hipMemcpyAsync(s->r_pinned, s->r_dev, rb, hipMemcpyDeviceToHost, s->stream));
   CPIR_HIP_TRY(hipStreamSynchronize(s->stream));
   memcpy(r_out, s->r_pinned, rb);
@@ -734,7 +730,7 @@ int cpir_server_respond_bytes(const cpir_server* srv, const uint8_t* query, size
 int cpir_server_respond_device(const cpir_server* srv, const uint32_t* q_dev, uint32_t* r_dev, uint32_t* scratch_dev, void* stream) {
   if (!srv || !q_dev || !r_dev) return CPIR_ERR_INVALID_ARGUMENT;
   DeviceGuard g(srv->dev->ordinal);
-  return launch_respond(srv->dev, srv->dtc, srv->layout, q_dev, srv->total_slots, srv->slot_offset, 1, r_dev, scratch_dev,
+  return launch_respond(srv->dev, srv->dtc, srv->layout, q_dev, srv->total_slots, srv->slot_offset, 1, 1, r_dev, scratch_dev,
                         pick_stream(srv->dev, stream));
 }
 

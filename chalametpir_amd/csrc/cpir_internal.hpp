@@ -63,11 +63,10 @@ inline hipStream_t pick_stream(const Device*, void* stream) { return reinterpret
 // ---- kernel launchers (defined in the .hip files) ---------------------------------------------
 // respond.hip
 uint64_t respond_scratch_words(const cpir_dtc_layout& L, uint32_t batch);
-// r_is_zero: the caller guarantees r is already zero on `stream` (skips the memset); zero_next/zero_count: a buffer this
-// launch zeroes for the launch that FOLLOWS it on the same stream (must not overlap r).
+// One launch = `passes` independent passes over the database, each answering `batch` (1, 2 or 4) queries that share the
+// stream of that pass: q holds passes*batch queries of q_len entries, r passes*batch responses of num_cols entries.
 int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
-                   uint64_t q_slot_offset, uint32_t batch, uint32_t* r, uint32_t* scratch, hipStream_t stream,
-                   bool r_is_zero = false, uint32_t* zero_next = nullptr, uint32_t zero_count = 0);
+                   uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, uint32_t* scratch, hipStream_t stream);
 const char* respond_kernel_name(const cpir_dtc_layout& L);
 bool respond_batch_fusion();
 
