@@ -193,7 +193,8 @@ def main() -> int:
     full_bytes = 4 * C * W + 4 * N + 4 * C
     # ONE respond launch answers the step's queries as that many independent passes over the database (enqueue=batch), or one
     # query (enqueue=python); bytes and duration below are per LAUNCH, as the kernel trace sees them
-    passes_per_launch = qps_step if args.enqueue == "batch" else 1
+    big = sharded.local is not None and int(sharded.local.layout.total_words) * 4 > (2560 << 20)  # one launch per query there
+    passes_per_launch = qps_step if (args.enqueue == "batch" and not big) else 1
     query_us = kernel_region_ms * 1e3 / n_queries
     launch_us = query_us * passes_per_launch
     launch_bytes_q = launch_bytes

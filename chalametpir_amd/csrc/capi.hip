@@ -456,7 +456,15 @@ int cpir_op_respond(cpir_device* dev, const uint32_t* dtc, const cpir_dtc_layout
 // without it every query is its own pass.  Either way the passes of one kind go into ONE launch.
 static int respond_batched(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                            uint64_t q_slot_offset, uint32_t batch, uint32_t* r, uint32_t* scratch, hipStream_t stream) {
-  if (!respond_batch_fusion()) return launch_respond(dev, dtc, L, q, q_len, q_slot_offset, 1, batch, r, scratch, stream);
+  if (!respond_batch_fusion()) {
+    // One launch for all passes saves a kernel fill/drain (~10 us) per query, but blocks of a long multi-pass launch drift
+    // apart and lose the L2 sharing of q: measured on MI355X it wins up to 1.3 GB per pass (196 vs 204 us) and loses at
+    // 5 GB and above (806 vs 770 us), so very large databases get one launch per query.
+    if (L.total_words * 4 <= (2560ull << 20)) return launch_respond(dev, dtc, L, q, q_len, q_slot_offset, 1, batch, r, scratch, stream);
+    for (uint32_t i = 0; i < batch; i++)
+      CPIR_TRY(launch_respond(dev, dtc, L, q + (uint64_t)i * q_len, q_len, q_slot_offset, 1, 1, r + (uint64_t)i * L.num_cols, scratch, stream));
+    return CPIR_OK;
+  }
   uint32_t done = 0;
   for (uint32_t width : {4u, 2u, 1u}) {
     const uint32_t passes = (batch - done) / width;

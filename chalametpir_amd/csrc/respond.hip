@@ -46,6 +46,10 @@ struct RespondArgs {
   uint32_t nx;             // chunk-axis split by blockIdx % nx (8 or 1)
   uint32_t q_scalar;       // q not 16-byte loadable -> guarded scalar loads everywhere
   uint32_t passes;         // independent passes over the database in this launch; pass i uses queries [i*Q, (i+1)*Q)
+  uint32_t interleave;     // 0: every block walks its own slice of the database once per pass (one query at a time
+                           //    grid-wide: q stays in L2); 1: passes laid end to end in the unit space, so different blocks
+                           //    stream the same rows for different queries at the same time (pays when the shard fits the
+                           //    256 MiB Infinity Cache)
 };
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -184,10 +188,12 @@ __global__ void __launch_bounds__(kThreads) respond_kernel(const RespondArgs a) 
   const int lane = tid & 63;
   const int wave = tid >> 6;
 
-  // ---- static partition of the (pass, row group, chunk) units over the persistent grid ------------------------------
-  // One launch can carry several PASSES: independent queries that each stream the whole database.  The passes are laid
-  // end to end in the unit space, so a launch of P passes costs one kernel fill/drain instead of P (worth ~10 us per
-  // query, which is 5 % of a 1.3 GB stream but 30 % of an eighth of it on an 8-GPU shard).
+  // ---- static partition of the (pass, row group, chunk) units over the persistent grid -------------------------------
+  // One launch can carry several PASSES: independent queries that each stream the whole database, so P passes cost one
+  // kernel fill/drain instead of P (worth ~10 us per query: 5 % of a 1.3 GB stream, 30 % of an eighth of it on an 8-GPU
+  // shard).  Two orders, chosen by the host (a.interleave), same arithmetic:
+  //   slice order:      a block keeps its slice of the units and walks it once per pass;
+  //   interleaved order: the passes are laid end to end and the whole (pass, unit) space is split evenly.
   const uint32_t nx = a.nx;
   const uint32_t xcd = blockIdx.x % nx;
   const uint32_t j = blockIdx.x / nx;
@@ -196,15 +202,22 @@ __global__ void __launch_bounds__(kThreads) respond_kernel(const RespondArgs a) 
   const uint32_t ke = (uint32_t)(((uint64_t)a.chunks_total * (xcd + 1)) / nx);
   const uint32_t span = ke - kb;
   if (span == 0) return;
-  const uint64_t units_per_pass = (uint64_t)a.groups * span;
-  const uint64_t units = units_per_pass * a.passes;
-  const uint64_t u_begin = units * j / nb;
-  const uint64_t u_end = units * (j + 1) / nb;
-  if (u_begin >= u_end) return;
-
-  uint32_t pass = (uint32_t)(u_begin / units_per_pass);
-  uint32_t g = (uint32_t)((u_begin % units_per_pass) / span);
-  uint32_t kc = kb + (uint32_t)(u_begin % span);
+  const uint64_t units = (uint64_t)a.groups * span;  // units of ONE pass in this XCD's slice of the chunk axis
+  uint64_t ub, ue, u, count;                          // a pass covers units [ub, ue) for this block; u = current unit
+  uint32_t pass;
+  if (a.interleave) {
+    const uint64_t total = units * a.passes;
+    const uint64_t ib = total * j / nb, ie = total * (j + 1) / nb;
+    ub = 0, ue = units, count = ie - ib;
+    pass = (uint32_t)(ib / units), u = ib % units;
+  } else {
+    ub = units * j / nb, ue = units * (j + 1) / nb;
+    count = (ue - ub) * a.passes;
+    pass = 0, u = ub;
+  }
+  if (count == 0) return;
+  const uint32_t g0 = (uint32_t)(ub / span), kc0 = kb + (uint32_t)(ub % span);  // where a pass starts for this block
+  uint32_t g = (uint32_t)(u / span), kc = kb + (uint32_t)(u % span);
   const uint32_t* qpass = a.q + (uint64_t)pass * Q * a.q_len;
   uint32_t* rpass = a.r + (uint64_t)pass * Q * a.num_cols;
 
@@ -236,7 +249,7 @@ __global__ void __launch_bounds__(kThreads) respond_kernel(const RespondArgs a) 
   };
 
   const uint64_t stride16 = a.row_stride / 4;
-  for (uint64_t u = u_begin; u < u_end; u++) {
+  for (uint64_t i = 0; i < count; i++) {
     const uint64_t slot0 = a.q_slot_offset + (uint64_t)kc * P::kSlotsPerChunk;  // first slot of this chunk
     // wave-uniform: does this chunk reach past the end of q?
     const bool guarded = a.q_scalar || (slot0 + P::kSlotsPerChunk > a.q_len);
@@ -279,19 +292,16 @@ __global__ void __launch_bounds__(kThreads) respond_kernel(const RespondArgs a) 
     for (int r = 0; r < R; r++) P::template mac<Q>(d[r], qv, acc_lo[r], acc_hi[r]);
 
     // ---- next unit -------------------------------------------------------------------------------------------------
-    kc++;
-    if (kc == ke) {
-      flush(g);
-      kc = kb;
-      if (++g == a.groups) {  // next pass: next query (or Q queries), same database
-        g = 0;
-        pass++;
-        qpass += (uint64_t)Q * a.q_len;
-        rpass += (uint64_t)Q * a.num_cols;
-      }
+    kc++, u++;
+    const bool row_done = (kc == ke), pass_done = (u == ue), last = (i + 1 == count);
+    if (row_done || pass_done || last) flush(g);  // the accumulators belong to (pass, row group g)
+    if (row_done) g++, kc = kb;
+    if (pass_done) {  // same slice of the database, next query
+      u = ub, g = g0, kc = kc0;
+      qpass += (uint64_t)Q * a.q_len;
+      rpass += (uint64_t)Q * a.num_cols;
     }
   }
-  if (kc != kb) flush(g);  // a partially covered row group is still pending
 }
 
 // ---- tuning state (benchmark harness can override; defaults chosen from measurements) ----------------
@@ -301,6 +311,7 @@ struct Tuning {
   int blocks_per_cu = 2;   // resident 256-thread blocks per CU; 0 = ask the occupancy API
   int xcd_split = 1;       // split the chunk axis by blockIdx % 8
   int batch_fusion = 1;    // respond_batch: 1 = passes of 4/2/1 queries share one DB stream, 0 = one pass per query
+  int interleave_passes = -1;  // order of the passes of one launch: 0 slice order, 1 interleaved, -1 by shard size
 };
 Tuning g_tuning;
 std::mutex g_tuning_mu;
@@ -364,6 +375,9 @@ extern "C" int cpir_tuning_set(const char* key, int value) {
     g_tuning.xcd_split = value ? 1 : 0;
   } else if (!strcmp(key, "respond.batch_fusion")) {
     g_tuning.batch_fusion = value ? 1 : 0;
+  } else if (!strcmp(key, "respond.interleave_passes")) {
+    if (value < -1 || value > 1) return CPIR_ERR_INVALID_ARGUMENT;
+    g_tuning.interleave_passes = value;
   } else if (!strcmp(key, "layout.dense")) {
     set_default_dense(value != 0);
   } else {
@@ -418,6 +432,10 @@ int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout
   a.chunks_total = (uint32_t)(L.words_per_row_padded / L.chunk_words);
   a.q_scalar = (reinterpret_cast<uintptr_t>(q) % 16 != 0 || q_slot_offset % 4 != 0 || (batch * passes > 1 && q_len % 4 != 0)) ? 1u : 0u;
   a.passes = passes;
+  // Order of the passes, from measurements on MI355X: below ~1 GB per pass the interleaved order wins
+  // (concurrent passes share database bytes on die: 23 vs 31 us per query on a 160 MB shard, 92 vs 104 us at 640 MB);
+  // at 1.3 GB and above the slice order wins (196 vs 198 us)
+  a.interleave = (passes > 1 && (t.interleave_passes == 1 || (t.interleave_passes < 0 && L.total_words * 4 <= (960ull << 20)))) ? 1u : 0u;
 
   int bpc = t.blocks_per_cu;
   if (bpc == 0) {
@@ -425,7 +443,7 @@ int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout
     CPIR_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(k.fn), kThreads, 0));
     bpc = occ < 1 ? 1 : (occ > 8 ? 8 : occ);
   }
-  const uint64_t units = (uint64_t)a.groups * a.chunks_total * passes;
+  const uint64_t units = (uint64_t)a.groups * a.chunks_total;
   uint64_t grid = (uint64_t)dev->num_cus * (uint64_t)bpc;
   a.nx = (t.xcd_split && a.chunks_total >= 8 && grid % 8 == 0) ? 8u : 1u;
   if (grid > units) {

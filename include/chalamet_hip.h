@@ -189,7 +189,8 @@ int cpir_op_synth_fill(cpir_device* dev, uint32_t* out, uint64_t count, uint64_t
 /* Tuning knobs of the respond kernel (benchmark harness only; defaults are the measured best):
  *   "respond.rows_per_unit" in {4, 8, 16}, "respond.nontemporal" {0,1}, "respond.blocks_per_cu" 0..8 (0 = occupancy API),
  *   "respond.xcd_split" {0,1}, "respond.batch_fusion" {0,1} (0: every query of a batch call streams the database on its
- *   own, i.e. a batch call is only a cheaper way to enqueue independent responds), "layout.dense" {0,1} (default packing
+ *   own, i.e. a batch call is only a cheaper way to enqueue independent responds), "respond.interleave_passes" {-1,0,1}
+ *   (order in which one launch walks its passes; -1 = by shard size), "layout.dense" {0,1} (default packing
  *   chosen by cpir_dtc_layout_for and therefore by every cpir_server_* constructor).
  * Process-wide; results are bit-identical for every setting. */
 int cpir_tuning_set(const char* key, int value);

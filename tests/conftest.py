@@ -36,4 +36,14 @@ def device(native):
     """cpir_device 0; GPU tests FAIL (not skip) if the HIP library cannot open a device"""
     import chalametpir_amd as cp
 
+    # torch shares the process' HIP runtime (chalametpir_amd/_native.py); initialise its context first, as bench.py does,
+    # instead of lazily in the middle of the suite
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.init()
+            torch.zeros(1, device="cuda")
+    except ImportError:
+        pass
     return cp.Device(0)

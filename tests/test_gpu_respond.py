@@ -190,9 +190,9 @@ def test_every_kernel_variant_is_bit_identical(orc, device):
                         assert np.array_equal(srv.respond_array(q), want), (R, nt, xs, bpc)
     finally:
         cp.tuning_set("respond.rows_per_unit", 8)
-        cp.tuning_set("respond.nontemporal", 0)
+        cp.tuning_set("respond.nontemporal", 1)
         cp.tuning_set("respond.xcd_split", 1)
-        cp.tuning_set("respond.blocks_per_cu", 0)
+        cp.tuning_set("respond.blocks_per_cu", 2)
 
 
 def test_device_entry_points_shards_and_batches(orc, device):
@@ -227,13 +227,23 @@ def test_device_entry_points_shards_and_batches(orc, device):
             total += r_dev.cpu().numpy().view(np.uint32)
         assert np.array_equal(total, want), b
 
-        # batch of 7 (4 + 2 + 1 passes) on the unsharded server
+        # batch of 11 on the unsharded server: fused (2 passes of 4, one of 2, one of 1) and unfused (11 passes in one launch),
+        # each in both pass orders
         srv = cp.Server.from_compressed(dtc_full, N, b, device=device)
-        Q = np.stack([random_query(rng, N) for _ in range(7)])
+        Q = np.stack([random_query(rng, N) for _ in range(11)])
+        want_all = [orc.row_vector_x_compressed_transposed_matrix(Q[i], dtc_full, N, b)[0] for i in range(11)]
         Q_dev = torch.from_numpy(Q.view(np.int32)).cuda()
-        R_dev = torch.empty((7, C), dtype=torch.int32, device="cuda")
-        srv.respond_batch_device(Q_dev, 7, R_dev, stream=torch.cuda.current_stream())
-        torch.cuda.synchronize()
-        got = R_dev.cpu().numpy().view(np.uint32)
-        for i in range(7):
-            assert np.array_equal(got[i], orc.row_vector_x_compressed_transposed_matrix(Q[i], dtc_full, N, b)[0]), (b, i)
+        try:
+            for fusion in (1, 0):
+                for order in (0, 1):
+                    cp.tuning_set("respond.batch_fusion", fusion)
+                    cp.tuning_set("respond.interleave_passes", order)
+                    R_dev = torch.full((11, C), -1, dtype=torch.int32, device="cuda")
+                    srv.respond_batch_device(Q_dev, 11, R_dev, stream=torch.cuda.current_stream())
+                    torch.cuda.synchronize()
+                    got = R_dev.cpu().numpy().view(np.uint32)
+                    for i in range(11):
+                        assert np.array_equal(got[i], want_all[i]), (b, fusion, order, i)
+        finally:
+            cp.tuning_set("respond.batch_fusion", 1)
+            cp.tuning_set("respond.interleave_passes", -1)
