@@ -13,9 +13,9 @@
 //     wave-instruction reads 1 KiB contiguous (`nt` policy: the database is read once per query);
 //   * the slice of q a lane needs is loaded ONCE per unit into registers and reused for the R rows, so q traffic (served by
 //     L2 / Infinity Cache) is a fraction 1/R of what a row-at-a-time kernel would pull;
-//   * exact u32 products without v_mul_lo_u32 (quarter rate): every field is < 2^16, so each product is formed from the
-//     16-bit halves of q on the full-rate 16x16+32 multiplier (v_mad_u32_u16, halves picked by op_sel):
-//     acc_lo += q.lo*d, acc_hi += q.hi*d, r = acc_lo + (acc_hi << 16)  -- identical mod 2^32, one VALU op per product;
+//   * exact u32 products in ONE VALU op each: acc64 += q*d with v_mad_u64_u32 (the low dword of the 64-bit running sum
+//     is the wrap-around u32 result).  On gfx950 every VOP3 integer op issues at half rate, so this beats both
+//     v_mul_lo_u32 + add and the "split q into 16-bit halves, two 16x16+32 MADs" trick (measured: scripts/valu_rate.hip);
 //   * persistent grid (CUs x resident blocks), units split evenly so there is no tail wave; the chunk axis is first split
 //     8 ways by blockIdx % 8 -- blocks that share an XCD (observed round-robin placement; speed only, never correctness)
 //     then share one eighth of q in that XCD's 4 MiB L2;
@@ -64,20 +64,15 @@ __device__ __forceinline__ uint4 load16(const uint4* p) {
   }
 }
 
-// acc + (16-bit half of q) * (16-bit half of f), wrap-around: ONE full-rate v_mad_u32_u16, the halves picked by op_sel
-// (QH / FH = 1 takes bits 31..16).  This is the whole trick behind exact u32 products on the fast multiplier:
-//   q*f mod 2^32 = q.lo*f + ((q.hi*f) << 16)   for f < 2^16,
-// so two accumulators per output are kept and combined once at the end -- and q never has to be split into separate
-// registers (hipcc, left alone, picks v_mul_u32_u24 with SDWA operands plus a separate add per product).
-// Plain VALU in an asm statement: no memory effects, no wait states to declare.
-template <int QH, int FH>
-__device__ __forceinline__ uint32_t mad16(uint32_t q, uint32_t f, uint32_t c) {
-  uint32_t d;
-  if constexpr (QH == 0 && FH == 0) asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(d) : "v"(q), "v"(f), "v"(c));
-  else if constexpr (QH == 1 && FH == 0) asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(d) : "v"(q), "v"(f), "v"(c));
-  else if constexpr (QH == 0 && FH == 1) asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[0,1,0,0]" : "=v"(d) : "v"(q), "v"(f), "v"(c));
-  else asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,1,0,0]" : "=v"(d) : "v"(q), "v"(f), "v"(c));
-  return d;
+// acc += q * f with a 64-bit accumulator: ONE v_mad_u64_u32 per product; the low 32 bits of the running sum are the exact
+// wrap-around u32 result.  Measured on MI355X (scripts/valu_rate.hip): v_mad_u64_u32 issues at 52 lanes/clk/CU, the 16x16+32
+// and 24x24+32 multipliers (v_mad_u32_u16 / _u24), v_mul_lo_u32, v_dot2_u32_u16 and v_bfe_u32 all at ~60 -- every VOP3
+// integer op runs at half the 128 lanes/clk/CU of the simple VOP2 ops.  Splitting q into 16-bit halves (two MADs per
+// product) therefore costs 2 x 1/60 against 1/52 for the 64-bit MAD: the wide MAD is the cheaper exact product.
+// (An asm statement because hipcc, seeing that only the low dword is used in the end, rewrites the C expression into
+// v_mul_lo_u32 plus a 64-bit add -- two half-rate ops.  Plain VALU: no memory effects; VCC receives the unused carry.)
+__device__ __forceinline__ void mac64(uint64_t& acc, uint32_t q, uint32_t f) {
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(q), "v"(f) : "vcc");
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -104,37 +99,24 @@ struct RefPack {
 
   __device__ static __forceinline__ uint32_t field(uint32_t w, int j) {
     constexpr int S = 32 / CF;
-    // unused high bits (cf = 3: bits 30,31) and bits >= b inside a slot are zero by construction of the layout
+    // unused high bits (cf = 3: bits 30,31) and bits >= b inside a slot are zero by construction of the layout;
+    // plain shift / and are VOP2 (full rate), v_bfe_u32 is VOP3 (half rate)
     if (j == CF - 1) return w >> (S * (CF - 1));
+    if (j == 0) return w & ((1u << S) - 1u);
     return __builtin_amdgcn_ubfe(w, S * j, S);
   }
 
   template <int Q>
-  __device__ static __forceinline__ void mac(const uint4 (&d)[kLoads], const uint32_t (&qv)[Q][kNQ], uint32_t (&alo)[Q], uint32_t (&ahi)[Q]) {
+  __device__ static __forceinline__ void mac(const uint4 (&d)[kLoads], const uint32_t (&qv)[Q][kNQ], uint64_t (&acc)[Q]) {
     const uint32_t wd[4] = {d[0].x, d[0].y, d[0].z, d[0].w};
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      if constexpr (CF == 2) {
-        // 16-bit slots: the multiplier picks the field straight out of the packed word, no extraction at all
+    for (int k = 0; k < 4; k++)
 #pragma unroll
-        for (int b = 0; b < Q; b++) {
-          alo[b] = mad16<0, 0>(qv[b][2 * k], wd[k], alo[b]);
-          ahi[b] = mad16<1, 0>(qv[b][2 * k], wd[k], ahi[b]);
-          alo[b] = mad16<0, 1>(qv[b][2 * k + 1], wd[k], alo[b]);
-          ahi[b] = mad16<1, 1>(qv[b][2 * k + 1], wd[k], ahi[b]);
-        }
-      } else {
+      for (int j = 0; j < CF; j++) {
+        const uint32_t f = field(wd[k], j);
 #pragma unroll
-        for (int j = 0; j < CF; j++) {
-          const uint32_t f = field(wd[k], j);
-#pragma unroll
-          for (int b = 0; b < Q; b++) {
-            alo[b] = mad16<0, 0>(qv[b][k * CF + j], f, alo[b]);
-            ahi[b] = mad16<1, 0>(qv[b][k * CF + j], f, ahi[b]);
-          }
-        }
+        for (int b = 0; b < Q; b++) mac64(acc[b], qv[b][k * CF + j], f);
       }
-    }
   }
 };
 
@@ -153,13 +135,14 @@ struct DensePack {
 
   __device__ static __forceinline__ uint32_t field(uint32_t lo, uint32_t hi, int j) {
     const int o = j * B;
+    if (o == 0) return lo & ((1u << B) - 1u);
     if (o + B <= 32) return (o + B == 32) ? (lo >> o) : __builtin_amdgcn_ubfe(lo, o, B);
     if (o >= 32) return (j == K - 1) ? (hi >> (o - 32)) : __builtin_amdgcn_ubfe(hi, o - 32, B);  // bits above K*B are zero
     return __builtin_amdgcn_alignbit(hi, lo, o) & ((1u << B) - 1u);                               // straddles the dword boundary
   }
 
   template <int Q>
-  __device__ static __forceinline__ void mac(const uint4 (&d)[kLoads], const uint32_t (&qv)[Q][kNQ], uint32_t (&alo)[Q], uint32_t (&ahi)[Q]) {
+  __device__ static __forceinline__ void mac(const uint4 (&d)[kLoads], const uint32_t (&qv)[Q][kNQ], uint64_t (&acc)[Q]) {
 #pragma unroll
     for (int L = 0; L < 2; L++) {
       const uint32_t lo[2] = {d[L].x, d[L].z};
@@ -170,10 +153,7 @@ struct DensePack {
         for (int j = 0; j < K; j++) {
           const uint32_t f = field(lo[e], hi[e], j);
 #pragma unroll
-          for (int b = 0; b < Q; b++) {
-            alo[b] = mad16<0, 0>(qv[b][j * 4 + 2 * L + e], f, alo[b]);
-            ahi[b] = mad16<1, 0>(qv[b][j * 4 + 2 * L + e], f, ahi[b]);
-          }
+          for (int b = 0; b < Q; b++) mac64(acc[b], qv[b][j * 4 + 2 * L + e], f);
         }
     }
   }
@@ -221,20 +201,20 @@ __global__ void __launch_bounds__(kThreads) respond_kernel(const RespondArgs a) 
   const uint32_t* qpass = a.q + (uint64_t)pass * Q * a.q_len;
   uint32_t* rpass = a.r + (uint64_t)pass * Q * a.num_cols;
 
-  uint32_t acc_lo[R][Q], acc_hi[R][Q];
+  uint64_t acc[R][Q];
 #pragma unroll
   for (int r = 0; r < R; r++)
 #pragma unroll
-    for (int b = 0; b < Q; b++) acc_lo[r][b] = acc_hi[r][b] = 0;
+    for (int b = 0; b < Q; b++) acc[r][b] = 0;
 
   auto flush = [&](uint32_t grp) {
 #pragma unroll
     for (int b = 0; b < Q; b++)
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        const uint32_t v = wave_sum(acc_lo[r][b] + (acc_hi[r][b] << 16));
+        const uint32_t v = wave_sum((uint32_t)acc[r][b]);  // low dword = the wrap-around u32 sum
         if (lane == 0) sm[b][wave][r] = v;
-        acc_lo[r][b] = acc_hi[r][b] = 0;
+        acc[r][b] = 0;
       }
     __syncthreads();
     if (tid < Q * R) {
@@ -254,7 +234,7 @@ __global__ void __launch_bounds__(kThreads) respond_kernel(const RespondArgs a) 
     // wave-uniform: does this chunk reach past the end of q?
     const bool guarded = a.q_scalar || (slot0 + P::kSlotsPerChunk > a.q_len);
 
-    // ---- this lane's slice of q (kept whole: the multiplier selects the 16-bit halves) ---------------------------------
+    // ---- this lane's slice of q --------------------------------------------------------------------------------------
     uint32_t qv[Q][NQ];
 #pragma unroll
     for (int b = 0; b < Q; b++) {
@@ -289,7 +269,7 @@ __global__ void __launch_bounds__(kThreads) respond_kernel(const RespondArgs a) 
 
     // ---- multiply-accumulate ---------------------------------------------------------------------------------------
 #pragma unroll
-    for (int r = 0; r < R; r++) P::template mac<Q>(d[r], qv, acc_lo[r], acc_hi[r]);
+    for (int r = 0; r < R; r++) P::template mac<Q>(d[r], qv, acc[r]);
 
     // ---- next unit -------------------------------------------------------------------------------------------------
     kc++, u++;
