@@ -94,6 +94,8 @@ SIGNATURES = {
                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "cpir_setup_kv_shape": (C.c_int, [C.c_uint32, C.POINTER(KvDb), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_size_t)]),
+    "cpir_hint_partial_device": (C.c_int, [vp, u8p, u32p, u32p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, u32p,
+                                           vp]),
     "cpir_server_from_device_matrix": (C.c_int, [vp, u32p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp,
                                                  C.POINTER(vp)]),
     "cpir_server_from_compressed": (C.c_int, [vp, u32p, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(vp)]),

@@ -150,7 +150,10 @@ static Server* server_new(Device* dev, const cpir_dtc_layout& L, uint64_t slot_o
 // A stays resident (8.4 GB at 2^20 keys, 33 GB at 2^22: sized for 288 GB of HBM) so the hint is ONE matmul launch.
 class PublicMatrixUpload {
  public:
-  PublicMatrixUpload(Device* dev, uint64_t N) : dev_(dev), N_(N) {}
+  // col_lo / col_n: keep only columns [col_lo, col_lo + col_n) of A on the device (an N-shard); the sponge still has to
+  // be squeezed for every byte of A, only the upload shrinks
+  PublicMatrixUpload(Device* dev, uint64_t N, uint64_t col_lo = 0, uint64_t col_n = 0)
+      : dev_(dev), N_(N), col_lo_(col_lo), col_n_(col_n ? col_n : N) {}
   ~PublicMatrixUpload() {
     join();
     DeviceGuard g(dev_->ordinal);
@@ -165,10 +168,10 @@ class PublicMatrixUpload {
   int start(const uint8_t seed[32], const uint32_t* A_host) {
     DeviceGuard g(dev_->ordinal);
     const uint64_t rows = CPIR_LWE_DIMENSION;
-    CPIR_HIP_TRY(hipMalloc(&A_dev_, (size_t)rows * N_ * 4));
+    CPIR_HIP_TRY(hipMalloc(&A_dev_, (size_t)rows * col_n_ * 4));
     CPIR_HIP_TRY(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
     if (A_host) {  // caller supplied A: plain upload, no XOF
-      CPIR_HIP_TRY(hipMemcpyAsync(A_dev_, A_host, (size_t)rows * N_ * 4, hipMemcpyHostToDevice, copy_stream_));
+      CPIR_HIP_TRY(hipMemcpy2DAsync(A_dev_, col_n_ * 4, A_host + col_lo_, N_ * 4, col_n_ * 4, rows, hipMemcpyHostToDevice, copy_stream_));
       return CPIR_OK;
     }
     // ~64 MiB staging blocks, whole rows
@@ -214,7 +217,8 @@ class PublicMatrixUpload {
       const double t0 = now_seconds();
       xof.squeeze(reinterpret_cast<uint8_t*>(pinned_[buf]), (size_t)rb * N_ * 4);  // matrix.rs:546-555: row-major LE u32
       xof_seconds_ += now_seconds() - t0;
-      CPIR_HIP_TRY(hipMemcpyAsync(A_dev_ + r0 * N_, pinned_[buf], (size_t)rb * N_ * 4, hipMemcpyHostToDevice, copy_stream_));
+      CPIR_HIP_TRY(hipMemcpy2DAsync(A_dev_ + r0 * col_n_, col_n_ * 4, pinned_[buf] + col_lo_, N_ * 4, col_n_ * 4, rb,
+                                    hipMemcpyHostToDevice, copy_stream_));
       CPIR_HIP_TRY(hipEventRecord(ev_[buf], copy_stream_));
       used[buf] = true;
     }
@@ -222,7 +226,7 @@ class PublicMatrixUpload {
   }
 
   Device* dev_;
-  uint64_t N_;
+  uint64_t N_, col_lo_, col_n_;
   uint32_t* A_dev_ = nullptr;
   uint32_t* pinned_[2] = {nullptr, nullptr};
   hipEvent_t ev_[2] = {nullptr, nullptr};
@@ -586,6 +590,24 @@ int cpir_server_setup_kv(cpir_device* dev, uint32_t arity, const uint8_t seed_mu
   srv->setup_timings[0] = t_encode;
   srv->setup_timings[7] = now_seconds() - t_begin;
   *out = static_cast<cpir_server*>(srv);
+  return CPIR_OK;
+}
+
+int cpir_hint_partial_device(cpir_device* dev, const uint8_t seed_mu[CPIR_SEED_BYTE_LEN], const uint32_t* pub_mat_a, const uint32_t* D_dev,
+                             uint64_t ldd, uint64_t slot_offset, uint64_t N_shard, uint64_t total_slots, uint32_t C, uint32_t rhs_max_bits,
+                             uint32_t* M_dev, void* stream) {
+  if (!dev || !D_dev || !M_dev || (!seed_mu && !pub_mat_a)) return CPIR_ERR_INVALID_ARGUMENT;
+  if (N_shard == 0 || C == 0 || total_slots == 0) return CPIR_ERR_INVALID_MATRIX_DIMENSION;
+  if (slot_offset + N_shard > total_slots) return CPIR_ERR_SHARD_RANGE;
+  PublicMatrixUpload upA(dev, total_slots, slot_offset, N_shard);
+  static const uint8_t zero_seed[32] = {0};
+  CPIR_TRY(upA.start(seed_mu ? seed_mu : zero_seed, pub_mat_a));
+  const uint32_t* A_dev = nullptr;
+  CPIR_TRY(upA.finish(&A_dev));
+  DeviceGuard g(dev->ordinal);
+  hipStream_t s = pick_stream(dev, stream);
+  CPIR_TRY(launch_mat_x_mat(dev, A_dev, N_shard, D_dev, ldd, M_dev, C, CPIR_LWE_DIMENSION, N_shard, C, rhs_max_bits, 0, s));
+  CPIR_HIP_TRY(hipStreamSynchronize(s));  // A_dev dies with upA
   return CPIR_OK;
 }
 

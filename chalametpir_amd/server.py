@@ -104,6 +104,13 @@ class Device:
                                          q_len if q_len is not None else q.numel(), q_slot_offset, _tensor_ptr(r), None,
                                          _stream_ptr(stream)))
 
+    def hint_partial(self, seed_mu: bytes, D_shard, slot_offset: int, num_slots: int, total_slots: int, num_cols: int, M_out, *,
+                     ldd: Optional[int] = None, rhs_max_bits: int = 16, stream=None) -> None:
+        """this shard's share of hint = A(seed) * D (reference server.rs:59-61): M_out (1774 x C device tensor) is overwritten with
+        A[:, slot_offset:slot_offset+num_slots] * D_shard; sum the partials over shards (distributed.reduce_u32_)"""
+        _check(self._lib.cpir_hint_partial_device(self._h, _seed_arg(seed_mu), None, _tensor_ptr(D_shard), ldd or num_cols, slot_offset,
+                                                  num_slots, total_slots, num_cols, rhs_max_bits, _tensor_ptr(M_out), _stream_ptr(stream)))
+
     def synth_fill(self, out, count: int, seed: int, index0: int = 0, mask: int = 0xFFFFFFFF, *, offset_words: int = 0, stream=None) -> None:
         _check(self._lib.cpir_op_synth_fill(self._h, _tensor_ptr(out) + 4 * offset_words, count, seed, index0, mask, _stream_ptr(stream)))
 

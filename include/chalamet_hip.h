@@ -243,6 +243,16 @@ int cpir_encode_kv_database(uint32_t arity, const cpir_kv_db* db, uint32_t mat_e
 int cpir_setup_kv_shape(uint32_t arity, const cpir_kv_db* db, uint32_t* mat_elem_bit_len, uint64_t* N, uint32_t* C,
                         size_t* hint_bytes_len);
 
+/* One shard's share of the hint (multi-GPU setup): with the database split along the filter-slot axis,
+ *   hint = sum over shards of  A[:, slot_offset : slot_offset + N_shard] * D[slot_offset : slot_offset + N_shard, :].
+ * Expands A from seed_mu on the host (the whole sponge has to be squeezed; only this shard's columns are uploaded), or takes
+ * those columns from a caller-supplied full A (pub_mat_a, 1774 x total_slots, host), multiplies by the shard of D that already
+ * sits on the device (N_shard x C, leading dim ldd) and OVERWRITES M_dev (1774 x C, device) with the partial product.  The caller
+ * sum-reduces the partials across shards (u32 wrap-around, e.g. chalametpir_amd.distributed.reduce_u32_).  Synchronous. */
+int cpir_hint_partial_device(cpir_device* dev, const uint8_t seed_mu[CPIR_SEED_BYTE_LEN], const uint32_t* pub_mat_a,
+                             const uint32_t* D_dev, uint64_t ldd, uint64_t slot_offset, uint64_t N_shard, uint64_t total_slots,
+                             uint32_t C, uint32_t rhs_max_bits, uint32_t* M_dev, void* stream);
+
 /* Build a server from matrices that already live on the device (multi-GPU shards, benchmarks):
  * D_dev is N_shard x C (ldd) on `dev`; the shard holds global slots [slot_offset, slot_offset + N_shard) of a
  * database with `total_slots` slots.  Shards are packed independently, so any slot_offset is valid; multiples of

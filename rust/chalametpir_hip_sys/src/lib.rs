@@ -48,6 +48,10 @@ pub struct cpir_dtc_layout {
     pub words_per_row_padded: u64,
     pub rows_padded: u32,
     pub total_words: u64,
+    pub packing: u32,
+    pub fields_per_word: u32,
+    pub chunk_words: u32,
+    pub slots_per_chunk: u64,
 }
 
 #[repr(C)]
@@ -77,6 +81,7 @@ unsafe extern "C" {
     pub fn cpir_encoded_num_cols(max_value_byte_len: u64, mat_elem_bit_len: u32) -> u64;
     pub fn cpir_generate_from_seed(rows: u64, cols: u64, seed: *const u8, out: *mut u32) -> c_int;
     pub fn cpir_dtc_layout_for(num_slots: u64, num_cols: u32, mat_elem_bit_len: u32, out: *mut cpir_dtc_layout) -> c_int;
+    pub fn cpir_dtc_layout_for_packing(num_slots: u64, num_cols: u32, mat_elem_bit_len: u32, packing: u32, out: *mut cpir_dtc_layout) -> c_int;
 
     pub fn cpir_op_mat_x_mat(dev: *mut cpir_device, a: *const u32, lda: u64, d: *const u32, ldd: u64, m: *mut u32, ldm: u64,
                              rows: u64, inner: u64, cols: u64, rhs_max_bits: u32, accumulate: c_int, stream: *mut c_void) -> c_int;
@@ -107,6 +112,9 @@ unsafe extern "C" {
                                    n: *mut u64, c: *mut u32) -> c_int;
     pub fn cpir_setup_kv_shape(arity: u32, db: *const cpir_kv_db, mat_elem_bit_len: *mut u32, n: *mut u64, c: *mut u32,
                                hint_bytes_len: *mut usize) -> c_int;
+    pub fn cpir_hint_partial_device(dev: *mut cpir_device, seed_mu: *const u8, pub_mat_a: *const u32, d_dev: *const u32, ldd: u64,
+                                    slot_offset: u64, n_shard: u64, total_slots: u64, c: u32, rhs_max_bits: u32, m_dev: *mut u32,
+                                    stream: *mut c_void) -> c_int;
     pub fn cpir_server_from_device_matrix(dev: *mut cpir_device, d_dev: *const u32, ldd: u64, n_shard: u64, c: u32,
                                           mat_elem_bit_len: u32, slot_offset: u64, total_slots: u64, stream: *mut c_void,
                                           out: *mut *mut cpir_server) -> c_int;

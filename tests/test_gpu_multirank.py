@@ -17,13 +17,19 @@ def test_bench_multirank_on_one_gpu(world, config):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", CPIR_BENCH_BACKEND="gloo", CPIR_BENCH_SHARE_DEVICE="1", OMP_NUM_THREADS="8")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(29600 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--config", config, "--steps", "2",
-           "--warmup", "1", "--no-setup", "--no-cpu-baseline", "--verify", "--queries-per-step", "8", "--query-pool", "16"]
+           "--warmup", "1", "--no-cpu-baseline", "--verify", "--queries-per-step", "8", "--query-pool", "16"]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == world and out["verified_vs_oracle"] is True and out["scaling"] == "strong"
     assert out["value"] > 0
+    # the sharded setup (partial hints reduced to rank 0) gives the same hint as the single-process setup of the same DB
+    single = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "1", "--warmup", "0",
+                             "--no-cpu-baseline", "--queries-per-step", "8", "--query-pool", "16"], capture_output=True, text=True, timeout=900)
+    assert single.returncode == 0, single.stderr[-3000:]
+    ref = json.loads([l for l in single.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["hint_checksum"] == ref["hint_checksum"] and out["server_setup_wall_sec"] > 0
 
 
 def test_bench_single_rank_verify():

@@ -231,3 +231,32 @@ def test_setup_error_behaviour(device):
     # a one-entry database is valid (reference test matrix.rs:1430-1446)
     srv, hint, fb = cp.Server.setup(bytes(32), {b"apple": b"red"}, 3, device=device)
     assert len(fb) == 68 and srv.mat_elem_bit_len == 14
+
+
+def test_sharded_hint_partials_sum_to_the_hint(orc, device):
+    """multi-GPU setup: hint = sum over N-shards of A[:, shard] * D[shard, :]; each shard's partial comes from
+    cpir_hint_partial_device (A expanded from the seed on the host, only the shard's columns uploaded)"""
+    import torch
+
+    import chalametpir_amd as cp
+    from chalametpir_amd.distributed import shard_range
+
+    rng = np.random.default_rng(808)
+    b, C = 9, 61
+    N = 7 * 1024 * 2 + 3 * 1024 + 5
+    seed = rng.bytes(32)
+    D = random_db_matrix(rng, N, C, b)
+    want = orc.mul(orc.generate_from_seed(1774, N, seed), D)
+    unit = cp.dtc_layout_for(N, C, b).slots_per_chunk
+    total = np.zeros((1774, C), dtype=np.uint32)
+    world = 3
+    for rank in range(world):
+        lo, hi = shard_range(N, unit, rank, world)
+        if hi <= lo:
+            continue
+        D_dev = _dev(D[lo:hi])
+        M = torch.empty((1774, C), dtype=torch.int32, device="cuda")
+        device.hint_partial(seed, D_dev, lo, hi - lo, N, C, M, stream=torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        total += _host(M)
+    assert np.array_equal(total, want)
