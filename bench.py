@@ -64,6 +64,7 @@ def main() -> int:
                     help="also time the FULL Server::setup(seed, kv database) incl. filter construction and row encoding "
                          "(builds a synthetic n-key database on the host: ~1.1 GB at cfg2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip timing Server.respond on host buffers (PCIe inclusive)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
     ap.add_argument("--tune", default="", help="comma list key=value for cpir_tuning_set, e.g. respond.rows_per_unit=16")
     ap.add_argument("--sweep", action="store_true", help="time every respond kernel variant (stderr table) before the run")
@@ -283,6 +284,9 @@ def main() -> int:
             "note": "cpir_server_respond_batch_device with batch fusion: 4 queries share one stream of the packed DB; same results bit for bit",
         }
         cp.tuning_set("respond.batch_fusion", 0)
+    # the C-ABI host path a Rust caller uses: query bytes on the host -> pinned copy -> H2D -> kernel -> D2H -> bytes
+    if world == 1 and not args.no_host_path:
+        result["respond_host_path"] = host_path_timing(sharded.local, q_pool, N, torch)
     if args.verify:
         result["verified_vs_oracle"] = verify(run_step, step_counter, r_step, qps_step, pool, N, C, b, mask, rank, torch)
     if rank == 0 and world == 1:
@@ -325,6 +329,40 @@ def verify(run_step, step_counter, r_step, qps_step, pool, N, C, b, mask, rank, 
     return ok
 
 
+def host_path_timing(server, q_pool, N, torch):
+    """Server::respond as the drop-in sees it (cpir_server_respond: host query in, host response out, PCIe both ways):
+    latency of one caller, and throughput with 8 concurrent callers on the one handle (the reference serves an
+    Arc<Server> from many tokio tasks).  Never the headline `value`: the headline has q resident in HBM."""
+    import threading
+
+    qs = [q_pool[i].cpu().numpy().view(np.uint32) for i in range(min(16, q_pool.shape[0]))]
+    for q in qs[:4]:
+        server.respond_array(q)
+    t0 = time.perf_counter()
+    n1 = 64
+    for i in range(n1):
+        server.respond_array(qs[i % len(qs)])
+    lat = (time.perf_counter() - t0) / n1
+    threads, per = 8, 32
+
+    def work(k):
+        for i in range(per):
+            server.respond_array(qs[(k + i) % len(qs)])
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
+    t0 = time.perf_counter()
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    thr = threads * per / (time.perf_counter() - t0)
+    return {
+        "one_caller_us_per_query": round(lat * 1e6, 1),
+        "one_caller_queries_per_sec": round(1.0 / lat, 1),
+        "eight_callers_queries_per_sec": round(thr, 1),
+        "query_bytes": 4 * N,
+        "note": "cpir_server_respond on host buffers: pinned staging + H2D + respond kernel + D2H, per-call pooled stream",
+    }
+
+
 def sweep(cp, torch, run_step, qps_step):
     """time each respond kernel variant (one process, interleaved rounds) -- tuning aid, output on stderr"""
     variants = [(R, nt, bpc) for R in (4, 8, 16) for nt in (0, 1) for bpc in (1, 2, 3, 4, 0)]
@@ -358,7 +396,7 @@ def cpu_baseline(server, q_pool, r_step, N, C, b, full_bytes, budget_s, torch, s
     queries; every CPU result is compared bit-for-bit with the GPU result of the same query."""
     from oracle import oracle as orc  # checker / baseline only
 
-    dtc = server.export_compressed()
+    dtc = orc.first_touch_copy(server.export_compressed())  # pages placed next to the threads that stream them (NUMA)
     orc.lib()
     n_done, t_total, mismatches = 0, 0.0, 0
     i = 0
@@ -380,7 +418,8 @@ def cpu_baseline(server, q_pool, r_step, N, C, b, full_bytes, budget_s, torch, s
         "unit": "queries/s",
         "cores": orc.num_threads(),
         "kind": "port",
-        "sample": f"{n_done} full-size queries on the same packed DB ({full_bytes / 1e9:.3f} GB/query), OpenMP over the C outputs like the reference's rayon loop",
+        "sample": f"{n_done} full-size queries on the same packed DB ({full_bytes / 1e9:.3f} GB/query), OpenMP over the C outputs like "
+                  "the reference's rayon loop, rows first-touched by the threads that stream them",
         "GBps": round(full_bytes * cpu_qps / 1e9, 1),
         "gpu_results_bit_exact": mismatches == 0,
         "queries_compared": n_done,

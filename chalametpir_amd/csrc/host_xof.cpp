@@ -27,7 +27,9 @@ inline uint64_t rotl(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
 // One permutation = 12 rounds, each written out on 25 named lanes (theta, rho+pi into B, chi+iota back into A).
 // Multi-versioned: on x86-64-v3 hosts (every EPYC/Xeon a GPU box has) chi's ~b & c becomes one ANDN and the rotates RORX;
 // the baseline clone keeps the library loadable anywhere.  The dispatch is resolved once at load time (ifunc).
+#if defined(__clang__) && defined(__x86_64__)  // hipcc builds the library; gcc (sanitizer builds) lacks this clone syntax
 __attribute__((target_clones("default", "arch=x86-64-v3")))
+#endif
 void keccak_p1600_12(uint64_t* A) {
   uint64_t a00 = A[0], a01 = A[1], a02 = A[2], a03 = A[3], a04 = A[4];
   uint64_t a05 = A[5], a06 = A[6], a07 = A[7], a08 = A[8], a09 = A[9];

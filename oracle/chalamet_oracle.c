@@ -230,8 +230,10 @@ HOT static void respond_rows(const uint32_t* q, uint64_t q_cols, const uint32_t*
                              uint64_t rhs_cols, unsigned cf, unsigned b, uint32_t* out) {
   const unsigned slot = 32u / cf;
   const uint32_t mask = (1u << b) - 1u;
-  /* matrix.rs:345 / 383 / 429: par_iter_mut over the output elements, one sequential fold per output */
-#pragma omp parallel for schedule(dynamic, 4)
+  /* matrix.rs:345 / 383 / 429: par_iter_mut over the output elements, one sequential fold per output.  Static schedule:
+   * every row costs the same, and together with or_first_touch_copy() it keeps a thread on the rows it first touched
+   * (NUMA-local on a multi-socket host), which is the best case for this CPU baseline. */
+#pragma omp parallel for schedule(static)
   for (uint64_t c_idx = 0; c_idx < rhs_rows; c_idx++) {
     const uint32_t* row = rhs + c_idx * rhs_cols;
     uint32_t acc = 0;
@@ -999,6 +1001,12 @@ uint64_t or_synth_u64(uint64_t seed, uint64_t index) {
 void or_synth_fill_u32(uint32_t* out, uint64_t count, uint64_t seed, uint64_t index0, uint32_t mask) {
 #pragma omp parallel for schedule(static)
   for (uint64_t i = 0; i < count; i++) out[i] = (uint32_t)(or_synth_u64(seed, index0 + i) >> 32) & mask;
+}
+
+void or_first_touch_copy(uint32_t* dst, const uint32_t* src, uint64_t rows, uint64_t cols) {
+  /* copy a row-major matrix so that each row's pages are first touched by the thread that respond_rows() gives that row to */
+#pragma omp parallel for schedule(static)
+  for (uint64_t r = 0; r < rows; r++) memcpy(dst + r * cols, src + r * cols, (size_t)cols * 4u);
 }
 
 int or_num_threads(void) {

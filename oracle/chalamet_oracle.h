@@ -225,6 +225,9 @@ int or_ternary_from_u32(uint32_t val, uint32_t* out);
 uint64_t or_synth_u64(uint64_t seed, uint64_t index);
 void or_synth_fill_u32(uint32_t* out, uint64_t count, uint64_t seed, uint64_t index0, uint32_t mask);
 
+/* NUMA-friendly placement for the timed CPU baseline: parallel first-touch copy with the same static row schedule the
+ * respond loop uses */
+void or_first_touch_copy(uint32_t* dst, const uint32_t* src, uint64_t rows, uint64_t cols);
 int or_num_threads(void);
 
 #ifdef __cplusplus

@@ -406,6 +406,14 @@ def client_process_response(filt: Filter, key: bytes, secret_c: np.ndarray, resp
     return bytes(out[: n.value])
 
 
+def first_touch_copy(m: np.ndarray) -> np.ndarray:
+    """copy of a row-major matrix whose pages are first touched by the OpenMP threads that will later stream those rows"""
+    m = _u32(m)
+    out = np.empty_like(m)
+    lib().or_first_touch_copy(_p(out), _p(m), C.c_uint64(m.shape[0]), C.c_uint64(m.shape[1]))
+    return out
+
+
 # ------------------------------------------------------------------ synthetic inputs
 def synth_fill_u32(count: int, seed: int, index0: int = 0, mask: int = 0xFFFFFFFF) -> np.ndarray:
     out = np.empty(count, dtype=np.uint32)
