@@ -1009,6 +1009,14 @@ void or_first_touch_copy(uint32_t* dst, const uint32_t* src, uint64_t rows, uint
   for (uint64_t r = 0; r < rows; r++) memcpy(dst + r * cols, src + r * cols, (size_t)cols * 4u);
 }
 
+void or_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int or_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

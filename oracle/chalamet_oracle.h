@@ -228,6 +228,7 @@ void or_synth_fill_u32(uint32_t* out, uint64_t count, uint64_t seed, uint64_t in
 /* NUMA-friendly placement for the timed CPU baseline: parallel first-touch copy with the same static row schedule the
  * respond loop uses */
 void or_first_touch_copy(uint32_t* dst, const uint32_t* src, uint64_t rows, uint64_t cols);
+void or_set_num_threads(int n);
 int or_num_threads(void);
 
 #ifdef __cplusplus

@@ -131,6 +131,23 @@ def num_threads() -> int:
     return int(lib().or_num_threads())
 
 
+def set_num_threads(n: int) -> None:
+    lib().or_set_num_threads(C.c_int(n))
+
+
+def usable_cpus() -> int:
+    """CPUs this process may actually use: min(affinity mask, cgroup v2 CPU quota) -- a container with a 16-CPU quota on a
+    256-thread host runs 128 OpenMP threads slower than 16"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 # ------------------------------------------------------------------ XOF
 def turboshake128(msg: bytes, out_len: int, domain_sep: int = 0x1F) -> bytes:
     out = (C.c_uint8 * out_len)()
