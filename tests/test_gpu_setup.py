@@ -260,3 +260,16 @@ def test_sharded_hint_partials_sum_to_the_hint(orc, device):
         torch.cuda.synchronize()
         total += _host(M)
     assert np.array_equal(total, want)
+
+
+def test_xof_fast_path_on_this_host_matches_oracle(orc, native):
+    """Matrix::generate_from_seed through the product's XOF on the GPU box's host CPU: there the long-squeeze fast path (AVX-512
+    single-state Keccak, chalametpir_amd/csrc/host_xof.cpp) is live, which the AVX-less build container cannot execute.
+    Marked gpu only because it has to run on that box; sizes straddle the 168-byte block and the 8-block fast-path threshold."""
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(4242)
+    for rows, cols in ((1, 1), (1, 41), (1, 42), (3, 335), (1, 336), (1, 337), (7, 100003), (1774, 3001)):
+        seed = rng.bytes(32)
+        got = cp.generate_from_seed(rows, cols, seed)
+        assert got.tobytes() == orc.turboshake128(seed, rows * cols * 4), (rows, cols)
