@@ -6,13 +6,12 @@
 //
 // Expanding the public matrix A is one sponge squeezed for 4*1774*N bytes (7.8 GiB at 2^20 keys): sequential by
 // construction, so it stays on a host core and is overlapped with H2D + the device matmul (capi.hip).
+// Measured on the GPU box's EPYC 9575F: this scalar permutation squeezes 1.45-1.7 GB/s.  An AVX-512 single-state variant
+// (five planes in zmm registers, vprolvq / vpermq / vpternlogq, a 5x5 qword transpose per round for pi) was written,
+// verified and measured at 1.31 GB/s -- its round is a chain of ~5 dependent cross-lane permutes -- so it was dropped.
 #include <cstddef>
 #include <cstdint>
-#include <cstdlib>
 #include <cstring>
-#if defined(__x86_64__)
-#include <immintrin.h>
-#endif
 
 #include "cpir_internal.hpp"
 
@@ -112,97 +111,6 @@ void keccak_p1600_12(uint64_t* A) {
   A[20] = a20, A[21] = a21, A[22] = a22, A[23] = a23, A[24] = a24;
 }
 
-#if defined(__x86_64__)
-// ---- AVX-512 single-state permutation for long squeezes -------------------------------------------------------------------
-// Expanding A is ONE sponge squeezed for gigabytes, so the only speed-up available is a faster Keccak-p itself.  The state is
-// held as five "planes" (row y = lanes A[0..4][y] in qwords 0..4 of one zmm); per round:
-//   theta  column parities with vpternlogq, the x-1 / x+1 neighbours with vpermq, one vprolq;
-//   rho    one vprolvq per plane (per-lane rotation counts);
-//   pi     new[y][x] = old[x][(x + 3y) mod 5]: one vpermq per plane lines the wanted lane up at position y, then a 5x5 qword
-//          transpose (unpack + vpermt2q + one masked vpermq per plane);
-//   chi    two vpermq + one vpternlogq (a ^ (~b & c)) per plane;  iota on plane 0.
-// The state stays in registers across blocks and every block's 168 bytes are stored straight into the output.
-__attribute__((target("avx512f"))) void squeeze_blocks_avx512(uint64_t* state, uint8_t* out, size_t nblocks) {
-  const __mmask8 m5 = 0x1f;
-  __m512i r0 = _mm512_maskz_loadu_epi64(m5, state + 0), r1 = _mm512_maskz_loadu_epi64(m5, state + 5),
-          r2 = _mm512_maskz_loadu_epi64(m5, state + 10), r3 = _mm512_maskz_loadu_epi64(m5, state + 15),
-          r4 = _mm512_maskz_loadu_epi64(m5, state + 20);
-  const __m512i xm1 = _mm512_setr_epi64(4, 0, 1, 2, 3, 5, 6, 7);  // lane x <- x-1
-  const __m512i xp1 = _mm512_setr_epi64(1, 2, 3, 4, 0, 5, 6, 7);  // lane x <- x+1
-  const __m512i xp2 = _mm512_setr_epi64(2, 3, 4, 0, 1, 5, 6, 7);  // lane x <- x+2
-  const __m512i rho0 = _mm512_setr_epi64(0, 1, 62, 28, 27, 0, 0, 0), rho1 = _mm512_setr_epi64(36, 44, 6, 55, 20, 0, 0, 0),
-                rho2 = _mm512_setr_epi64(3, 10, 43, 25, 39, 0, 0, 0), rho3 = _mm512_setr_epi64(41, 45, 15, 21, 8, 0, 0, 0),
-                rho4 = _mm512_setr_epi64(18, 2, 61, 56, 14, 0, 0, 0);
-  // pi, step 1: plane X gets its lane (X + 3Y) mod 5 moved to position Y
-  const __m512i pi0 = _mm512_setr_epi64(0, 3, 1, 4, 2, 5, 6, 7), pi1 = _mm512_setr_epi64(1, 4, 2, 0, 3, 5, 6, 7),
-                pi2 = _mm512_setr_epi64(2, 0, 3, 1, 4, 5, 6, 7), pi3 = _mm512_setr_epi64(3, 1, 4, 2, 0, 5, 6, 7),
-                pi4 = _mm512_setr_epi64(4, 2, 0, 3, 1, 5, 6, 7);
-  // pi, step 2 (transpose): pick pairs out of the unpacked (T0,T1) / (T2,T3) registers, then drop T4's lane into position 4
-  const __m512i tA = _mm512_setr_epi64(0, 1, 8, 9, 0, 0, 0, 0), tB = _mm512_setr_epi64(2, 3, 10, 11, 0, 0, 0, 0),
-                tC = _mm512_setr_epi64(4, 5, 12, 13, 0, 0, 0, 0);
-  const __m512i e0 = _mm512_set1_epi64(0), e1 = _mm512_set1_epi64(1), e2 = _mm512_set1_epi64(2), e3 = _mm512_set1_epi64(3),
-                e4 = _mm512_set1_epi64(4);
-  const __mmask8 m4 = 0x10, m0123 = 0x0f;
-  for (size_t blk = 0; blk < nblocks; blk++) {
-    for (int round = 0; round < 12; round++) {
-      // theta
-      __m512i c = _mm512_ternarylogic_epi64(_mm512_ternarylogic_epi64(r0, r1, r2, 0x96), r3, r4, 0x96);
-      const __m512i d = _mm512_xor_si512(_mm512_permutexvar_epi64(xm1, c), _mm512_rol_epi64(_mm512_permutexvar_epi64(xp1, c), 1));
-      // theta apply + rho
-      r0 = _mm512_rolv_epi64(_mm512_xor_si512(r0, d), rho0);
-      r1 = _mm512_rolv_epi64(_mm512_xor_si512(r1, d), rho1);
-      r2 = _mm512_rolv_epi64(_mm512_xor_si512(r2, d), rho2);
-      r3 = _mm512_rolv_epi64(_mm512_xor_si512(r3, d), rho3);
-      r4 = _mm512_rolv_epi64(_mm512_xor_si512(r4, d), rho4);
-      // pi
-      const __m512i t0 = _mm512_permutexvar_epi64(pi0, r0), t1 = _mm512_permutexvar_epi64(pi1, r1),
-                    t2 = _mm512_permutexvar_epi64(pi2, r2), t3 = _mm512_permutexvar_epi64(pi3, r3),
-                    t4 = _mm512_permutexvar_epi64(pi4, r4);
-      const __m512i u01l = _mm512_unpacklo_epi64(t0, t1), u01h = _mm512_unpackhi_epi64(t0, t1);
-      const __m512i u23l = _mm512_unpacklo_epi64(t2, t3), u23h = _mm512_unpackhi_epi64(t2, t3);
-      __m512i b0 = _mm512_maskz_permutex2var_epi64(m0123, u01l, tA, u23l);
-      __m512i b1 = _mm512_maskz_permutex2var_epi64(m0123, u01h, tA, u23h);
-      __m512i b2 = _mm512_maskz_permutex2var_epi64(m0123, u01l, tB, u23l);
-      __m512i b3 = _mm512_maskz_permutex2var_epi64(m0123, u01h, tB, u23h);
-      __m512i b4 = _mm512_maskz_permutex2var_epi64(m0123, u01l, tC, u23l);
-      b0 = _mm512_mask_permutexvar_epi64(b0, m4, e0, t4);
-      b1 = _mm512_mask_permutexvar_epi64(b1, m4, e1, t4);
-      b2 = _mm512_mask_permutexvar_epi64(b2, m4, e2, t4);
-      b3 = _mm512_mask_permutexvar_epi64(b3, m4, e3, t4);
-      b4 = _mm512_mask_permutexvar_epi64(b4, m4, e4, t4);
-      // chi: a ^ (~b & c) = truth table 0xD2
-      r0 = _mm512_ternarylogic_epi64(b0, _mm512_permutexvar_epi64(xp1, b0), _mm512_permutexvar_epi64(xp2, b0), 0xD2);
-      r1 = _mm512_ternarylogic_epi64(b1, _mm512_permutexvar_epi64(xp1, b1), _mm512_permutexvar_epi64(xp2, b1), 0xD2);
-      r2 = _mm512_ternarylogic_epi64(b2, _mm512_permutexvar_epi64(xp1, b2), _mm512_permutexvar_epi64(xp2, b2), 0xD2);
-      r3 = _mm512_ternarylogic_epi64(b3, _mm512_permutexvar_epi64(xp1, b3), _mm512_permutexvar_epi64(xp2, b3), 0xD2);
-      r4 = _mm512_ternarylogic_epi64(b4, _mm512_permutexvar_epi64(xp1, b4), _mm512_permutexvar_epi64(xp2, b4), 0xD2);
-      // iota
-      r0 = _mm512_xor_si512(r0, _mm512_maskz_set1_epi64(0x01, (long long)kRoundConstants[round]));
-    }
-    // 168 bytes = lanes 0..20
-    _mm512_mask_storeu_epi64(out + 0, m5, r0);
-    _mm512_mask_storeu_epi64(out + 40, m5, r1);
-    _mm512_mask_storeu_epi64(out + 80, m5, r2);
-    _mm512_mask_storeu_epi64(out + 120, m5, r3);
-    _mm512_mask_storeu_epi64(out + 160, 0x01, r4);
-    out += kRate;
-  }
-  _mm512_mask_storeu_epi64(state + 0, m5, r0);
-  _mm512_mask_storeu_epi64(state + 5, m5, r1);
-  _mm512_mask_storeu_epi64(state + 10, m5, r2);
-  _mm512_mask_storeu_epi64(state + 15, m5, r3);
-  _mm512_mask_storeu_epi64(state + 20, m5, r4);
-}
-
-bool have_avx512() {
-  static const bool yes = __builtin_cpu_supports("avx512f") && getenv("CPIR_XOF_SCALAR") == nullptr;
-  return yes;
-}
-#else
-bool have_avx512() { return false; }
-void squeeze_blocks_avx512(uint64_t*, uint8_t*, size_t) {}
-#endif
-
 }  // namespace
 
 TurboShake128::TurboShake128() : pos(0) { memset(s, 0, sizeof(s)); }
@@ -229,13 +137,6 @@ void TurboShake128::finalize(uint8_t domain_sep) {
 void TurboShake128::squeeze(uint8_t* out, size_t len) {
   const uint8_t* bytes = reinterpret_cast<const uint8_t*>(s);
   while (len) {
-    if (pos == kRate && len >= 8 * kRate && have_avx512()) {
-      // long squeeze on a block boundary: "permute, emit 168 bytes" repeated with the state kept in zmm registers
-      const size_t nblocks = len / kRate;
-      squeeze_blocks_avx512(s, out, nblocks);
-      out += nblocks * kRate, len -= nblocks * kRate;  // pos stays at kRate: the last block is fully consumed
-      continue;
-    }
     if (pos == kRate) keccak_p1600_12(s), pos = 0;
     size_t n = kRate - pos;
     if (n > len) n = len;

@@ -262,10 +262,10 @@ def test_sharded_hint_partials_sum_to_the_hint(orc, device):
     assert np.array_equal(total, want)
 
 
-def test_xof_fast_path_on_this_host_matches_oracle(orc, native):
-    """Matrix::generate_from_seed through the product's XOF on the GPU box's host CPU: there the long-squeeze fast path (AVX-512
-    single-state Keccak, chalametpir_amd/csrc/host_xof.cpp) is live, which the AVX-less build container cannot execute.
-    Marked gpu only because it has to run on that box; sizes straddle the 168-byte block and the 8-block fast-path threshold."""
+def test_xof_on_this_host_matches_oracle(orc, native):
+    """Matrix::generate_from_seed through the product's XOF on the GPU box's host CPU: there the x86-64-v3 clone of the Keccak
+    permutation (chalametpir_amd/csrc/host_xof.cpp) is the one dispatched, which the build container's older CPU never runs.
+    Marked gpu only because it has to run on that box; sizes straddle the 168-byte block boundary."""
     import chalametpir_amd as cp
 
     rng = np.random.default_rng(4242)
