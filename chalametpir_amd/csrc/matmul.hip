@@ -270,13 +270,27 @@ int launch_mat_x_mat(const Device* dev, const uint32_t* A, uint64_t lda, const u
   const uint64_t tiles_m = (rows + BM - 1) / BM;
   const uint64_t tiles_n = (cols + BN - 1) / BN;
   if (tiles_m > 65535 || tiles_n > 0x7fffffffull) return CPIR_ERR_INVALID_ARGUMENT;
-  // split-K so that even one 64-row block of the hint fills the chip (u32 atomics keep the sum exact)
-  const uint64_t target = (uint64_t)dev->num_cus * 4;
-  uint64_t splits = target / (tiles_m * tiles_n);
-  const uint64_t max_splits = (inner + 511) / 512;  // at least 512 k per split
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  if (splits > 65535) splits = 65535;
+  // split-K (u32 atomics keep the sum exact) so that the grid is a whole number of "rounds" of resident blocks: with 224
+  // output tiles (the 1774 x 940 hint) and 3 resident blocks per CU, 4 splits = 896 blocks run as one full round of 768 plus
+  // a round that keeps a sixth of the chip busy (58 % efficiency, measured 21 TMAC/s); 24 splits = 5376 blocks = exactly 7
+  // rounds.  Pick the split count with the best round efficiency, fewest splits on ties.
+  int occ = 0;
+  const void* fn = packed ? reinterpret_cast<const void*>(mat_x_mat_packed16_kernel<true>) : reinterpret_cast<const void*>(mat_x_mat_u32_kernel);
+  CPIR_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, kThreads, 0));
+  if (occ < 1) occ = 1;
+  const uint64_t resident = (uint64_t)dev->num_cus * (uint64_t)occ;
+  const uint64_t tiles = tiles_m * tiles_n;
+  uint64_t max_splits = (inner + 2047) / 2048;  // at least 2048 k per split: the epilogue's atomics stay negligible
+  if (max_splits > 64) max_splits = 64;
+  if (max_splits < 1) max_splits = 1;
+  uint64_t splits = 1;
+  double best = 0.0;
+  for (uint64_t sct = 1; sct <= max_splits; sct++) {
+    const uint64_t blocks = tiles * sct;
+    const uint64_t rounds = (blocks + resident - 1) / resident;
+    const double eff = (double)blocks / (double)(rounds * resident);
+    if (eff > best + 0.02) best = eff, splits = sct;
+  }
   uint64_t k_per_split = (inner + splits - 1) / splits;
   k_per_split = (k_per_split + ks - 1) / ks * ks;
   splits = (inner + k_per_split - 1) / k_per_split;

@@ -60,6 +60,16 @@ def main():
                 summary["respond"][ctr + "_mean_raw"] = mean
                 summary["respond"][ctr + "_dispatches"] = len(vals)
                 print(f"-- {ctr}: respond_kernel mean over {len(vals)} dispatches = {mean:.1f} (raw units; x1024 = bytes => {mean * 1024 / 1e9:.4f} GB)")
+    setup = kernel_stats(os.path.join(root, "setup_trace"))
+    setup.sort(key=lambda r: -float(r.get("TotalDurationNs", 0) or 0))
+    if setup:
+        print("-- kernel stats of a run that includes Server::setup (hint matmul, transpose+pack) --")
+        summary["setup_kernels"] = []
+        for r in setup[:8]:
+            name, calls = r.get("Name", ""), int(float(r.get("Calls", 0)))
+            avg, tot = float(r.get("AverageNs", 0) or 0), float(r.get("TotalDurationNs", 0) or 0)
+            print(f"{calls:7d} calls  avg {avg / 1e3:10.2f} us  total {tot / 1e6:10.3f} ms  {name[:110]}")
+            summary["setup_kernels"].append({"name": name, "calls": calls, "avg_us": avg / 1e3, "total_ms": tot / 1e6})
     with open(os.path.join(root, "summary.json"), "w") as fh:
         json.dump(summary, fh, indent=1)
 
