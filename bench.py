@@ -138,7 +138,10 @@ def main() -> int:
     for i in range(pool):
         device.synth_fill(q_pool, N, SEED_Q + i, offset_words=i * N, stream=stream)
     qps_step = args.queries_per_step
-    r_step = torch.zeros((qps_step, C), dtype=torch.int32, device="cuda")
+    # two response buffers: with several ranks the all-reduce of step k overlaps the respond launches of step k+1
+    r_bufs = [torch.zeros((qps_step, C), dtype=torch.int32, device="cuda") for _ in range(2)]
+    r_step = r_bufs[0]
+    pending = [None, None]
     torch.cuda.synchronize()
 
     step_counter = [0]
@@ -149,26 +152,40 @@ def main() -> int:
     # used to enqueue the step's launches from C instead of one Python/ctypes round trip per query
     cp.tuning_set("respond.batch_fusion", 0)
 
-    def run_step(events=None):
-        base = (step_counter[0] * qps_step) % pool
+    def drain():
+        for i in range(2):
+            if pending[i] is not None:
+                pending[i].wait()
+                pending[i] = None
+
+    def run_step(events=None, out=None):
+        k = step_counter[0]
+        base = (k * qps_step) % pool
         step_counter[0] += 1
+        buf = k % 2 if out is None else 0
+        r = r_bufs[buf] if out is None else out
+        if pending[buf] is not None:  # the collective that last used this buffer must be done before it is overwritten
+            pending[buf].wait()
+            pending[buf] = None
         if events:
             events[0].record(stream)
         if args.enqueue == "batch":
-            sharded.respond_partial_device(q_pool[base:base + qps_step], r_step, batch=qps_step, stream=stream)
+            sharded.respond_partial_device(q_pool[base:base + qps_step], r, batch=qps_step, stream=stream)
         else:
             for j in range(qps_step):
-                sharded.respond_partial_device(q_pool[base + j], r_step[j], stream=stream)
+                sharded.respond_partial_device(q_pool[base + j], r[j], stream=stream)
         if events:
             events[1].record(stream)
         if world > 1:
-            dist.all_reduce(r_step)  # int32 sum == u32 wrap-around sum; one collective for the step's queries
+            # int32 sum == u32 wrap-around sum; ONE collective for the step's queries, overlapped with the next step
+            pending[buf] = dist.all_reduce(r, async_op=True)
 
     if args.sweep and rank == 0:
         sweep(cp, torch, run_step, qps_step)
 
     for _ in range(args.warmup):
         run_step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -178,6 +195,7 @@ def main() -> int:
     t_begin = time.perf_counter()
     for k in range(args.steps):
         run_step(step_events[k])
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -227,7 +245,7 @@ def main() -> int:
                         f"encoded DB N={N} x C={C}, b={b}, {cf} fields/u32, packed D^T {4 * C * W / 1e9:.3f} GB",
             "queries_per_step": qps_step,
             "query_pool": pool,
-            "sharding": f"N split over {world} GPU(s), one all-reduce of {qps_step}x{C} u32 per step" if world > 1 else "single GPU",
+            "sharding": f"N split over {world} GPU(s), one all-reduce of {qps_step}x{C} u32 per step, overlapped with the next step" if world > 1 else "single GPU",
         },
         "achieved_hbm_GBps_whole_job": round(full_bytes * qps / 1e9, 1),
         "algorithmic_bytes_per_query": full_bytes,
@@ -271,12 +289,14 @@ def main() -> int:
         cp.tuning_set("respond.batch_fusion", 1)
         for _ in range(3):
             run_step()
+        drain()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         n_fused_steps = max(4, args.steps // 4)
         for _ in range(n_fused_steps):
             run_step()
+        drain()
         e1.record(stream)
         torch.cuda.synchronize()
         fused_us = e0.elapsed_time(e1) * 1e3 / (n_fused_steps * qps_step)
@@ -291,7 +311,8 @@ def main() -> int:
     if world == 1 and not args.no_host_path:
         result["respond_host_path"] = host_path_timing(sharded.local, q_pool, N, torch)
     if args.verify:
-        result["verified_vs_oracle"] = verify(run_step, step_counter, r_step, qps_step, pool, N, C, b, mask, rank, torch)
+        drain()
+        result["verified_vs_oracle"] = verify(run_step, drain, step_counter, r_step, qps_step, pool, N, C, b, mask, rank, torch)
     if rank == 0 and world == 1:
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sharded.local, q_pool, r_step, N, C, b, full_bytes, args.cpu_seconds, torch, stream)
@@ -312,11 +333,12 @@ def main() -> int:
     return 0
 
 
-def verify(run_step, step_counter, r_step, qps_step, pool, N, C, b, mask, rank, torch):
+def verify(run_step, drain, step_counter, r_step, qps_step, pool, N, C, b, mask, rank, torch):
     """One more step; rank 0 rebuilds the FULL synthetic DB and the step's queries on the host with the oracle's copy of the
     generator, and checks the (all-reduced) responses bit for bit."""
     base = (step_counter[0] * qps_step) % pool
-    run_step()
+    run_step(out=r_step)
+    drain()
     torch.cuda.synchronize()
     if rank != 0:
         return None
