@@ -225,7 +225,7 @@ def main() -> int:
     # bytes the launch really has to move with the packing in use (device rows incl. zero padding + q slice + response)
     shard_words = int(sharded.local.layout.total_words) if sharded.local is not None else 0
     moved_bytes = (4 * shard_words + 4 * (hi - lo) + 4 * C) * passes_per_launch
-    packing = "dense64" if full_layout.packing == 1 else "reference"
+    packing = {0: "reference", 1: "dense64", 2: "planar"}[int(full_layout.packing)]
 
     result = {
         "metric": "server_respond_queries_per_sec",
@@ -251,7 +251,7 @@ def main() -> int:
         "algorithmic_bytes_per_query": full_bytes,
         "roofline": {
             "bound": "hbm",
-            "kernel": "respond_kernel",
+            "kernel": "respond_planar_kernel" if full_layout.packing == 2 else "respond_kernel",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
@@ -261,7 +261,8 @@ def main() -> int:
             "bytes_per_launch": launch_bytes,
             "passes_per_launch": passes_per_launch,
             "us_per_query": round(query_us, 2),
-            "packing": f"{packing} ({full_layout.fields_per_word} fields per {'u64' if full_layout.packing == 1 else 'u32'})",
+            "packing": (f"planar (low byte + {b - 8} bit plane(s) per field = {b} bits, i8 MFMA operand order)" if full_layout.packing == 2 else
+                        f"{packing} ({full_layout.fields_per_word} fields per {'u64' if full_layout.packing == 1 else 'u32'})"),
             "moved_bytes_per_launch": moved_bytes,
             "moved_GBps": round(moved_bytes / (launch_us * 1e-6) / 1e9, 1) if launch_us > 0 else 0.0,
             "mall_resident": bool(launch_bytes_q <= 256 * (1 << 20)),

@@ -68,6 +68,10 @@ uint64_t respond_scratch_words(const cpir_dtc_layout& L, uint32_t batch);
 int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                    uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, uint32_t* scratch, hipStream_t stream);
 const char* respond_kernel_name(const cpir_dtc_layout& L);
+// respond_planar.hip (CPIR_PACK_PLANAR: the MFMA path); same contract as launch_respond
+int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
+                          uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, int blocks_per_cu,
+                          bool nontemporal, bool xcd_split, int interleave);
 bool respond_batch_fusion();
 
 // pack.hip
@@ -105,7 +109,9 @@ uint64_t encoded_num_cols(uint64_t max_value_byte_len, uint32_t b);
 int dtc_layout_for(uint64_t N, uint32_t C, uint32_t b, cpir_dtc_layout* out);
 int dtc_layout_for_packing(uint64_t N, uint32_t C, uint32_t b, uint32_t packing, cpir_dtc_layout* out);
 uint32_t dense_fields_per_word64(uint32_t b);
+uint32_t planar_hi_planes(uint32_t b);
 void set_default_dense(bool on);
+void set_default_planar(bool on);
 int check_layout(const cpir_dtc_layout& L);
 
 // host_encoder.cpp : binary fuse filter + row codec (Matrix::from_kv_database)

@@ -70,8 +70,18 @@ uint32_t dense_fields_per_word64(uint32_t b) {
   return k > 2 * cf ? k : 0;
 }
 
+// bit planes above the low byte in the planar packing, or 0 where it is not offered.  planar stores a field as its low
+// byte plus (b - 8) one-bit planes: exactly b bits per field, so it is offered where that beats both other packings
+// (b >= 9; at b <= 8 the reference packing already spends 8 bits per field)
+uint32_t planar_hi_planes(uint32_t b) {
+  if (compression_factor(b) == 0 || b < 9) return 0;
+  return b - 8;
+}
+
 static std::atomic<int> g_default_dense{1};
+static std::atomic<int> g_default_planar{0};
 void set_default_dense(bool on) { g_default_dense.store(on ? 1 : 0); }
+void set_default_planar(bool on) { g_default_planar.store(on ? 1 : 0); }
 
 int dtc_layout_for_packing(uint64_t N, uint32_t C, uint32_t b, uint32_t packing, cpir_dtc_layout* out) {
   if (!out) return CPIR_ERR_INVALID_ARGUMENT;
@@ -93,6 +103,21 @@ int dtc_layout_for_packing(uint64_t N, uint32_t C, uint32_t b, uint32_t packing,
     if (k == 0) return CPIR_ERR_INVALID_ARGUMENT;
     out->fields_per_word = k;
     out->chunk_words = 2048;
+  } else if (packing == CPIR_PACK_PLANAR) {
+    // super-tiles of 16 columns x 512 slots: 8 KiB of low bytes + 1 KiB per high bit plane, stored tile after tile
+    // (column tile major, then along the slots); after the tiles one u32 per padded column: the wrap-around sum of its fields
+    const uint32_t hb = planar_hi_planes(b);
+    if (hb == 0) return CPIR_ERR_INVALID_ARGUMENT;
+    const uint64_t rp = ((uint64_t)C + CPIR_DTC_ROW_ALIGN - 1) / CPIR_DTC_ROW_ALIGN * CPIR_DTC_ROW_ALIGN;
+    if (rp > 0xffffffffull) return CPIR_ERR_INVALID_MATRIX_DIMENSION;
+    out->fields_per_word = 0;
+    out->chunk_words = (8 + hb) * 256;  // u32 words of one super-tile
+    out->slots_per_chunk = CPIR_PLANAR_SLOTS_PER_TILE;
+    const uint64_t ks = (N + CPIR_PLANAR_SLOTS_PER_TILE - 1) / CPIR_PLANAR_SLOTS_PER_TILE;
+    out->words_per_row_padded = ks * (out->chunk_words / 16);  // per column: each super-tile spends chunk_words / 16 on it
+    out->rows_padded = (uint32_t)rp;
+    out->total_words = rp * out->words_per_row_padded + rp;
+    return CPIR_OK;
   } else {
     return CPIR_ERR_INVALID_ARGUMENT;
   }
@@ -107,6 +132,7 @@ int dtc_layout_for_packing(uint64_t N, uint32_t C, uint32_t b, uint32_t packing,
 }
 
 int dtc_layout_for(uint64_t N, uint32_t C, uint32_t b, cpir_dtc_layout* out) {
+  if (g_default_planar.load() && planar_hi_planes(b) != 0) return dtc_layout_for_packing(N, C, b, CPIR_PACK_PLANAR, out);
   const bool dense = g_default_dense.load() && dense_fields_per_word64(b) != 0;
   return dtc_layout_for_packing(N, C, b, dense ? CPIR_PACK_DENSE64 : CPIR_PACK_REFERENCE, out);
 }

@@ -257,6 +257,132 @@ __global__ void __launch_bounds__(kThreads) dtc_export_dense_kernel(const uint64
   }
 }
 
+// ---- planar packing (CPIR_PACK_PLANAR; layout documented at cpir_dtc_layout, consumed by respond_planar.hip) -----------------------
+// One block = one super-tile: 16 columns x 512 slots.  FROM_REF = false reads the encoded DB matrix D (N x C, leading dim ld);
+// FROM_REF = true reads the reference's compressed transposed matrix (C x W, ld = W), dropping fields >= N and bits >= b as
+// normalise_word does.  Also accumulates, per column, the wrap-around sum of its fields (the correction term of the signed-byte
+// arithmetic) into colsum (zeroed by the launcher).
+template <bool FROM_REF>
+__global__ void __launch_bounds__(kThreads) planar_pack_kernel(const uint32_t* __restrict__ src, uint64_t ld, uint64_t N, uint32_t C,
+                                                                uint32_t b, uint32_t cf, uint32_t hb, uint32_t ks_total,
+                                                                uint4* __restrict__ tiles, uint32_t* __restrict__ colsum,
+                                                                uint32_t* __restrict__ or_of_entries) {
+  __shared__ uint16_t tile[CPIR_PLANAR_SLOTS_PER_TILE][18];
+  const int tid = threadIdx.x;
+  const uint32_t ks = blockIdx.x, T = blockIdx.y, c0 = T * 16;
+  const uint64_t n0 = (uint64_t)ks * CPIR_PLANAR_SLOTS_PER_TILE;
+  const uint32_t mask = (1u << b) - 1u;
+  uint32_t seen = 0;
+  if constexpr (!FROM_REF) {
+    for (int i = tid; i < (int)CPIR_PLANAR_SLOTS_PER_TILE * 16; i += kThreads) {  // 16 lanes cover one 64-byte piece of a D row
+      const uint32_t c = i & 15, sl = i >> 4;
+      const uint64_t n = n0 + sl;
+      const uint32_t v = (n < N && c0 + c < C) ? src[n * ld + c0 + c] : 0u;
+      seen |= v;
+      tile[sl][c] = (uint16_t)(v & mask);  // matrix.rs:121,149,181: every field is masked to b bits
+    }
+  } else {
+    const uint32_t S = 32 / cf;
+    for (int i = tid; i < (int)CPIR_PLANAR_SLOTS_PER_TILE * 16; i += kThreads) {  // lanes run along the packed words of one row
+      const uint32_t sl = i & (CPIR_PLANAR_SLOTS_PER_TILE - 1), c = i >> 9;
+      const uint64_t n = n0 + sl;
+      uint32_t v = 0;
+      if (n < N && c0 + c < C) v = (src[(uint64_t)(c0 + c) * ld + n / cf] >> ((uint32_t)(n % cf) * S)) & mask;
+      tile[sl][c] = (uint16_t)v;
+    }
+  }
+  __syncthreads();
+
+  const uint32_t st16 = (8 + hb) * 64;
+  uint4* base = tiles + ((uint64_t)T * ks_total + ks) * st16;
+  // low bytes, XOR 0x80 (signed-byte operand): k-block kb, lane l = 16*g + cl holds slots 64*kb + 16*g + 0..15 of column cl
+  for (int piece = tid; piece < 512; piece += kThreads) {
+    const uint32_t kb = piece >> 6, l = piece & 63, cl = l & 15, g = l >> 4;
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int jx = 0; jx < 16; jx++) {
+      const uint32_t f = tile[kb * 64 + g * 16 + jx][cl];
+      w[jx >> 2] |= ((f & 0xFFu) ^ 0x80u) << (8 * (jx & 3));
+    }
+    base[kb * 64 + l] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  // bit planes: plane p, lane l: dword w, bit 8*jj + 4*s + d  <-  bit 8+p of slot 64*(2w+s) + 16*g + 4*d + jj
+  for (uint32_t p = tid >> 6; p < hb; p += kThreads / 64) {
+    const uint32_t l = tid & 63, cl = l & 15, g = l >> 4;
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int ww = 0; ww < 4; ww++)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+#pragma unroll
+          for (int jj = 0; jj < 4; jj++) {
+            const uint32_t f = tile[(2 * ww + s2) * 64 + g * 16 + 4 * d + jj][cl];
+            w[ww] |= ((f >> (8 + p)) & 1u) << (8 * jj + 4 * s2 + d);
+          }
+    base[512 + p * 64 + l] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  if (tid < 16) {
+    uint32_t sum = 0;
+    for (uint32_t sl = 0; sl < CPIR_PLANAR_SLOTS_PER_TILE; sl++) sum += tile[sl][tid];
+    if (sum) atomicAdd(colsum + c0 + tid, sum);
+  }
+  if (or_of_entries) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) seen |= __shfl_xor(seen, off, 64);
+    if ((tid & 63) == 0 && seen) atomicOr(or_of_entries, seen);
+  }
+}
+
+// field (n, c) of a planar image
+__device__ __forceinline__ uint32_t planar_field(const uint8_t* bytes, uint64_t n, uint32_t c, uint32_t hb, uint32_t ks_total) {
+  const uint32_t T = c >> 4, cl = c & 15;
+  const uint64_t ks = n / CPIR_PLANAR_SLOTS_PER_TILE;
+  const uint32_t sl = (uint32_t)(n % CPIR_PLANAR_SLOTS_PER_TILE), kb = sl >> 6, g = (sl >> 4) & 3, jx = sl & 15, l = g * 16 + cl;
+  const uint8_t* t = bytes + ((uint64_t)T * ks_total + ks) * ((8 + hb) * 1024ull);
+  uint32_t f = (uint32_t)t[kb * 1024 + l * 16 + jx] ^ 0x80u;
+  for (uint32_t p = 0; p < hb; p++) {
+    const uint32_t word = reinterpret_cast<const uint32_t*>(t + 8192 + p * 1024 + l * 16)[kb >> 1];
+    f |= ((word >> (8 * (jx & 3) + 4 * (kb & 1) + (jx >> 2))) & 1u) << (8 + p);
+  }
+  return f;
+}
+
+__global__ void __launch_bounds__(kThreads) planar_export_kernel(const uint8_t* __restrict__ bytes, uint64_t W, uint64_t N, uint32_t C,
+                                                                  uint32_t cf, uint32_t hb, uint32_t ks_total, uint32_t* __restrict__ dst) {
+  const uint32_t S = 32 / cf;
+  const uint64_t total = (uint64_t)C * W;
+  for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (uint64_t)gridDim.x * kThreads) {
+    const uint64_t c = i / W, w = i % W;
+    uint32_t out = 0;
+    for (uint32_t jj = 0; jj < cf; jj++) {
+      const uint64_t n = w * cf + jj;
+      if (n < N) out |= planar_field(bytes, n, (uint32_t)c, hb, ks_total) << (jj * S);
+    }
+    dst[i] = out;
+  }
+}
+
+int launch_planar_pack(const uint32_t* src, uint64_t ld, bool from_ref, const cpir_dtc_layout& L, uint32_t* dtc, uint32_t* or_of_entries,
+                       hipStream_t stream) {
+  const uint32_t hb = planar_hi_planes(L.mat_elem_bit_len);
+  const uint64_t ks_total = (L.num_slots + CPIR_PLANAR_SLOTS_PER_TILE - 1) / CPIR_PLANAR_SLOTS_PER_TILE;
+  const uint32_t col_tiles = L.rows_padded / 16;
+  if (hb == 0 || ks_total > 0x7fffffffull || col_tiles > 65535u) return CPIR_ERR_INVALID_ARGUMENT;
+  uint32_t* colsum = dtc + (uint64_t)L.rows_padded * L.words_per_row_padded;
+  CPIR_HIP_TRY(hipMemsetAsync(colsum, 0, (size_t)L.rows_padded * sizeof(uint32_t), stream));
+  const dim3 grid((unsigned)ks_total, col_tiles);
+  if (from_ref)
+    hipLaunchKernelGGL((planar_pack_kernel<true>), grid, dim3(kThreads), 0, stream, src, ld, L.num_slots, L.num_cols, L.mat_elem_bit_len,
+                       L.compression_factor, hb, (uint32_t)ks_total, reinterpret_cast<uint4*>(dtc), colsum, or_of_entries);
+  else
+    hipLaunchKernelGGL((planar_pack_kernel<false>), grid, dim3(kThreads), 0, stream, src, ld, L.num_slots, L.num_cols, L.mat_elem_bit_len,
+                       L.compression_factor, hb, (uint32_t)ks_total, reinterpret_cast<uint4*>(dtc), colsum, or_of_entries);
+  CPIR_HIP_TRY(hipGetLastError());
+  return CPIR_OK;
+}
+
 uint32_t grid_for(const Device* dev, uint64_t total) {
   uint64_t blocks = (total + kThreads - 1) / kThreads;
   const uint64_t cap = (uint64_t)dev->num_cus * 8;
@@ -272,6 +398,7 @@ int launch_transpose_compress(const Device* dev, const uint32_t* D, uint64_t ldd
   if (!D || !dtc || ldd < L.num_cols) return CPIR_ERR_INVALID_ARGUMENT;
   CPIR_TRY(check_layout(L));
   if (reinterpret_cast<uintptr_t>(dtc) % 16 != 0) return CPIR_ERR_INVALID_ARGUMENT;
+  if (L.packing == CPIR_PACK_PLANAR) return launch_planar_pack(D, ldd, false, L, dtc, or_of_entries, stream);
   if (L.packing == CPIR_PACK_DENSE64) {
     const uint64_t chunks = L.words_per_row_padded / L.chunk_words;
     if (chunks * 16 > 0x7fffffffull) return CPIR_ERR_INVALID_ARGUMENT;
@@ -315,6 +442,10 @@ int launch_transpose_compress(const Device* dev, const uint32_t* D, uint64_t ldd
 int launch_dtc_import(const Device* dev, const uint32_t* compressed, const cpir_dtc_layout& L, uint32_t* dtc, hipStream_t stream) {
   if (!compressed || !dtc) return CPIR_ERR_INVALID_ARGUMENT;
   CPIR_TRY(check_layout(L));
+  if (L.packing == CPIR_PACK_PLANAR) {
+    if (reinterpret_cast<uintptr_t>(dtc) % 16 != 0) return CPIR_ERR_INVALID_ARGUMENT;
+    return launch_planar_pack(compressed, L.words_per_row, true, L, dtc, nullptr, stream);
+  }
   if (L.packing == CPIR_PACK_DENSE64) {
     const uint64_t stride64 = L.words_per_row_padded / 2;
     hipLaunchKernelGGL(dtc_import_dense_kernel, dim3(grid_for(dev, (uint64_t)L.rows_padded * stride64)), dim3(kThreads), 0, stream,
@@ -339,6 +470,13 @@ int launch_dtc_export(const Device* dev, const uint32_t* dtc, const cpir_dtc_lay
   if (!compressed || !dtc) return CPIR_ERR_INVALID_ARGUMENT;
   CPIR_TRY(check_layout(L));
   const uint32_t grid = grid_for(dev, (uint64_t)L.num_cols * L.words_per_row);
+  if (L.packing == CPIR_PACK_PLANAR) {
+    const uint64_t ks_total = (L.num_slots + CPIR_PLANAR_SLOTS_PER_TILE - 1) / CPIR_PLANAR_SLOTS_PER_TILE;
+    hipLaunchKernelGGL(planar_export_kernel, dim3(grid), dim3(kThreads), 0, stream, reinterpret_cast<const uint8_t*>(dtc), L.words_per_row,
+                       L.num_slots, L.num_cols, L.compression_factor, planar_hi_planes(L.mat_elem_bit_len), (uint32_t)ks_total, compressed);
+    CPIR_HIP_TRY(hipGetLastError());
+    return CPIR_OK;
+  }
   if (L.packing == CPIR_PACK_DENSE64) {
     hipLaunchKernelGGL(dtc_export_dense_kernel, dim3(grid), dim3(kThreads), 0, stream, reinterpret_cast<const uint64_t*>(dtc),
                        L.words_per_row_padded / 2, L.words_per_row, L.num_slots, L.num_cols, L.mat_elem_bit_len,

@@ -292,6 +292,7 @@ struct Tuning {
   int xcd_split = 1;       // split the chunk axis by blockIdx % 8
   int batch_fusion = 1;    // respond_batch: 1 = passes of 4/2/1 queries share one DB stream, 0 = one pass per query
   int interleave_passes = -1;  // order of the passes of one launch: 0 slice order, 1 interleaved, -1 by shard size
+  int planar_blocks_per_cu = 0;  // the matrix-core kernel (respond_planar.hip): 0 = what the occupancy API allows
 };
 Tuning g_tuning;
 std::mutex g_tuning_mu;
@@ -351,6 +352,9 @@ extern "C" int cpir_tuning_set(const char* key, int value) {
   } else if (!strcmp(key, "respond.blocks_per_cu")) {
     if (value < 0 || value > 8) return CPIR_ERR_INVALID_ARGUMENT;
     g_tuning.blocks_per_cu = value;
+  } else if (!strcmp(key, "respond.planar_blocks_per_cu")) {
+    if (value < 0 || value > 8) return CPIR_ERR_INVALID_ARGUMENT;
+    g_tuning.planar_blocks_per_cu = value;
   } else if (!strcmp(key, "respond.xcd_split")) {
     g_tuning.xcd_split = value ? 1 : 0;
   } else if (!strcmp(key, "respond.batch_fusion")) {
@@ -360,6 +364,8 @@ extern "C" int cpir_tuning_set(const char* key, int value) {
     g_tuning.interleave_passes = value;
   } else if (!strcmp(key, "layout.dense")) {
     set_default_dense(value != 0);
+  } else if (!strcmp(key, "layout.planar")) {
+    set_default_planar(value != 0);
   } else {
     return CPIR_ERR_INVALID_ARGUMENT;
   }
@@ -377,7 +383,9 @@ uint64_t respond_scratch_words(const cpir_dtc_layout&, uint32_t) {
   return 0;
 }
 
-const char* respond_kernel_name(const cpir_dtc_layout&) { return "respond_kernel"; }
+const char* respond_kernel_name(const cpir_dtc_layout& L) {
+  return L.packing == CPIR_PACK_PLANAR ? "respond_planar_kernel" : "respond_kernel";
+}
 
 int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                    uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, uint32_t* /*scratch*/, hipStream_t stream) {
@@ -386,13 +394,16 @@ int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout
   CPIR_TRY(check_layout(L));
   if (q_slot_offset + L.num_slots > q_len) return CPIR_ERR_SHARD_RANGE;  // the shard's slots must lie inside the query
   if (reinterpret_cast<uintptr_t>(dtc) % 16 != 0) return CPIR_ERR_INVALID_ARGUMENT;
-  if (L.words_per_row_padded / L.chunk_words > 0xffffffffull) return CPIR_ERR_INVALID_ARGUMENT;
 
   Tuning t;
   {
     std::lock_guard<std::mutex> lk(g_tuning_mu);
     t = g_tuning;
   }
+  if (L.packing == CPIR_PACK_PLANAR)  // the matrix-core path (respond_planar.hip)
+    return launch_respond_planar(dev, dtc, L, q, q_len, q_slot_offset, batch, passes, r, stream, t.planar_blocks_per_cu, t.nontemporal != 0,
+                                 t.xcd_split != 0, t.interleave_passes);
+  if (L.words_per_row_padded / L.chunk_words > 0xffffffffull) return CPIR_ERR_INVALID_ARGUMENT;
   Picked k;
   if (batch == 1) k = pick_kernel<1>(L, t.rows_per_unit, t.nontemporal);
   else if (batch == 2) k = pick_kernel<2>(L, t.rows_per_unit, t.nontemporal);

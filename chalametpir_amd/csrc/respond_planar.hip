@@ -1,0 +1,324 @@
+// respond_planar.hip -- the online hot loop on the i8 matrix cores, for the planar packing (CPIR_PACK_PLANAR).
+//
+// Same contraction as respond.hip (reference chalametpir_common/src/matrix.rs:328-485):
+//
+//   r[c] = sum_{n < N} q[n] *wrap f(c, n)      (u32, wrap-around)
+//
+// u32 wrap-around products are not an MFMA type, but the sum splits exactly into signed-byte products, which are
+// (v_mfma_i32_16x16x64_i8; its i32 accumulators wrap, scripts/mfma_i8_probe.hip):
+//
+//   q[n]   = sum_{i<4} 2^(8i) * (qs_i[n] + 128)          qs_i = byte i of q[n], XOR 0x80, read as a signed byte
+//   f(c,n) = ls + 128 + 256 * h                          ls = low byte of f, XOR 0x80, signed;  h = f >> 8  (0 .. 2^(b-8) - 1)
+//
+//   sum_n q f = sum_i 2^(8i) * [ sum_n qs_i * ls  +  256 * sum_n qs_i * h ]      <- two MFMAs per 64 slots x 16 columns
+//             + 128 * sum_n (q[n] - 0x80808080)                                  <- per query, same for every column
+//             + 0x80808080 * sum_n f(c,n)                                        <- per column, stored behind the tiles
+//
+// all mod 2^32.  The matrix cores do the 1.1 * 10^9 products per query that cost the VALU kernel ~65 us of issue time; what is
+// left for the VALU is turning the high bit planes into bytes (two VOP2 ops per 4 fields) and gathering the query bytes.
+// The A operand rows are (query, byte): 16 rows = up to 4 queries answered by ONE stream of the database.
+//
+// Roofline: HBM read, exactly b bits per field (1.6 % fewer bytes than dense64 at b = 9, 15.6 % fewer than the reference packing).
+//
+//   * work unit of a block = 4 column tiles (64 columns, one per wave) x one super-tile step (512 slots); the step's A fragments
+//     (8 KiB) are built once per block from q (L2 / Infinity Cache hits; each wave gathers two of the eight k-blocks), shared
+//     through double-buffered LDS and read back just in time, one ds_read_b128 per MFMA pair;
+//   * a wave's tile step is 8 + HB fully coalesced 1 KiB wave-loads (`nt`), issued one step ahead of the MFMAs that consume them;
+//   * persistent grid, units split evenly over the blocks, one barrier per step; the slot axis is first split 8 ways by
+//     blockIdx % 8 as in respond.hip so that an XCD's L2 holds one eighth of q;
+//   * the accumulator tile has the column on the lane and (query, byte) in the register index, so the recombination
+//     sum_i 2^(8i) (lo_i + 256 hi_i) is lane-local; one u32 atomicAdd per (wave, query, column) and tile group.
+#include "cpir_internal.hpp"
+
+namespace cpir {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kM = 4;  // column tiles per work unit = waves per block
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct PlanarArgs {
+  const uint32_t* dtc;
+  const uint32_t* q;
+  uint32_t* r;
+  uint64_t q_len;          // entries in each query
+  uint64_t q_slot_offset;  // first global slot held by this DtC
+  uint64_t num_slots;      // slots held by this DtC (N of the shard)
+  uint32_t num_cols;       // C
+  uint32_t col_tiles;      // rows_padded / 16
+  uint32_t tile_groups;    // ceil(col_tiles / kM)
+  uint32_t ks_total;       // super-tile steps along the slots: ceil(N / 512)
+  uint32_t nx;             // slot-axis split by blockIdx % nx (8 or 1)
+  uint32_t q_per_pass;     // queries answered per pass (1..4): rows 4*i .. 4*i+3 of the A operand belong to query i
+  uint32_t passes;         // independent passes over the database in this launch
+  uint32_t q_scalar;       // q not 16-byte loadable -> guarded scalar loads everywhere
+};
+
+template <bool NT>
+__device__ __forceinline__ uint4 load16(const uint4* p) {
+  if constexpr (NT) {
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+  } else {
+    return *p;
+  }
+}
+
+__device__ __forceinline__ v4i as_v4i(const uint4& u) { return v4i{(int)u.x, (int)u.y, (int)u.z, (int)u.w}; }
+
+// byte `limb` of four consecutive query words -> one dword (k order = word order); sel01 = limb | (4 + limb) << 8
+__device__ __forceinline__ uint32_t gather_limb(uint32_t x, uint32_t y, uint32_t z, uint32_t w, uint32_t sel01) {
+  const uint32_t p01 = __builtin_amdgcn_perm(y, x, sel01);  // byte 0 = x.byte[limb], byte 1 = y.byte[limb]
+  const uint32_t p23 = __builtin_amdgcn_perm(w, z, sel01);
+  return __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+}
+
+__device__ __forceinline__ uint32_t comp(const uint4& u, int i) { return i == 0 ? u.x : (i == 1 ? u.y : (i == 2 ? u.z : u.w)); }
+
+// One step of a block: wave w multiplies column tile 4*tg + w by the step's A fragments (shared through LDS), with the loads of
+// its NEXT tile and the block's next A fragments issued first.  P = parity of the step (register / LDS double buffering).
+template <int HB, bool NT>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(HB <= 1 ? 4 : 3, HB <= 1 ? 4 : 3))) respond_planar_kernel(const PlanarArgs a) {
+  constexpr int NL = 8 + HB;     // 16-byte loads per lane and tile step
+  constexpr int ST16 = NL * 64;  // uint4 per super-tile
+  __shared__ uint4 abuf[2][8][64];  // A fragments of a step: [parity][k-block][lane]
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const uint32_t cl = lane & 15;   // B / C operand: column inside the tile;  A operand: row = 4 * query + byte
+  const uint32_t grp = lane >> 4;  // A / B operand: 16-slot group inside a k-block;  C operand: query (rows 4*grp .. 4*grp+3)
+
+  // ---- static partition of the (tile group, step) units over the BLOCKS of the persistent grid (block-uniform) -------
+  const uint32_t nx = a.nx;
+  const uint32_t xcd = blockIdx.x % nx;
+  const uint32_t j = blockIdx.x / nx;
+  const uint32_t nb = gridDim.x / nx;  // host guarantees gridDim.x % nx == 0
+  const uint32_t kb0 = (uint32_t)(((uint64_t)a.ks_total * xcd) / nx);
+  const uint32_t ke0 = (uint32_t)(((uint64_t)a.ks_total * (xcd + 1)) / nx);
+  const uint32_t span = ke0 - kb0;
+  if (span == 0) return;
+  const uint64_t units = (uint64_t)a.tile_groups * span;
+  const uint64_t ub = units * j / nb, ue = units * (j + 1) / nb;
+  if (ub == ue) return;
+  const uint32_t tg0 = (uint32_t)(ub / span), ks0 = kb0 + (uint32_t)(ub % span);
+  const uint64_t cnt = ue - ub, total = cnt * a.passes;  // steps of this block: the passes laid end to end
+
+  const uint32_t nq = a.q_per_pass;
+  const bool arow = cl < 4 * nq;
+  const uint32_t qi = arow ? (cl >> 2) : 0, limb = cl & 3;
+  const uint32_t sel01 = limb | ((4 + limb) << 8);
+  const uint4* const tiles = reinterpret_cast<const uint4*>(a.dtc);
+
+  // (tile group, step, pass) of the current step and of the next one
+  uint32_t tg = tg0, ks = ks0, pass = 0;
+  uint64_t in_pass = 0;  // steps done in the current pass
+
+  // A fragments of (ks_, pass_) -> abuf[par]: wave w builds k-blocks 2w and 2w+1
+  auto build_a = [&](uint32_t ks_, uint32_t pass_, int par) {
+    const uint64_t slot0 = (uint64_t)ks_ * CPIR_PLANAR_SLOTS_PER_TILE;  // local to this DtC
+    const bool guarded = a.q_scalar || slot0 + CPIR_PLANAR_SLOTS_PER_TILE > a.num_slots ||
+                         a.q_slot_offset + slot0 + CPIR_PLANAR_SLOTS_PER_TILE > a.q_len;  // block-uniform
+    const uint32_t* qrow = a.q + ((uint64_t)pass_ * nq + qi) * a.q_len + a.q_slot_offset;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int kb = 2 * wave + h;
+      const uint64_t base = slot0 + kb * 64 + grp * 16;
+      uint4 f = make_uint4(0, 0, 0, 0);
+      if (arow) {
+        uint32_t o[4];
+        if (!guarded) {
+          const uint4* src = reinterpret_cast<const uint4*>(qrow + base);
+#pragma unroll
+          for (int d = 0; d < 4; d++) {
+            const uint4 t = src[d];
+            o[d] = gather_limb(t.x, t.y, t.z, t.w, sel01) ^ 0x80808080u;
+          }
+        } else {
+          // slots past the end of the shard or of the query take part with qs = 0 (byte 0x00), exactly as
+          // planar_init_kernel counts them
+#pragma unroll
+          for (int d = 0; d < 4; d++) {
+            uint32_t w[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              const uint64_t n = base + d * 4 + e;
+              const bool ok = n < a.num_slots && a.q_slot_offset + n < a.q_len;
+              w[e] = ok ? (qrow[n] ^ 0x80808080u) : 0u;
+            }
+            o[d] = gather_limb(w[0], w[1], w[2], w[3], sel01);
+          }
+        }
+        f = make_uint4(o[0], o[1], o[2], o[3]);
+      }
+      abuf[par][kb][lane] = f;
+    }
+  };
+
+  v4i acc_lo = v4i{0, 0, 0, 0}, acc_hi = v4i{0, 0, 0, 0};
+  uint4 b0[NL], b1[NL];
+
+  auto load_tile = [&](uint4(&dst)[NL], uint32_t tg_, uint32_t ks_) {
+    const uint32_t T = tg_ * kM + wave;
+    if (T < a.col_tiles) {  // wave-uniform
+      const uint4* p = tiles + ((uint64_t)T * a.ks_total + ks_) * ST16 + lane;
+#pragma unroll
+      for (int i = 0; i < NL; i++) dst[i] = load16<NT>(p + i * 64);
+    }
+  };
+
+  auto flush = [&](uint32_t tg_, uint32_t pass_) {
+    const uint32_t T = tg_ * kM + wave;
+    if (T < a.col_tiles) {
+      uint32_t v = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) v += ((uint32_t)acc_lo[i] + ((uint32_t)acc_hi[i] << 8)) << (8 * i);
+      const uint32_t col = T * 16 + cl;
+      if (grp < nq && col < a.num_cols) atomicAdd(a.r + ((uint64_t)pass_ * nq + grp) * a.num_cols + col, v);
+    }
+    acc_lo = v4i{0, 0, 0, 0}, acc_hi = v4i{0, 0, 0, 0};
+  };
+
+  auto step = [&](uint4(&cur)[NL], uint4(&nxt)[NL], int par, bool last) {
+    // where the next step is
+    uint32_t tg_n = tg, ks_n = ks + 1, pass_n = pass;
+    const bool pass_end = (in_pass + 1 == cnt);
+    if (pass_end) tg_n = tg0, ks_n = ks0, pass_n = pass + 1;
+    else if (ks_n == ke0) ks_n = kb0, tg_n = tg + 1;
+    if (!last) {
+      load_tile(nxt, tg_n, ks_n);
+      build_a(ks_n, pass_n, par ^ 1);
+    }
+    if (tg * kM + wave < a.col_tiles) {
+#pragma unroll
+      for (int kb = 0; kb < 8; kb++) {
+        const uint4 au = abuf[par][kb][lane];
+        const v4i af = as_v4i(au);
+        acc_lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, as_v4i(cur[kb]), acc_lo, 0, 0, 0);
+        v4i hb;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+          uint32_t x = 0;
+#pragma unroll
+          for (int p = 0; p < HB; p++) x += ((comp(cur[8 + p], kb >> 1) >> (4 * (kb & 1) + d)) & 0x01010101u) << p;
+          hb[d] = (int)x;
+        }
+        acc_hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, hb, acc_hi, 0, 0, 0);
+      }
+    }
+    if (pass_end || tg_n != tg) flush(tg, pass);
+    __syncthreads();  // A fragments of the next step are in LDS; everybody is done with this step's
+    tg = tg_n, ks = ks_n, pass = pass_n;
+    in_pass = pass_end ? 0 : in_pass + 1;
+  };
+
+  // prologue: first tile and first A fragments
+  load_tile(b0, tg0, ks0);
+  build_a(ks0, 0, 0);
+  __syncthreads();
+  uint64_t i = 0;
+  for (; i + 2 <= total; i += 2) {
+    step(b0, b1, 0, false);
+    step(b1, b0, 1, i + 2 == total);
+  }
+  if (i < total) step(b0, b1, 0, true);
+}
+
+// r[q][c] += 128 * sum_n (q[n] - 0x80808080) over this block's slice of the valid slots, and (slice 0 only) += 0x80808080 * colsum[c]:
+// the two correction terms of the signed-byte split (top of the file).  r was zeroed on the stream before; all updates are u32
+// atomic adds, so their order against the main kernel's does not matter.
+__global__ void __launch_bounds__(kThreads) planar_init_kernel(const uint32_t* __restrict__ q, uint64_t q_len, uint64_t q_slot_offset,
+                                                                uint64_t num_slots, const uint32_t* __restrict__ colsum,
+                                                                uint32_t num_cols, uint32_t* __restrict__ r, uint32_t split) {
+  __shared__ uint32_t sm[kThreads / 64];
+  const uint32_t qi = blockIdx.x / split, s = blockIdx.x % split;
+  const uint64_t room = q_len > q_slot_offset ? q_len - q_slot_offset : 0;
+  const uint64_t nvalid = num_slots < room ? num_slots : room;
+  const uint64_t lo = nvalid * s / split, hi = nvalid * (s + 1) / split;
+  const uint32_t* src = q + (uint64_t)qi * q_len + q_slot_offset;
+  uint32_t sum = 0;
+#pragma unroll 8
+  for (uint64_t n = lo + threadIdx.x; n < hi; n += kThreads) sum += src[n];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  sum = sm[0] + sm[1] + sm[2] + sm[3];
+  const uint32_t k = 128u * sum - 0x40404000u * (uint32_t)(hi - lo);  // 128 * 0x80808080 = 0x40404000 mod 2^32
+  for (uint32_t c = threadIdx.x; c < num_cols; c += kThreads) {
+    const uint32_t v = k + (s == 0 ? 0x80808080u * colsum[c] : 0u);
+    atomicAdd(r + (uint64_t)qi * num_cols + c, v);
+  }
+}
+
+using KernelFn = void (*)(const PlanarArgs);
+
+KernelFn pick(uint32_t hb, bool nt) {
+  switch (hb) {
+    case 1: return nt ? respond_planar_kernel<1, true> : respond_planar_kernel<1, false>;
+    case 2: return nt ? respond_planar_kernel<2, true> : respond_planar_kernel<2, false>;
+    case 3: return nt ? respond_planar_kernel<3, true> : respond_planar_kernel<3, false>;
+    case 4: return nt ? respond_planar_kernel<4, true> : respond_planar_kernel<4, false>;
+    case 5: return nt ? respond_planar_kernel<5, true> : respond_planar_kernel<5, false>;
+    case 6: return nt ? respond_planar_kernel<6, true> : respond_planar_kernel<6, false>;
+    default: return nullptr;
+  }
+}
+
+}  // namespace
+
+int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
+                          uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, int blocks_per_cu,
+                          bool nontemporal, bool xcd_split, int /*interleave*/) {
+  // shape invariants the kernel relies on (layout already checked by the caller)
+  if (L.packing != CPIR_PACK_PLANAR || batch == 0 || batch > 4 || passes == 0) return CPIR_ERR_INVALID_ARGUMENT;
+  const uint32_t hb = planar_hi_planes(L.mat_elem_bit_len);
+  KernelFn fn = pick(hb, nontemporal);
+  if (!fn || L.chunk_words != (8 + hb) * 256 || L.rows_padded % 16 != 0) return CPIR_ERR_INVALID_ARGUMENT;
+  const uint64_t ks_total = (L.num_slots + CPIR_PLANAR_SLOTS_PER_TILE - 1) / CPIR_PLANAR_SLOTS_PER_TILE;
+  if (ks_total > 0xffffffffull || ks_total * (L.chunk_words / 16) != L.words_per_row_padded) return CPIR_ERR_INVALID_ARGUMENT;
+
+  PlanarArgs a;
+  a.dtc = dtc;
+  a.q = q;
+  a.r = r;
+  a.q_len = q_len;
+  a.q_slot_offset = q_slot_offset;
+  a.num_slots = L.num_slots;
+  a.num_cols = L.num_cols;
+  a.col_tiles = L.rows_padded / 16;
+  a.tile_groups = (a.col_tiles + kM - 1) / kM;
+  a.ks_total = (uint32_t)ks_total;
+  a.q_per_pass = batch;
+  a.passes = passes;
+  a.q_scalar = (reinterpret_cast<uintptr_t>(q) % 16 != 0 || q_slot_offset % 4 != 0 || (batch * passes > 1 && q_len % 4 != 0)) ? 1u : 0u;
+
+  int bpc = blocks_per_cu;
+  if (bpc == 0) {
+    int occ = 0;
+    CPIR_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(fn), kThreads, 0));
+    bpc = occ < 1 ? 1 : (occ > 8 ? 8 : occ);
+  }
+  const uint64_t units = (uint64_t)a.tile_groups * a.ks_total;
+  uint64_t grid = (uint64_t)dev->num_cus * (uint64_t)bpc;
+  a.nx = (xcd_split && a.ks_total >= 8 && grid % 8 == 0) ? 8u : 1u;
+  const uint64_t blocks_needed = (units + kThreads / 64 - 1) / (kThreads / 64);
+  if (grid > blocks_needed) {
+    grid = blocks_needed;
+    if (a.nx == 8) grid = (grid / 8) * 8;
+    if (grid == 0) grid = 1, a.nx = 1;
+  }
+
+  const uint32_t nq = batch * passes;
+  CPIR_HIP_TRY(hipMemsetAsync(r, 0, (size_t)nq * L.num_cols * sizeof(uint32_t), stream));
+  const uint32_t* colsum = dtc + (uint64_t)L.rows_padded * L.words_per_row_padded;
+  const uint32_t split = 16;
+  hipLaunchKernelGGL(planar_init_kernel, dim3(nq * split), dim3(kThreads), 0, stream, q, q_len, q_slot_offset, L.num_slots, colsum,
+                     L.num_cols, r, split);
+  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(kThreads), 0, stream, a);
+  CPIR_HIP_TRY(hipGetLastError());
+  return CPIR_OK;
+}
+
+}  // namespace cpir

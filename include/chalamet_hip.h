@@ -122,12 +122,24 @@ int cpir_op_mat_x_mat(cpir_device* dev, const uint32_t* A, uint64_t lda, const u
  *                       m = L*512 + 2t + e  <->  p = 4t + 2L + e  (t < 256, L,e in {0,1}): lane t of a workgroup then reads
  *                       two fully coalesced 16-byte pieces per row and, per field plane j, ONE aligned 16-byte piece of q.
  *
- * Either way rows are stored row-major with the row stride padded to whole chunks (zero words) and the row count padded to
+ *  CPIR_PACK_PLANAR     exactly b bits per field, laid out as operands of the i8 matrix cores (v_mfma_i32_16x16x64_i8), offered
+ *                       for b >= 9: a field is split into its low byte and (b - 8) one-bit planes.  The unit is a super-tile of
+ *                       16 columns x 512 slots = 8 k-blocks of 64 slots: 8 x 1 KiB of low bytes (k-block kb, lane l = 16*g + c holds,
+ *                       in byte j of its 16 bytes, (f XOR 0x80) & 0xFF of column c, slot 64*kb + 16*g + j -- the B operand of one
+ *                       MFMA as it stands) followed by 1 KiB per bit plane p (lane l holds 4 dwords; dword w, bit 8*jj + 4*s + d is
+ *                       bit 8+p of the field at slot 64*(2w+s) + 16*g + 4*d + jj).  Super-tiles are stored column-tile major, then
+ *                       along the slots; after them one u32 per padded column holds the wrap-around sum of that column's fields
+ *                       (a correction term of the signed-byte arithmetic, see respond_planar.hip).  chunk_words = u32 words of one
+ *                       super-tile, slots_per_chunk = 512, words_per_row_padded = u32 words spent per column, fields_per_word = 0.
+ *
+ * For the first two packings rows are stored row-major with the row stride padded to whole chunks (zero words) and the row count padded to
  * CPIR_DTC_ROW_ALIGN (zero rows), so every 16-byte load is aligned and no kernel has a ragged tail.  The packing is private to
  * the device: cpir_op_dtc_import / _export and cpir_server_from_compressed / _export_compressed convert from / to the
  * reference's C x ceil(N/cf) matrix bit-exactly. */
 #define CPIR_PACK_REFERENCE 0u
 #define CPIR_PACK_DENSE64 1u
+#define CPIR_PACK_PLANAR 2u
+#define CPIR_PLANAR_SLOTS_PER_TILE 512u
 typedef struct cpir_dtc_layout {
   uint64_t num_slots;            /* N: filter slots = rows of D = decompressed columns of D^T (server.rs:66) */
   uint32_t num_cols;             /* C: columns of D = rows of D^T = response length */
@@ -137,7 +149,7 @@ typedef struct cpir_dtc_layout {
   uint64_t words_per_row_padded; /* device row stride in u32 words, multiple of chunk_words */
   uint32_t rows_padded;          /* >= C, multiple of CPIR_DTC_ROW_ALIGN */
   uint64_t total_words;          /* rows_padded * words_per_row_padded (u32 words of device memory) */
-  uint32_t packing;              /* CPIR_PACK_REFERENCE or CPIR_PACK_DENSE64 */
+  uint32_t packing;              /* CPIR_PACK_REFERENCE, CPIR_PACK_DENSE64 or CPIR_PACK_PLANAR */
   uint32_t fields_per_word;      /* cf (per u32) for the reference packing, K (per u64) for dense64 */
   uint32_t chunk_words;          /* u32 words of one row per chunk: 1024 (reference) or 2048 (dense64) */
   uint64_t slots_per_chunk;      /* cf*1024 or K*1024: shard boundaries must be multiples of this */
@@ -148,7 +160,7 @@ typedef struct cpir_dtc_layout {
 /* Default layout for a database shape: dense64 where it is offered (b in {7, 9, 11, 12}: denser than the reference packing
  * and within the kernels' register budget), the reference packing otherwise; cpir_tuning_set("layout.dense", 0) forces the reference packing process-wide. */
 int cpir_dtc_layout_for(uint64_t num_slots, uint32_t num_cols, uint32_t mat_elem_bit_len, cpir_dtc_layout* out);
-/* Explicit packing choice (CPIR_ERR_INVALID_ARGUMENT if dense64 is not offered for b). */
+/* Explicit packing choice (CPIR_ERR_INVALID_ARGUMENT if that packing is not offered for b). */
 int cpir_dtc_layout_for_packing(uint64_t num_slots, uint32_t num_cols, uint32_t mat_elem_bit_len, uint32_t packing,
                                 cpir_dtc_layout* out);
 
@@ -190,8 +202,9 @@ int cpir_op_synth_fill(cpir_device* dev, uint32_t* out, uint64_t count, uint64_t
  *   "respond.rows_per_unit" in {4, 8, 16}, "respond.nontemporal" {0,1}, "respond.blocks_per_cu" 0..8 (0 = occupancy API),
  *   "respond.xcd_split" {0,1}, "respond.batch_fusion" {0,1} (0: every query of a batch call streams the database on its
  *   own, i.e. a batch call is only a cheaper way to enqueue independent responds), "respond.interleave_passes" {-1,0,1}
- *   (order in which one launch walks its passes; -1 = by shard size), "layout.dense" {0,1} (default packing
- *   chosen by cpir_dtc_layout_for and therefore by every cpir_server_* constructor).
+ *   (order in which one launch walks its passes; -1 = by shard size), "layout.dense" {0,1} and "layout.planar" {0,1}
+ *   (default packing chosen by cpir_dtc_layout_for and therefore by every cpir_server_* constructor: planar where it is
+ *   offered and enabled, else dense64 where offered and enabled, else the reference packing).
  * Process-wide; results are bit-identical for every setting. */
 int cpir_tuning_set(const char* key, int value);
 /* Name of the dominant kernel last launched by cpir_op_respond for this layout (for matching rocprof traces). */

@@ -10,6 +10,7 @@ the 1.5 GB packed database is read exactly once, at the right slot, with wrap-ar
   * exact 64-bit reference sums computed by torch from the UNPACKED matrix (independent of packing, kernel and oracle),
   * shard partials sum to the whole (the multi-GPU exchange step),
   * fused batches equal single responds,
+  * all three packings (reference words, dense64, planar = the matrix-core path) answer identically,
   * the hint obeys  respond(w^T A) = w^T hint  for random w (a Freivalds check of all 1774 x 940 x 1 179 648 MACs),
   * README byte sizes of the reference (hint 6 670 248 B, query 4 718 600 B, response 3 768 B).
 """
@@ -19,6 +20,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 N_KEYS, ARITY, VALUE_BYTES = 1 << 20, 3, 1024
+PACKINGS = ["reference", "dense64", "planar"]
 SEED_D = 0xD
 SEED_MU = bytes(range(32))
 
@@ -44,11 +46,13 @@ def full(native, device, orc):
     f.D = torch.empty((f.N, f.C), dtype=torch.int32, device="cuda")
     device.synth_fill(f.D, f.N * f.C, SEED_D, mask=f.mask, stream=f.stream)
     f.servers = {}
-    for name, dense in (("reference", 0), ("dense64", 1)):
+    for name, dense, planar in (("reference", 0, 0), ("dense64", 1, 0), ("planar", 1, 1)):
         cp.tuning_set("layout.dense", dense)
+        cp.tuning_set("layout.planar", planar)
         f.servers[name] = cp.Server.from_device_matrix(f.D, f.N, f.C, f.b, device=device, stream=f.stream)
     cp.tuning_set("layout.dense", 1)
-    assert f.servers["reference"].layout.packing == 0 and f.servers["dense64"].layout.packing == 1
+    cp.tuning_set("layout.planar", 0)
+    assert [f.servers[k].layout.packing for k in ("reference", "dense64", "planar")] == [0, 1, 2]
     torch.cuda.synchronize()
     yield f
     for s in f.servers.values():
@@ -86,7 +90,7 @@ def exact_reference_response(f, q_dev):
     return (acc & 0xFFFFFFFF).cpu().numpy().astype(np.uint32)
 
 
-@pytest.mark.parametrize("packing", ["reference", "dense64"])
+@pytest.mark.parametrize("packing", PACKINGS)
 def test_unit_queries_read_back_database_rows(packing, full, device, orc):
     import torch
 
@@ -104,7 +108,7 @@ def test_unit_queries_read_back_database_rows(packing, full, device, orc):
         assert np.array_equal(respond(f, srv, q), want), n
 
 
-@pytest.mark.parametrize("packing", ["reference", "dense64"])
+@pytest.mark.parametrize("packing", PACKINGS)
 def test_random_and_all_ones_queries_match_exact_64bit_sums(packing, full, device):
     import torch
 
@@ -119,7 +123,7 @@ def test_random_and_all_ones_queries_match_exact_64bit_sums(packing, full, devic
     assert np.array_equal(respond(f, srv, top), (0 - col_sums.astype(np.int64)).astype(np.uint32))
 
 
-@pytest.mark.parametrize("packing", ["reference", "dense64"])
+@pytest.mark.parametrize("packing", PACKINGS)
 def test_respond_is_linear_mod_2_32(packing, full, device):
     f, srv = full, full.servers[packing]
     q1, q2 = synth_query(f, device, 0x2001), synth_query(f, device, 0x2002)
@@ -133,6 +137,7 @@ def test_both_packings_and_the_oracle_agree_on_a_full_size_query(full, device, o
     dtc = f.servers["dense64"].export_compressed()
     assert dtc.shape == (940, 393216)
     assert np.array_equal(dtc, f.servers["reference"].export_compressed())
+    assert np.array_equal(dtc, f.servers["planar"].export_compressed())
     # spot-check the packed words against the generator: row c, word w holds slots 3w..3w+2 in 10-bit lanes (matrix.rs:131-147)
     rng = np.random.default_rng(9)
     for c, w in zip(rng.integers(0, f.C, size=64), rng.integers(0, dtc.shape[1], size=64)):
@@ -177,7 +182,7 @@ def test_shard_partials_sum_to_the_whole(world, full, device):
     assert np.array_equal(total.cpu().numpy().view(np.uint32), want)
 
 
-@pytest.mark.parametrize("packing", ["reference", "dense64"])
+@pytest.mark.parametrize("packing", PACKINGS)
 def test_batches_equal_single_responds(packing, full, device):
     import torch
 

@@ -13,15 +13,17 @@ from _cases import ALL_BITS, cf_of, random_db_matrix, random_query, unwire, wire
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["reference-packing", "dense64-where-offered"])
+@pytest.fixture(autouse=True, params=["reference-packing", "dense64-where-offered", "planar-where-offered"])
 def packing(request, native):
     """every test of this module runs once with the reference packing forced and once with the default (dense64 for
     b in {7, 9, 11, 12}); results must be bit-identical either way"""
     import chalametpir_amd as cp
 
     cp.tuning_set("layout.dense", 0 if request.param.startswith("reference") else 1)
+    cp.tuning_set("layout.planar", 1 if request.param.startswith("planar") else 0)
     yield request.param
     cp.tuning_set("layout.dense", 1)
+    cp.tuning_set("layout.planar", 0)
 
 
 def make_server(cp, orc, device, rng, N, C, b):

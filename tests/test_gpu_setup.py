@@ -8,13 +8,15 @@ from _cases import ALL_BITS, cf_of, random_db_matrix, random_query, unwire, wire
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["reference-packing", "dense64-where-offered"])
+@pytest.fixture(autouse=True, params=["reference-packing", "dense64-where-offered", "planar-where-offered"])
 def packing(request, native):
     import chalametpir_amd as cp
 
     cp.tuning_set("layout.dense", 0 if request.param.startswith("reference") else 1)
+    cp.tuning_set("layout.planar", 1 if request.param.startswith("planar") else 0)
     yield request.param
     cp.tuning_set("layout.dense", 1)
+    cp.tuning_set("layout.planar", 0)
 
 
 def _dev(a):
@@ -47,6 +49,10 @@ def test_transpose_compress_matches_oracle(b, orc, device):
         flag = torch.zeros(1, dtype=torch.int32, device="cuda")
         device.transpose_compress(_dev(D), L, dtc, or_of_entries=flag, stream=torch.cuda.current_stream())
         torch.cuda.synchronize()
+        assert int(_host(flag)[0]) == int(np.bitwise_or.reduce(D, axis=None))
+        if L.packing == 2:  # planar: low bytes XOR 0x80 + bit planes in MFMA operand order, then the column sums
+            check_planar_image(_host(dtc), L, D, b)
+            continue
         img = _host(dtc).reshape(L.rows_padded, L.words_per_row_padded)
         assert not img[C:].any()  # padded rows are zero
         if L.packing == 0:  # reference packing: the device image IS the reference matrix plus zero padding
@@ -62,7 +68,35 @@ def test_transpose_compress_matches_oracle(b, orc, device):
             got = (img64[:C][:, (chunk * 1024 + m).astype(np.int64)] >> (j * b).astype(np.uint64)) & np.uint64((1 << b) - 1)
             assert np.array_equal(got.astype(np.uint32), (D & ((1 << b) - 1)).T)
             assert int(np.count_nonzero(img64[:C])) <= N * C  # nothing but fields: unused positions and top bits stay zero
-        assert int(_host(flag)[0]) == int(np.bitwise_or.reduce(D, axis=None))
+
+
+def check_planar_image(words, L, D, b):
+    """decode the planar device image (layout documented at cpir_dtc_layout in include/chalamet_hip.h) with numpy, independently of
+    the library's own export kernel: every (slot, column) incl. padding, and the per-column field sums behind the tiles"""
+    N, C = D.shape
+    hb = b - 8
+    ks_total = -(-N // 512)
+    tile_bytes = (8 + hb) * 1024
+    assert (L.chunk_words, L.slots_per_chunk, L.words_per_row_padded) == (tile_bytes // 4, 512, ks_total * (8 + hb) * 16)
+    assert L.total_words == L.rows_padded * L.words_per_row_padded + L.rows_padded
+    n_tiles_words = L.rows_padded * L.words_per_row_padded
+    raw = words[:n_tiles_words].view(np.uint8)
+    n = np.arange(ks_total * 512, dtype=np.int64)[:, None]
+    c = np.arange(L.rows_padded, dtype=np.int64)[None, :]
+    T, cl = c >> 4, c & 15
+    ks, s = n >> 9, n & 511
+    kb, g, j = s >> 6, (s >> 4) & 3, s & 15
+    lane = g * 16 + cl
+    tile0 = (T * ks_total + ks) * tile_bytes
+    f = (raw[tile0 + kb * 1024 + lane * 16 + j] ^ 0x80).astype(np.uint32)
+    for p in range(hb):
+        off = tile0 + 8192 + p * 1024 + lane * 16 + (kb >> 1) * 4
+        word = sum(raw[off + i].astype(np.uint32) << (8 * i) for i in range(4))
+        f |= ((word >> (8 * (j & 3) + 4 * (kb & 1) + (j >> 2)).astype(np.uint32)) & 1) << (8 + p)
+    want = np.zeros((ks_total * 512, L.rows_padded), dtype=np.uint32)
+    want[:N, :C] = D & ((1 << b) - 1)
+    assert np.array_equal(f, want)  # fields where they belong, zero fields in every padding slot and padding column
+    assert np.array_equal(words[n_tiles_words:], want.sum(axis=0, dtype=np.uint64).astype(np.uint32))
 
 
 def test_compress_then_decompress_round_trip(orc, device):
