@@ -302,10 +302,10 @@ def main() -> int:
         torch.cuda.synchronize()
         fused_us = e0.elapsed_time(e1) * 1e3 / (n_fused_steps * qps_step)
         result["batched_respond"] = {
-            "queries_per_pass": 4,
+            "queries_per_pass": 8 if full_layout.packing == 2 else 4,
             "queries_per_sec": round(1e6 / fused_us, 1),
             "us_per_query": round(fused_us, 2),
-            "note": "cpir_server_respond_batch_device with batch fusion: 4 queries share one stream of the packed DB; same results bit for bit",
+            "note": "cpir_server_respond_batch_device with batch fusion: the queries of a pass share one stream of the packed DB; same results bit for bit",
         }
         cp.tuning_set("respond.batch_fusion", 0)
     # the C-ABI host path a Rust caller uses: query bytes on the host -> pinned copy -> H2D -> kernel -> D2H -> bytes

@@ -470,6 +470,18 @@ static int respond_batched(const Device* dev, const uint32_t* dtc, const cpir_dt
     return CPIR_OK;
   }
   uint32_t done = 0;
+  if (L.packing == CPIR_PACK_PLANAR) {
+    // the matrix-core kernel takes any 1..8 queries per pass: passes of 8, then one pass for the rest
+    const uint32_t W8 = CPIR_PLANAR_MAX_QUERIES_PER_PASS;
+    if (batch >= W8) {
+      CPIR_TRY(launch_respond(dev, dtc, L, q, q_len, q_slot_offset, W8, batch / W8, r, scratch, stream));
+      done = batch / W8 * W8;
+    }
+    if (done < batch)
+      CPIR_TRY(launch_respond(dev, dtc, L, q + (uint64_t)done * q_len, q_len, q_slot_offset, batch - done, 1,
+                              r + (uint64_t)done * L.num_cols, scratch, stream));
+    return CPIR_OK;
+  }
   for (uint32_t width : {4u, 2u, 1u}) {
     const uint32_t passes = (batch - done) / width;
     if (passes == 0) continue;

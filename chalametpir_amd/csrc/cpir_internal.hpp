@@ -68,7 +68,8 @@ uint64_t respond_scratch_words(const cpir_dtc_layout& L, uint32_t batch);
 int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                    uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, uint32_t* scratch, hipStream_t stream);
 const char* respond_kernel_name(const cpir_dtc_layout& L);
-// respond_planar.hip (CPIR_PACK_PLANAR: the MFMA path); same contract as launch_respond
+// respond_planar.hip (CPIR_PACK_PLANAR: the MFMA path); same contract as launch_respond, batch up to CPIR_PLANAR_MAX_QUERIES_PER_PASS
+constexpr uint32_t CPIR_PLANAR_MAX_QUERIES_PER_PASS = 8;
 int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                           uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, int blocks_per_cu,
                           bool nontemporal, bool xcd_split, int interleave);
