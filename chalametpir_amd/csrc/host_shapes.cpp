@@ -79,7 +79,7 @@ uint32_t planar_hi_planes(uint32_t b) {
 }
 
 static std::atomic<int> g_default_dense{1};
-static std::atomic<int> g_default_planar{0};
+static std::atomic<int> g_default_planar{1};
 void set_default_dense(bool on) { g_default_dense.store(on ? 1 : 0); }
 void set_default_planar(bool on) { g_default_planar.store(on ? 1 : 0); }
 

@@ -54,6 +54,7 @@ struct PlanarArgs {
   uint32_t q_per_pass;     // queries answered per pass (1..8): rows 4*i .. 4*i+3 of A row set i / 4 belong to query i
   uint32_t passes;         // independent passes over the database in this launch
   uint32_t q_scalar;       // q not 16-byte loadable -> guarded scalar loads everywhere
+  uint32_t interleave;     // order of the passes of one launch (see the kernel)
 };
 
 template <bool NT>
@@ -102,10 +103,26 @@ respond_planar_kernel(const PlanarArgs a) {
   const uint32_t span = ke0 - kb0;
   if (span == 0) return;
   const uint64_t units = (uint64_t)a.tile_groups * span;
-  const uint64_t ub = units * j / nb, ue = units * (j + 1) / nb;
-  if (ub == ue) return;
-  const uint32_t tg0 = (uint32_t)(ub / span), ks0 = kb0 + (uint32_t)(ub % span);
-  const uint64_t cnt = ue - ub, total = cnt * a.passes;  // steps of this block: the passes laid end to end
+  // Two orders of the passes of one launch (same arithmetic; as respond.hip):
+  //   slice order:       a block keeps its slice [sb, se) of the units and walks it once per pass;
+  //   interleaved order: the passes are laid end to end and the whole (pass, unit) space is split evenly, so different blocks
+  //                      stream the same tiles for different queries at about the same time (pays when the shard fits the
+  //                      256 MiB Infinity Cache).
+  uint64_t sb, se, u0, total;  // a pass covers units [sb, se) for this block; it starts at unit u0 of pass pass0 and does `total` steps
+  uint32_t pass0;
+  if (a.interleave) {
+    const uint64_t all = units * a.passes;
+    const uint64_t ib = all * j / nb, ie = all * (j + 1) / nb;
+    sb = 0, se = units, total = ie - ib;
+    pass0 = (uint32_t)(ib / units), u0 = ib % units;
+  } else {
+    sb = units * j / nb, se = units * (j + 1) / nb;
+    total = (se - sb) * a.passes;
+    pass0 = 0, u0 = sb;
+  }
+  if (total == 0) return;
+  const uint32_t tgs = (uint32_t)(sb / span), kss = kb0 + (uint32_t)(sb % span);  // where a pass starts for this block
+  const uint32_t tg0 = (uint32_t)(u0 / span), ks0 = kb0 + (uint32_t)(u0 % span);  // where this block starts
 
   const uint32_t nq = a.q_per_pass;
   bool arow[NS];     // does this lane's A row of set s belong to a query?
@@ -120,8 +137,8 @@ respond_planar_kernel(const PlanarArgs a) {
   const uint4* const tiles = reinterpret_cast<const uint4*>(a.dtc);
 
   // (tile group, step, pass) of the current step and of the next one
-  uint32_t tg = tg0, ks = ks0, pass = 0;
-  uint64_t in_pass = 0;  // steps done in the current pass
+  uint32_t tg = tg0, ks = ks0, pass = pass0;
+  uint64_t u = u0;  // unit inside the pass
 
   // ---- A fragments of a step -> abuf[par]: wave w builds k-blocks 2w and 2w+1 ---------------------------------------------
   // Split in two so that the (L2-hit) query loads are ISSUED before the step's database loads and CONSUMED after the MFMAs of the
@@ -219,8 +236,8 @@ respond_planar_kernel(const PlanarArgs a) {
   auto step = [&](uint4(&cur)[NL], uint4(&nxt)[NL], int par, bool last) {
     // where the next step is
     uint32_t tg_n = tg, ks_n = ks + 1, pass_n = pass;
-    const bool pass_end = (in_pass + 1 == cnt);
-    if (pass_end) tg_n = tg0, ks_n = ks0, pass_n = pass + 1;
+    const bool pass_end = (u + 1 == se);
+    if (pass_end) tg_n = tgs, ks_n = kss, pass_n = pass + 1;
     else if (ks_n == ke0) ks_n = kb0, tg_n = tg + 1;
     uint4 raw[NS][2][4];
     const bool g_n = guarded_step(ks_n);
@@ -252,15 +269,15 @@ respond_planar_kernel(const PlanarArgs a) {
       if (!g_n) a_finish(raw, par ^ 1);
       else a_guarded(ks_n, pass_n, par ^ 1);
     }
-    if (pass_end || tg_n != tg) flush(tg, pass);
+    if (pass_end || tg_n != tg || last) flush(tg, pass);
     __syncthreads();  // A fragments of the next step are in LDS; everybody is done with this step's
     tg = tg_n, ks = ks_n, pass = pass_n;
-    in_pass = pass_end ? 0 : in_pass + 1;
+    u = pass_end ? sb : u + 1;
   };
 
   // prologue: first tile and first A fragments
   load_tile(b0, tg0, ks0);
-  a_guarded(ks0, 0, 0);
+  a_guarded(ks0, pass0, 0);
   __syncthreads();
   uint64_t i = 0;
   for (; i + 2 <= total; i += 2) {
@@ -318,11 +335,18 @@ KernelFn pick(uint32_t hb, uint32_t batch, bool nt) { return batch <= 4 ? pick_h
 
 int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                           uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, int blocks_per_cu,
-                          bool nontemporal, bool xcd_split, int /*interleave*/) {
+                          bool nontemporal, bool xcd_split, int interleave) {
   // shape invariants the kernel relies on (layout already checked by the caller)
   if (L.packing != CPIR_PACK_PLANAR || batch == 0 || batch > CPIR_PLANAR_MAX_QUERIES_PER_PASS || passes == 0) return CPIR_ERR_INVALID_ARGUMENT;
   const uint32_t hb = planar_hi_planes(L.mat_elem_bit_len);
-  KernelFn fn = pick(hb, batch, nontemporal);
+  // order of the passes: interleaved where the shard is small enough for concurrent passes to share its bytes on die (same rule
+  // as respond.hip), slice order for HBM-sized streams.  Measured on MI355X, us per query, one query per pass, 32 passes:
+  //   1/8 of the 2^20-key DB (157 MB): slice+nt 24.6, interleaved+nt 16.9, interleaved+cached loads 12.6
+  //   1/2 (629 MB): 95.7 / 74.1 / 51.7;  whole (1.26 GB): 186.5 / 154.6 / 107.2 -- above the HBM roof, i.e. on-die reuse
+  const bool inter = passes > 1 && (interleave == 1 || (interleave < 0 && L.total_words * 4 <= (960ull << 20)));
+  // `nt` loads keep a once-per-query stream out of the caches; passes that are meant to share bytes on die use plain loads
+  const bool nt = nontemporal && !inter;
+  KernelFn fn = pick(hb, batch, nt);
   if (!fn || L.chunk_words != (8 + hb) * 256 || L.rows_padded % 16 != 0) return CPIR_ERR_INVALID_ARGUMENT;
   const uint64_t ks_total = (L.num_slots + CPIR_PLANAR_SLOTS_PER_TILE - 1) / CPIR_PLANAR_SLOTS_PER_TILE;
   if (ks_total > 0xffffffffull || ks_total * (L.chunk_words / 16) != L.words_per_row_padded) return CPIR_ERR_INVALID_ARGUMENT;
@@ -340,10 +364,13 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
   a.ks_total = (uint32_t)ks_total;
   a.q_per_pass = batch;
   a.passes = passes;
+  a.interleave = inter ? 1u : 0u;
   a.q_scalar = (reinterpret_cast<uintptr_t>(q) % 16 != 0 || q_slot_offset % 4 != 0 || (batch * passes > 1 && q_len % 4 != 0)) ? 1u : 0u;
 
-  // measured on MI355X at 2^20 keys: 2 resident blocks per CU 188.7 us per query, 3 blocks 192.9, 1 block 273
-  const int bpc = blocks_per_cu > 0 ? blocks_per_cu : 2;
+  // resident blocks per CU, measured on MI355X at 2^20 keys: streaming (slice order) 2 blocks 188.7 us per query, 3 blocks 192.9,
+  // 1 block 273; sharing passes (interleaved) 3 blocks 107 vs 2 blocks 118.  The two-row-set kernel fits 2 blocks per CU.
+  int bpc = blocks_per_cu > 0 ? blocks_per_cu : (inter ? 3 : 2);
+  if (batch > 4 && bpc > 2) bpc = 2;
   const uint64_t units = (uint64_t)a.tile_groups * a.ks_total;
   uint64_t grid = (uint64_t)dev->num_cus * (uint64_t)bpc;
   a.nx = (xcd_split && a.ks_total >= 8 && grid % 8 == 0) ? 8u : 1u;

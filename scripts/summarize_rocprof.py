@@ -33,6 +33,49 @@ def counters(root):
     return out
 
 
+def is_respond(name):
+    """the dominant online kernel: respond_kernel<...> (VALU path) or respond_planar_kernel<...> (matrix-core path)"""
+    return "respond_kernel" in name or "respond_planar_kernel" in name
+
+
+def traffic_record(root, summary, tag):
+    """profiles/respond_traffic.json: HBM bytes per pass from the two counter passes, with the guide's gfx950 correction
+    (FETCH_SIZE counts 64 B per 128 B request of a 16 B/lane coalesced stream -> x2; WRITE_SIZE as is), next to the byte
+    counts the bench run under the profiler reports for the same launch"""
+    r = summary.get("respond", {})
+    if "FETCH_SIZE_mean_raw" not in r:
+        return None
+    try:
+        with open(os.path.join(root, "fetch_bench.json")) as fh:
+            bench = json.loads(fh.read().strip().splitlines()[-1])
+    except (OSError, ValueError, IndexError):
+        return None
+    roof = bench["roofline"]
+    passes = roof["passes_per_launch"]
+    traffic = (2 * r["FETCH_SIZE_mean_raw"] + r.get("WRITE_SIZE_mean_raw", 0.0)) * 1024 / passes
+    algo = roof["bytes_per_launch"] / passes
+    layout = roof["moved_bytes_per_launch"] / passes
+    return {
+        "kernel": r.get("name", ""),
+        "workload": bench["config"]["workload"],
+        "packing": roof["packing"].split(" ")[0],
+        "pass_order": roof.get("pass_order", ""),
+        "dispatches": r.get("FETCH_SIZE_dispatches"),
+        "passes_per_launch": passes,
+        "FETCH_SIZE_mean_KiB_per_launch": r["FETCH_SIZE_mean_raw"],
+        "WRITE_SIZE_mean_KiB_per_launch": r.get("WRITE_SIZE_mean_raw"),
+        "traffic_bytes_per_pass": traffic,
+        "algorithmic_bytes_per_pass": algo,
+        "layout_bytes_per_pass": layout,
+        "traffic_over_algorithmic": traffic / algo,
+        "traffic_over_layout_bytes": traffic / layout,
+        "correction": "gfx950: FETCH_SIZE counts 64 B per 128 B request for 16 B/lane coalesced streaming reads -> x2 "
+                      "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE taken as is",
+        "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), scripts/profile_gpu.sh {tag}; "
+                  f"one launch = {passes} passes (queries)",
+    }
+
+
 def main():
     root, tag = sys.argv[1], sys.argv[2]
     summary = {"tag": tag, "kernels": [], "respond": {}}
@@ -48,12 +91,13 @@ def main():
         pct = r.get("Percentage", "")
         print(f"{calls:7d} calls  avg {avg / 1e3:10.2f} us  total {tot / 1e6:10.3f} ms  {pct:>7}%  {name[:110]}")
         summary["kernels"].append({"name": name, "calls": calls, "avg_us": avg / 1e3, "total_ms": tot / 1e6})
-        if "respond_kernel" in name and "avg_us" not in summary["respond"]:
+        if is_respond(name) and "avg_us" not in summary["respond"]:
             summary["respond"].update({"name": name, "calls": calls, "avg_us": avg / 1e3})
     for label, sub, ctr in (("fetch", "pmc_fetch", "FETCH_SIZE"), ("write", "pmc_write", "WRITE_SIZE")):
         c = counters(os.path.join(root, sub))
+        want = summary["respond"].get("name")  # the instantiation that dominates the kernel trace (the headline launches)
         for k, d in c.items():
-            if "respond_kernel" in k and ctr in d:
+            if is_respond(k) and ctr in d and (want is None or k == want):
                 vals = d[ctr]
                 mean = sum(vals) / len(vals)
                 # FETCH_SIZE / WRITE_SIZE are reported in KiB-like units of 1024 B by rocprofv3's derived metric
@@ -70,6 +114,12 @@ def main():
             avg, tot = float(r.get("AverageNs", 0) or 0), float(r.get("TotalDurationNs", 0) or 0)
             print(f"{calls:7d} calls  avg {avg / 1e3:10.2f} us  total {tot / 1e6:10.3f} ms  {name[:110]}")
             summary["setup_kernels"].append({"name": name, "calls": calls, "avg_us": avg / 1e3, "total_ms": tot / 1e6})
+    tr = traffic_record(root, summary, tag)
+    if tr:
+        print(f"-- HBM traffic per pass: {tr['traffic_bytes_per_pass'] / 1e9:.4f} GB = {tr['traffic_over_algorithmic']:.3f} x algorithmic, "
+              f"{tr['traffic_over_layout_bytes']:.3f} x the bytes of the resident layout")
+        with open(os.path.join(root, "respond_traffic.json"), "w") as fh:
+            json.dump(tr, fh, indent=1)
     with open(os.path.join(root, "summary.json"), "w") as fh:
         json.dump(summary, fh, indent=1)
 

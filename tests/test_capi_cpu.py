@@ -64,16 +64,27 @@ def test_baseline_config_shapes(native):
         assert cp.find_encoded_db_matrix_element_bit_length(n) == b
         assert cp.filter_shape(arity, n)[2] == N
         assert cp.encoded_num_cols(vb, b) == Cc
-        L = cp.dtc_layout_for(N, Cc, b)
-        assert L.words_per_row == -(-N // 3) and L.words_per_row_padded % L.chunk_words == 0 and L.rows_padded % 16 == 0
-        assert L.total_words == L.rows_padded * L.words_per_row_padded  # 64-bit: cfg 4/5 exceed 2^32 elements
         ref = cp.dtc_layout_for(N, Cc, b, packing=0)
         assert (ref.packing, ref.fields_per_word, ref.chunk_words) == (0, 3, 1024)
+        assert ref.words_per_row == -(-N // 3) and ref.words_per_row_padded % ref.chunk_words == 0 and ref.rows_padded % 16 == 0
+        assert ref.total_words == ref.rows_padded * ref.words_per_row_padded  # 64-bit: cfg 4/5 exceed 2^32 elements
+        # default: planar (exactly b bits per field + one u32 column sum per padded column) for every b >= 9
+        L = cp.dtc_layout_for(N, Cc, b)
+        ks = -(-N // 512)
+        assert (L.packing, L.slots_per_chunk, L.chunk_words, L.words_per_row) == (2, 512, b * 256, -(-N // 3))
+        assert L.rows_padded % 16 == 0 and L.words_per_row_padded == ks * b * 16
+        assert L.total_words == L.rows_padded * L.words_per_row_padded + L.rows_padded
+        assert abs(L.total_words / ref.total_words - b / (32 / 3)) < 0.03  # b bits per field against 32/3 (padding differs)
+        cp.tuning_set("layout.planar", 0)
+        try:
+            D = cp.dtc_layout_for(N, Cc, b)
+        finally:
+            cp.tuning_set("layout.planar", 1)
         if b == 9:  # dense64: 7 fields per u64 -> 6/7 of the reference packing's bytes
-            assert (L.packing, L.fields_per_word, L.slots_per_chunk) == (1, 7, 7168)
-            assert 0.85 < L.total_words / ref.total_words < 0.87
+            assert (D.packing, D.fields_per_word, D.slots_per_chunk) == (1, 7, 7168)
+            assert 0.85 < D.total_words / ref.total_words < 0.87
         else:  # b = 10: 6 fields per u64 either way, the reference packing stays
-            assert L.packing == 0
+            assert D.packing == 0
 
 
 def test_layout_invariants(native):
@@ -85,7 +96,17 @@ def test_layout_invariants(native):
         assert (L.num_slots, L.num_cols, L.mat_elem_bit_len, L.compression_factor) == (N, Cc, b, cf)
         assert L.words_per_row == -(-N // cf) <= L.words_per_row_padded < L.words_per_row + 1024
         assert Cc <= L.rows_padded < Cc + 16
-    for b in range(4, 15):  # dense64 is offered exactly for b in {7, 9, 11, 12}
+    for b in range(4, 15):  # planar is offered exactly for b >= 9 and is the default there
+        if b >= 9:
+            P = cp.dtc_layout_for(50_000, 10, b)
+            assert (P.packing, P.chunk_words, P.slots_per_chunk) == (2, b * 256, 512)
+            assert cp.dtc_layout_for(50_000, 10, b, packing=2).total_words == P.total_words
+        else:
+            assert cp.dtc_layout_for(50_000, 10, b).packing != 2
+            with pytest.raises(cp.ChalametPIRError):
+                cp.dtc_layout_for(50_000, 10, b, packing=2)
+    cp.tuning_set("layout.planar", 0)
+    for b in range(4, 15):  # without planar: dense64 is offered exactly for b in {7, 9, 11, 12}
         L = cp.dtc_layout_for(50_000, 10, b)
         if b in (7, 9, 11, 12):
             K = 64 // b
@@ -100,6 +121,7 @@ def test_layout_invariants(native):
         assert cp.dtc_layout_for(50_000, 10, 9).packing == 0
     finally:
         cp.tuning_set("layout.dense", 1)
+        cp.tuning_set("layout.planar", 1)
     for args, variant in (((0, 3, 9), "InvalidMatrixDimension"), ((5, 0, 9), "InvalidMatrixDimension"),
                           ((5, 3, 3), "ImpossibleEncodedDBMatrixElementBitLength")):
         with pytest.raises(cp.ChalametPIRError) as e:

@@ -51,7 +51,7 @@ def full(native, device, orc):
         cp.tuning_set("layout.planar", planar)
         f.servers[name] = cp.Server.from_device_matrix(f.D, f.N, f.C, f.b, device=device, stream=f.stream)
     cp.tuning_set("layout.dense", 1)
-    cp.tuning_set("layout.planar", 0)
+    cp.tuning_set("layout.planar", 1)
     assert [f.servers[k].layout.packing for k in ("reference", "dense64", "planar")] == [0, 1, 2]
     torch.cuda.synchronize()
     yield f

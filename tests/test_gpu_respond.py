@@ -23,7 +23,7 @@ def packing(request, native):
     cp.tuning_set("layout.planar", 1 if request.param.startswith("planar") else 0)
     yield request.param
     cp.tuning_set("layout.dense", 1)
-    cp.tuning_set("layout.planar", 0)
+    cp.tuning_set("layout.planar", 1)
 
 
 def make_server(cp, orc, device, rng, N, C, b):

@@ -16,7 +16,7 @@ def packing(request, native):
     cp.tuning_set("layout.planar", 1 if request.param.startswith("planar") else 0)
     yield request.param
     cp.tuning_set("layout.dense", 1)
-    cp.tuning_set("layout.planar", 0)
+    cp.tuning_set("layout.planar", 1)
 
 
 def _dev(a):
