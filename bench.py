@@ -215,7 +215,9 @@ def main() -> int:
     full_bytes = 4 * C * W + 4 * N + 4 * C
     # ONE respond launch answers the step's queries as that many independent passes over the database (enqueue=batch), or one
     # query (enqueue=python); bytes and duration below are per LAUNCH, as the kernel trace sees them
-    big = sharded.local is not None and int(sharded.local.layout.total_words) * 4 > (2560 << 20)  # one launch per query there
+    limit_mb = next((int(kv.split("=")[1]) for kv in args.tune.split(",") if kv.startswith("respond.multi_pass_limit_mb=")), 2560)
+    big = (sharded.local is not None and full_layout.packing != 2 and
+           int(sharded.local.layout.total_words) * 4 > (limit_mb << 20))  # one launch per query there (VALU kernels only)
     passes_per_launch = qps_step if (args.enqueue == "batch" and not big) else 1
     query_us = kernel_region_ms * 1e3 / n_queries
     launch_us = query_us * passes_per_launch

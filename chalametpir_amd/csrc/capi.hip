@@ -464,7 +464,8 @@ static int respond_batched(const Device* dev, const uint32_t* dtc, const cpir_dt
     // One launch for all passes saves a kernel fill/drain (~10 us) per query, but blocks of a long multi-pass launch drift
     // apart and lose the L2 sharing of q: measured on MI355X it wins up to 1.3 GB per pass (196 vs 204 us) and loses at
     // 5 GB and above (806 vs 770 us), so very large databases get one launch per query.
-    if (L.total_words * 4 <= (2560ull << 20)) return launch_respond(dev, dtc, L, q, q_len, q_slot_offset, 1, batch, r, scratch, stream);
+    // (the matrix-core kernel keeps one launch at every size: 1 440 vs 1 505 us per query at 9.8 GB, 790 vs 799 at 5 GB)
+    if (L.packing == CPIR_PACK_PLANAR || L.total_words * 4 <= respond_multi_pass_limit_bytes()) return launch_respond(dev, dtc, L, q, q_len, q_slot_offset, 1, batch, r, scratch, stream);
     for (uint32_t i = 0; i < batch; i++)
       CPIR_TRY(launch_respond(dev, dtc, L, q + (uint64_t)i * q_len, q_len, q_slot_offset, 1, 1, r + (uint64_t)i * L.num_cols, scratch, stream));
     return CPIR_OK;

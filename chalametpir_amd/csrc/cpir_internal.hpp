@@ -74,6 +74,7 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
                           uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, int blocks_per_cu,
                           bool nontemporal, bool xcd_split, int interleave);
 bool respond_batch_fusion();
+uint64_t respond_multi_pass_limit_bytes();
 
 // pack.hip
 int launch_transpose_compress(const Device* dev, const uint32_t* D, uint64_t ldd, const cpir_dtc_layout& L, uint32_t* dtc,

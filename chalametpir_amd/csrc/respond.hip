@@ -292,7 +292,8 @@ struct Tuning {
   int xcd_split = 1;       // split the chunk axis by blockIdx % 8
   int batch_fusion = 1;    // respond_batch: 1 = passes of 4/2/1 queries share one DB stream, 0 = one pass per query
   int interleave_passes = -1;  // order of the passes of one launch: 0 slice order, 1 interleaved, -1 by shard size
-  int planar_blocks_per_cu = 0;  // the matrix-core kernel (respond_planar.hip): 0 = what the occupancy API allows
+  int planar_blocks_per_cu = 0;  // the matrix-core kernel (respond_planar.hip): 0 = by pass order (2 streaming, 3 sharing)
+  int multi_pass_limit_mb = 2560;  // unfused batches: databases above this size get one launch per query
 };
 Tuning g_tuning;
 std::mutex g_tuning_mu;
@@ -355,6 +356,9 @@ extern "C" int cpir_tuning_set(const char* key, int value) {
   } else if (!strcmp(key, "respond.planar_blocks_per_cu")) {
     if (value < 0 || value > 8) return CPIR_ERR_INVALID_ARGUMENT;
     g_tuning.planar_blocks_per_cu = value;
+  } else if (!strcmp(key, "respond.multi_pass_limit_mb")) {
+    if (value < 0) return CPIR_ERR_INVALID_ARGUMENT;
+    g_tuning.multi_pass_limit_mb = value;
   } else if (!strcmp(key, "respond.xcd_split")) {
     g_tuning.xcd_split = value ? 1 : 0;
   } else if (!strcmp(key, "respond.batch_fusion")) {
@@ -370,6 +374,11 @@ extern "C" int cpir_tuning_set(const char* key, int value) {
     return CPIR_ERR_INVALID_ARGUMENT;
   }
   return CPIR_OK;
+}
+
+uint64_t respond_multi_pass_limit_bytes() {
+  std::lock_guard<std::mutex> lk(g_tuning_mu);
+  return (uint64_t)g_tuning.multi_pass_limit_mb << 20;
 }
 
 bool respond_batch_fusion() {

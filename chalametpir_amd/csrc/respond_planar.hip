@@ -384,7 +384,10 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
   const uint32_t nq = batch * passes;
   CPIR_HIP_TRY(hipMemsetAsync(r, 0, (size_t)nq * L.num_cols * sizeof(uint32_t), stream));
   const uint32_t* colsum = dtc + (uint64_t)L.rows_padded * L.words_per_row_padded;
-  const uint32_t split = 16;
+  // slices of the query per init block: at most 64 Ki slots each (a lone query of a 2^22-key database would otherwise leave
+  // 16 blocks reading 1.2 MB each in front of the main kernel)
+  uint32_t split = (uint32_t)((L.num_slots + 65535) / 65536);
+  split = split < 4 ? 4 : (split > 256 ? 256 : split);
   hipLaunchKernelGGL(planar_init_kernel, dim3(nq * split), dim3(kThreads), 0, stream, q, q_len, q_slot_offset, L.num_slots, colsum,
                      L.num_cols, r, split);
   hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(kThreads), 0, stream, a);
