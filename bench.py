@@ -416,7 +416,8 @@ def host_path_timing(server, q_pool, N, torch):
         "one_caller_queries_per_sec": round(1.0 / lat, 1),
         "eight_callers_queries_per_sec": round(thr, 1),
         "query_bytes": 4 * N,
-        "note": "cpir_server_respond on host buffers: pinned staging + H2D + respond kernel + D2H, per-call pooled stream",
+        "note": "cpir_server_respond on host buffers: pinned staging in 1 MiB pieces + H2D + respond kernel + D2H; concurrent callers are "
+                "coalesced into batched launches on two alternating arenas (one arena's uploads overlap the other's kernel); PCIe-bound",
     }
 
 

@@ -24,13 +24,25 @@ void set_last_hip_error(hipError_t e, const char* what, const char* file, int li
 // ---------------------------------------------------------------------------------------------------------------
 // Server handle
 // ---------------------------------------------------------------------------------------------------------------
-struct RespondSlot {
+// Host callers of respond(&self) are COALESCED: queries that arrive while the device is busy share the next launch
+// (row f3 behind the thread-safe ABI; the reference serves an Arc<Server> from many tokio tasks, examples/server.rs:45,55,85).
+// Two arenas alternate.  A caller takes a seat in the OPEN arena (the first one in becomes its leader), copies its query into the
+// arena's pinned block and enqueues the host->device copy of its seat on the arena's stream -- these copies overlap with the other
+// arena's kernel.  The leader launches one batched respond for all seats as soon as the other arena is not on the device any more
+// (or the arena is full), waits for it, and wakes the followers, who copy their responses out.  A lone caller finds the device
+// idle and launches at once: no added latency.
+struct RespondArena {
   hipStream_t stream = nullptr;
-  uint32_t* q_dev = nullptr;   // total_slots u32
-  uint32_t* r_dev = nullptr;   // C u32
-  uint32_t* q_pinned = nullptr;
-  uint32_t* r_pinned = nullptr;
-  bool busy = false;
+  uint32_t* q_dev = nullptr;     // kSeats x total_slots u32
+  uint32_t* r_dev = nullptr;     // kSeats x C u32
+  uint32_t* q_pinned = nullptr;  // kSeats x total_slots u32
+  uint32_t* r_pinned = nullptr;  // kSeats x C u32
+  // guarded by Server::mu
+  enum State { FREE, OPEN, LAUNCHED, DONE } state = FREE;
+  uint32_t joined = 0;  // seats taken
+  uint32_t staged = 0;  // seats whose query is copied and whose upload is enqueued
+  uint32_t left = 0;    // seats whose caller has taken its response
+  int status = CPIR_OK; // outcome of the launch (shared by every seat)
 };
 
 struct Server {
@@ -42,11 +54,13 @@ struct Server {
   uint64_t total_slots = 0;
   double setup_timings[CPIR_SETUP_TIMING_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
 
-  // pool of per-call resources so respond(&self) is re-entrant (reference: Arc<Server> shared by many tokio tasks)
+  // 4, not the 8 the matrix-core kernel could fuse: a query costs ~170 us of PCIe against 30-50 us of kernel, so what matters is
+  // that one arena's uploads overlap the other arena's kernel -- 8 closed-loop callers then split 4 + 4 instead of convoying
+  static constexpr uint32_t kSeats = 4;
   std::mutex mu;
   std::condition_variable cv;
-  std::vector<std::unique_ptr<RespondSlot>> slots;
-  static constexpr size_t kMaxSlots = 8;
+  RespondArena arena[2];
+  bool arenas_ready = false;
 };
 
 static double now_seconds() {
@@ -62,70 +76,45 @@ static void device_release(Device* d) {
   }
 }
 
-static void slot_destroy(RespondSlot* s) {
-  if (s->stream) (void)hipStreamDestroy(s->stream);
-  if (s->q_dev) (void)hipFree(s->q_dev);
-  if (s->r_dev) (void)hipFree(s->r_dev);
-  if (s->q_pinned) (void)hipHostFree(s->q_pinned);
-  if (s->r_pinned) (void)hipHostFree(s->r_pinned);
+// the arenas live in ONE device block and ONE pinned block (pinning is the slow call: one instead of four per server)
+static void arenas_destroy(Server* srv) {
+  for (RespondArena& a : srv->arena)
+    if (a.stream) (void)hipStreamDestroy(a.stream);
+  if (srv->arena[0].q_dev) (void)hipFree(srv->arena[0].q_dev);
+  if (srv->arena[0].q_pinned) (void)hipHostFree(srv->arena[0].q_pinned);
+  for (RespondArena& a : srv->arena) a = RespondArena{};
+  srv->arenas_ready = false;
 }
 
-static int slot_create(const Server* srv, std::unique_ptr<RespondSlot>* out) {
-  std::unique_ptr<RespondSlot> s(new RespondSlot);
-  auto fail = [&](int st) { slot_destroy(s.get()); return st; };
-  const size_t qb = (size_t)srv->total_slots * 4, rb = (size_t)srv->layout.num_cols * 4;
+// both arenas, on first use (caller holds Server::mu)
+static int arenas_create(Server* srv) {
+  // per arena: kSeats queries, then kSeats responses (query block first: it stays 16-byte aligned)
+  const size_t qw = (size_t)srv->total_slots * Server::kSeats, rw = ((size_t)srv->layout.num_cols * Server::kSeats + 3) / 4 * 4;
+  uint32_t *dev = nullptr, *pin = nullptr;
 #define TRY_(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_last_hip_error(_e, #e, __FILE__, __LINE__); \
-    return fail(_e == hipErrorOutOfMemory ? CPIR_ERR_OUT_OF_DEVICE_MEMORY : CPIR_ERR_HIP); } } while (0)
-  TRY_(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-  TRY_(hipMalloc(&s->q_dev, qb));
-  TRY_(hipMalloc(&s->r_dev, rb));
-  TRY_(hipHostMalloc(&s->q_pinned, qb, hipHostMallocDefault));
-  TRY_(hipHostMalloc(&s->r_pinned, rb, hipHostMallocDefault));
+    if (dev) (void)hipFree(dev); if (pin) (void)hipHostFree(pin); \
+    for (RespondArena& x : srv->arena) { if (x.stream) (void)hipStreamDestroy(x.stream); x = RespondArena{}; } \
+    return _e == hipErrorOutOfMemory ? CPIR_ERR_OUT_OF_DEVICE_MEMORY : CPIR_ERR_HIP; } } while (0)
+  TRY_(hipMalloc(&dev, 2 * (qw + rw) * 4));
+  TRY_(hipHostMalloc(&pin, 2 * (qw + rw) * 4, hipHostMallocDefault));
+  for (int i = 0; i < 2; i++) TRY_(hipStreamCreateWithFlags(&srv->arena[i].stream, hipStreamNonBlocking));
 #undef TRY_
-  *out = std::move(s);
+  for (int i = 0; i < 2; i++) {
+    RespondArena& a = srv->arena[i];
+    a.q_dev = dev + (size_t)i * qw;
+    a.r_dev = dev + 2 * qw + (size_t)i * rw;
+    a.q_pinned = pin + (size_t)i * qw;
+    a.r_pinned = pin + 2 * qw + (size_t)i * rw;
+  }
+  srv->arenas_ready = true;
   return CPIR_OK;
-}
-
-// borrow a slot (creating up to kMaxSlots, then waiting for a free one)
-static int slot_acquire(Server* srv, RespondSlot** out) {
-  std::unique_lock<std::mutex> lk(srv->mu);
-  for (;;) {
-    for (auto& s : srv->slots)
-      if (!s->busy) {
-        s->busy = true;
-        *out = s.get();
-        return CPIR_OK;
-      }
-    if (srv->slots.size() < Server::kMaxSlots) {
-      std::unique_ptr<RespondSlot> s;
-      const int st = slot_create(srv, &s);
-      if (st != CPIR_OK) {
-        if (srv->slots.empty()) return st;  // nothing to wait for
-      } else {
-        s->busy = true;
-        *out = s.get();
-        srv->slots.push_back(std::move(s));
-        return CPIR_OK;
-      }
-    }
-    srv->cv.wait(lk);
-  }
-}
-
-static void slot_release(Server* srv, RespondSlot* s) {
-  {
-    std::lock_guard<std::mutex> lk(srv->mu);
-    s->busy = false;
-  }
-  srv->cv.notify_one();
 }
 
 static void server_destroy(Server* srv) {
   if (!srv) return;
   {
     DeviceGuard g(srv->dev->ordinal);
-    for (auto& s : srv->slots) slot_destroy(s.get());
-    srv->slots.clear();
+    arenas_destroy(srv);
     if (srv->dtc) (void)hipFree(srv->dtc);
   }
   device_release(srv->dev);
@@ -729,21 +718,85 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
   // matrix.rs:329-331: the query must be a 1 x N row vector
   if (!(q_rows == 1 && q_cols == srv->total_slots)) return CPIR_ERR_INCOMPATIBLE_DIM_ROWVEC_X_TRANSPOSED;
   DeviceGuard g(srv->dev->ordinal);
-  RespondSlot* s = nullptr;
-  CPIR_TRY(slot_acquire(srv, &s));
-  struct Release {
-    Server* srv;
-    RespondSlot* s;
-    ~Release() { slot_release(srv, s); }
-  } rel{srv, s};
-  const size_t qb = (size_t)srv->total_slots * 4, rb = (size_t)srv->layout.num_cols * 4;
-  memcpy(s->q_pinned, q, qb);  // the reference copies too (from_bytes .to_vec(), matrix.rs:1001-1007); pinned => true async DMA
-  CPIR_HIP_TRY(hipMemcpyAsync(s->q_dev, s->q_pinned, qb, hipMemcpyHostToDevice, s->stream));
-  CPIR_TRY(launch_respond(srv->dev, srv->dtc, srv->layout, s->q_dev, srv->total_slots, srv->slot_offset, 1, 1, s->r_dev, nullptr, s->stream));
-  CPIR_HIP_TRY(hipMemcpyAsync(s->r_pinned, s->r_dev, rb, hipMemcpyDeviceToHost, s->stream));
-  CPIR_HIP_TRY(hipStreamSynchronize(s->stream));
-  memcpy(r_out, s->r_pinned, rb);
-  return CPIR_OK;
+  const size_t N = (size_t)srv->total_slots, C = srv->layout.num_cols;
+
+  // ---- take a seat ----------------------------------------------------------------------------------------------
+  std::unique_lock<std::mutex> lk(srv->mu);
+  if (!srv->arenas_ready) CPIR_TRY(arenas_create(srv));
+  RespondArena* a = nullptr;
+  for (;;) {
+    for (RespondArena& x : srv->arena)
+      if (x.state == RespondArena::OPEN && x.joined < Server::kSeats) a = &x;
+    if (!a) {
+      const bool any_open = srv->arena[0].state == RespondArena::OPEN || srv->arena[1].state == RespondArena::OPEN;
+      if (!any_open)  // (a full OPEN arena is about to launch: wait for it rather than opening a second one)
+        for (RespondArena& x : srv->arena)
+          if (!a && x.state == RespondArena::FREE) a = &x, x.state = RespondArena::OPEN, x.status = CPIR_OK;
+    }
+    if (a) break;
+    srv->cv.wait(lk);
+  }
+  RespondArena* other = (a == &srv->arena[0]) ? &srv->arena[1] : &srv->arena[0];
+  const uint32_t seat = a->joined++;
+  const bool leader = (seat == 0);
+  lk.unlock();
+
+  // ---- stage the query: pinned copy (the reference copies too: from_bytes .to_vec(), matrix.rs:1001-1007), then its upload ----
+  // in pieces, so that the DMA of one piece runs while the next is being copied into the pinned block
+  hipError_t up = hipSuccess;
+  const size_t piece = (size_t)1 << 18;  // 1 MiB of u32
+  for (size_t o = 0; o < N && up == hipSuccess; o += piece) {
+    const size_t n = (N - o < piece) ? N - o : piece;
+    memcpy(a->q_pinned + seat * N + o, q + o, n * 4);
+    up = hipMemcpyAsync(a->q_dev + seat * N + o, a->q_pinned + seat * N + o, n * 4, hipMemcpyHostToDevice, a->stream);
+  }
+  if (up != hipSuccess) set_last_hip_error(up, "hipMemcpyAsync(query upload)", __FILE__, __LINE__);
+
+  lk.lock();
+  if (up != hipSuccess) a->status = CPIR_ERR_HIP;
+  a->staged++;
+  srv->cv.notify_all();
+  if (leader) {
+    // launch when every seat taken so far is staged AND the device is free of the other arena's launch (or we are full);
+    // callers keep joining until then
+    srv->cv.wait(lk, [&] {
+      return a->staged == a->joined && (other->state != RespondArena::LAUNCHED || a->joined == Server::kSeats);
+    });
+    a->state = RespondArena::LAUNCHED;  // closed: later callers open the other arena
+    srv->cv.notify_all();
+    const uint32_t k = a->joined;
+    int st = a->status;
+    lk.unlock();
+    if (st == CPIR_OK) {
+      st = respond_batched(srv->dev, srv->dtc, srv->layout, a->q_dev, srv->total_slots, srv->slot_offset, k, a->r_dev, nullptr, a->stream);
+      hipError_t e = hipSuccess;
+      if (st == CPIR_OK) e = hipMemcpyAsync(a->r_pinned, a->r_dev, (size_t)k * C * 4, hipMemcpyDeviceToHost, a->stream);
+      const hipError_t e2 = hipStreamSynchronize(a->stream);  // always drain the stream before the arena is reused
+      if (e == hipSuccess) e = e2;
+      if (st == CPIR_OK && e != hipSuccess) {
+        set_last_hip_error(e, "respond launch / download", __FILE__, __LINE__);
+        st = CPIR_ERR_HIP;
+      }
+    } else {
+      (void)hipStreamSynchronize(a->stream);
+    }
+    lk.lock();
+    a->status = st;
+    a->state = RespondArena::DONE;
+    srv->cv.notify_all();
+  } else {
+    srv->cv.wait(lk, [&] { return a->state == RespondArena::DONE; });
+  }
+  const int status = a->status;
+  lk.unlock();
+  if (status == CPIR_OK) memcpy(r_out, a->r_pinned + seat * C, C * 4);
+  lk.lock();
+  if (++a->left == a->joined) {  // last one out frees the arena
+    a->state = RespondArena::FREE;
+    a->joined = a->staged = a->left = 0;
+    srv->cv.notify_all();
+  }
+  return status;
 }
 
 int cpir_server_respond_bytes(const cpir_server* srv, const uint8_t* query, size_t query_len, uint8_t* response, size_t response_cap,

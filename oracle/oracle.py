@@ -111,6 +111,9 @@ def lib():
         _lib.or_encoded_num_cols.argtypes = [C.c_uint64, C.c_uint]
         _lib.or_matrix_num_bytes.restype = C.c_size_t
         _lib.or_matrix_num_bytes.argtypes = [C.c_uint64, C.c_uint64]
+        # OpenMP defaults to one thread per VISIBLE CPU; a GPU box shows 256 of them to a container with a 16-CPU quota, and
+        # 256 spinning threads make every small oracle call cost 0.1 s: start from the CPUs this process may really use
+        _lib.or_set_num_threads(C.c_int(usable_cpus()))
     return _lib
 
 

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# idle OpenMP workers of the oracle must sleep, not spin (a GPU box gives the container a CPU quota far below the CPUs it shows);
+# has to be in the environment before libgomp is loaded
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
