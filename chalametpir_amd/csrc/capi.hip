@@ -335,6 +335,7 @@ const char* cpir_strerror(int status) {
 
 const char* cpir_last_hip_error(void) { return t_last_hip_error; }
 const char* cpir_version(void) { return "chalamet_hip 0.1.0 (gfx950)"; }
+const char* cpir_xof_permutation(void) { return xof_permutation_name(); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // device

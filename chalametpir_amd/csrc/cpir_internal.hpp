@@ -102,6 +102,7 @@ struct TurboShake128 {
   void squeeze(uint8_t* out, size_t len);
 };
 void turboshake128(const uint8_t* msg, size_t len, uint8_t* out, size_t out_len);
+const char* xof_permutation_name();
 
 // host_shapes.cpp
 uint32_t compression_factor(uint32_t b);

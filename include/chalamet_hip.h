@@ -94,6 +94,9 @@ uint64_t cpir_encoded_num_cols(uint64_t max_value_byte_len, uint32_t mat_elem_bi
 /* Matrix::generate_from_seed (matrix.rs:541-558): TurboSHAKE128(seed || 0x1F) squeezed into rows*cols LE u32.
  * Host-side, sequential by construction of the sponge. */
 int cpir_generate_from_seed(uint64_t rows, uint64_t cols, const uint8_t seed[CPIR_SEED_BYTE_LEN], uint32_t* out);
+/* Which Keccak-p[1600,12] implementation this host runs for the XOF ("scalar" or "avx512vl (lane per xmm)"); picked once at
+ * load time from the CPU's features, CPIR_XOF_SCALAR=1 in the environment forces the scalar one. */
+const char* cpir_xof_permutation(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Low-level device operations on caller-owned DEVICE pointers (what gpu_utils::mat_x_mat / mat_transpose and
