@@ -73,6 +73,9 @@ def main() -> int:
     ap.add_argument("--sweep", action="store_true", help="time every respond kernel variant (stderr table) before the run")
     ap.add_argument("--enqueue", default="batch", choices=["batch", "python"],
                     help="how a step's launches are enqueued: one C call for the step (default) or one ctypes call per query")
+    ap.add_argument("--group-shards", type=int, default=0,
+                    help="also time Server::respond on host buffers through an in-process GROUP handle (cpir_server_setup_multi): 0 = one "
+                         "shard per visible device when there are at least two, K = K shards cycled over the visible devices")
     ap.add_argument("--shard-of", type=int, default=0,
                     help="tuning aid: run ONE process on rank 0's shard of a K-way split (no collective); the JSON line then "
                          "describes that shard's kernel only")
@@ -342,6 +345,14 @@ def main() -> int:
     # the C-ABI host path a Rust caller uses: query bytes on the host -> pinned copy -> H2D -> kernel -> D2H -> bytes
     if world == 1 and not args.no_host_path:
         result["respond_host_path"] = host_path_timing(sharded.local, q_pool, N, torch)
+    if world == 1 and not args.no_host_path:
+        n_vis = torch.cuda.device_count()
+        k = args.group_shards or (n_vis if n_vis >= 2 else 0)
+        if k >= 1:
+            try:
+                result["respond_host_path_group"] = group_host_path_timing(cp, torch, device, sharded.local, q_pool, N, C, b, mask, k, n_vis, stream)
+            except Exception as exc:  # noqa: BLE001 -- an optional extra must never take the headline down
+                result["respond_host_path_group"] = {"error": repr(exc)}
     if args.verify:
         drain()
         result["verified_vs_oracle"] = verify(run_step, drain, step_counter, r_step, qps_step, pool, N, C, b, mask, rank, torch)
@@ -419,6 +430,60 @@ def host_path_timing(server, q_pool, N, torch):
         "note": "cpir_server_respond on host buffers: pinned staging in 1 MiB pieces + H2D + respond kernel + D2H; concurrent callers are "
                 "coalesced into batched launches on two alternating arenas (one arena's uploads overlap the other's kernel); PCIe-bound",
     }
+
+
+def group_host_path_timing(cp, torch, device0, single, q_pool, N, C, b, mask, shards, n_vis, stream):
+    """Server::respond on host buffers through a GROUP handle: the database split over the devices of THIS process, every query
+    scattered (device g receives only its slots of q over its own host link), partial responses summed on the host.  Checked
+    against the single-device server on the same database first."""
+    import threading
+
+    D_dev = torch.empty((N, C), dtype=torch.int32, device="cuda")
+    device0.synth_fill(D_dev, N * C, SEED_D, mask=mask, stream=stream)
+    torch.cuda.synchronize()
+    D_host = D_dev.cpu().numpy().view(np.uint32)
+    del D_dev
+    torch.cuda.empty_cache()
+    devs = [device0 if (i % n_vis) == device0.ordinal else cp.Device(i % n_vis) for i in range(shards)]
+    t0 = time.perf_counter()
+    grp, hint = cp.Server.setup_from_matrix(SEED_MU, D_host, b, devices=devs)
+    setup_wall = time.perf_counter() - t0
+    del D_host
+    qs = [q_pool[i].cpu().numpy().view(np.uint32) for i in range(min(16, q_pool.shape[0]))]
+    # same answers as the single-device server the headline ran on (same synthetic database)?
+    same = all(bool(np.array_equal(grp.respond_array(qs[i]), single.respond_array(qs[i]))) for i in range(3))
+    n1 = 48
+    for q in qs[:4]:
+        grp.respond_array(q)
+    t0 = time.perf_counter()
+    for i in range(n1):
+        grp.respond_array(qs[i % len(qs)])
+    lat = (time.perf_counter() - t0) / n1
+    threads, per = 8, 24
+
+    def work(k):
+        for i in range(per):
+            grp.respond_array(qs[(k + i) % len(qs)])
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
+    t0 = time.perf_counter()
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    thr = threads * per / (time.perf_counter() - t0)
+    out = {
+        "shards": grp.group_shards(),
+        "visible_devices": n_vis,
+        "one_caller_us_per_query": round(lat * 1e6, 1),
+        "one_caller_queries_per_sec": round(1.0 / lat, 1),
+        "eight_callers_queries_per_sec": round(thr, 1),
+        "setup_wall_sec": round(setup_wall, 3),
+        "hint_checksum": int(hint.sum(dtype=np.uint64) & 0xFFFFFFFFFFFFFFFF),
+        "responses_equal_single_device": same,
+        "note": "cpir_server_setup_multi + cpir_server_respond: one process, database split along the filter slots over the listed "
+                "devices, query slices scattered over each device's own host link, C-word partial responses summed on the host",
+    }
+    grp.close()
+    return out
 
 
 def sweep(cp, torch, run_step, qps_step):

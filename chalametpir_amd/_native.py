@@ -91,6 +91,12 @@ SIGNATURES = {
     "cpir_server_setup": (C.c_int, [vp, u8p, u32p, u32p, C.c_uint64, C.c_uint32, C.c_uint32, u32p, C.POINTER(vp)]),
     "cpir_server_setup_kv": (C.c_int, [vp, C.c_uint32, u8p, C.POINTER(KvDb), u8p, C.c_uint32, vp, C.c_size_t, C.POINTER(C.c_size_t),
                                        u8p, C.POINTER(vp)]),
+    "cpir_server_setup_multi": (C.c_int, [C.POINTER(vp), C.c_uint32, u8p, u32p, u32p, C.c_uint64, C.c_uint32, C.c_uint32, u32p,
+                                          C.POINTER(vp)]),
+    "cpir_server_setup_kv_multi": (C.c_int, [C.POINTER(vp), C.c_uint32, C.c_uint32, u8p, C.POINTER(KvDb), u8p, C.c_uint32, vp,
+                                             C.c_size_t, C.POINTER(C.c_size_t), u8p, C.POINTER(vp)]),
+    "cpir_server_group_size": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
+    "cpir_server_group_shard": (C.c_int, [vp, C.c_uint32, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "cpir_encode_kv_database": (C.c_int, [C.c_uint32, C.POINTER(KvDb), C.c_uint32, u8p, C.c_uint32, u8p, vp, C.c_uint64,
                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "cpir_setup_kv_shape": (C.c_int, [C.c_uint32, C.POINTER(KvDb), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),

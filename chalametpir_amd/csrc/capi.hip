@@ -61,6 +61,23 @@ struct Server {
   std::condition_variable cv;
   RespondArena arena[2];
   bool arenas_ready = false;
+
+  // ---- group handle (cpir_server_setup_multi): the database is split along the filter slots over several devices of this
+  // process; `shards` then holds one ordinary server per device and this handle owns no packed database itself.  A host query is
+  // SCATTERED: device g receives only q[n_g : n_{g+1}] over its own host link, answers its shard, and the C-word partial
+  // responses are summed on the host (u32 wrap-around: order-independent, bit-identical to one device).
+  std::vector<Server*> shards;
+  struct GroupLane {  // per shard, per call context
+    hipStream_t stream = nullptr;
+    uint32_t *q_dev = nullptr, *r_dev = nullptr, *q_pinned = nullptr, *r_pinned = nullptr;
+  };
+  struct GroupCtx {
+    bool busy = false;
+    std::vector<GroupLane> lanes;
+  };
+  static constexpr int kGroupCtx = 2;  // concurrent callers served at once; further callers wait
+  GroupCtx gctx[kGroupCtx];
+  bool gctx_ready = false;
 };
 
 static double now_seconds() {
@@ -110,8 +127,29 @@ static int arenas_create(Server* srv) {
   return CPIR_OK;
 }
 
+static void server_destroy(Server* srv);
+
+static void group_ctx_destroy(Server* srv) {
+  for (Server::GroupCtx& c : srv->gctx) {
+    for (size_t g = 0; g < c.lanes.size(); g++) {
+      Server::GroupLane& l = c.lanes[g];
+      DeviceGuard dg(srv->shards[g]->dev->ordinal);
+      if (l.stream) (void)hipStreamDestroy(l.stream);
+      if (l.q_dev) (void)hipFree(l.q_dev);  // q_dev and r_dev are one block
+      if (l.q_pinned) (void)hipHostFree(l.q_pinned);  // q_pinned and r_pinned are one block
+    }
+    c.lanes.clear();
+  }
+  srv->gctx_ready = false;
+}
+
 static void server_destroy(Server* srv) {
   if (!srv) return;
+  if (!srv->shards.empty()) {
+    group_ctx_destroy(srv);
+    for (Server* c : srv->shards) server_destroy(c);
+    srv->shards.clear();
+  }
   {
     DeviceGuard g(srv->dev->ordinal);
     arenas_destroy(srv);
@@ -119,6 +157,92 @@ static void server_destroy(Server* srv) {
   }
   device_release(srv->dev);
   delete srv;
+}
+
+// per shard: a stream, a device block (query slice + response) and a pinned block of the same shape, for every call context
+static int group_ctx_create(Server* srv) {
+  const uint32_t C = srv->layout.num_cols;
+  for (Server::GroupCtx& c : srv->gctx) {
+    c.lanes.resize(srv->shards.size());
+    for (size_t g = 0; g < srv->shards.size(); g++) {
+      Server::GroupLane& l = c.lanes[g];
+      const Server* child = srv->shards[g];
+      DeviceGuard dg(child->dev->ordinal);
+      const size_t qw = ((size_t)child->layout.num_slots + 3) / 4 * 4, words = qw + C;
+#define TRY_(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_last_hip_error(_e, #e, __FILE__, __LINE__); group_ctx_destroy(srv); \
+    return _e == hipErrorOutOfMemory ? CPIR_ERR_OUT_OF_DEVICE_MEMORY : CPIR_ERR_HIP; } } while (0)
+      TRY_(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+      TRY_(hipMalloc(&l.q_dev, words * 4));
+      TRY_(hipHostMalloc(&l.q_pinned, words * 4, hipHostMallocDefault));
+#undef TRY_
+      l.r_dev = l.q_dev + qw;
+      l.r_pinned = l.q_pinned + qw;
+    }
+  }
+  srv->gctx_ready = true;
+  return CPIR_OK;
+}
+
+// Server::respond on a group handle: scatter the query slices, one launch per device, sum the partial responses on the host
+static int group_respond(Server* srv, const uint32_t* q, uint32_t* r_out) {
+  const uint32_t C = srv->layout.num_cols;
+  Server::GroupCtx* ctx = nullptr;
+  {
+    std::unique_lock<std::mutex> lk(srv->mu);
+    if (!srv->gctx_ready) CPIR_TRY(group_ctx_create(srv));
+    srv->cv.wait(lk, [&] {
+      for (Server::GroupCtx& c : srv->gctx)
+        if (!c.busy) {
+          ctx = &c;
+          return true;
+        }
+      return false;
+    });
+    ctx->busy = true;
+  }
+  struct Release {
+    Server* srv;
+    Server::GroupCtx* c;
+    ~Release() {
+      {
+        std::lock_guard<std::mutex> lk(srv->mu);
+        c->busy = false;
+      }
+      srv->cv.notify_all();
+    }
+  } rel{srv, ctx};
+  int status = CPIR_OK;
+  size_t enqueued = 0;
+  for (size_t g = 0; g < srv->shards.size() && status == CPIR_OK; g++, enqueued++) {
+    const Server* child = srv->shards[g];
+    Server::GroupLane& l = ctx->lanes[g];
+    DeviceGuard dg(child->dev->ordinal);
+    const size_t n = (size_t)child->layout.num_slots;
+    memcpy(l.q_pinned, q + child->slot_offset, n * 4);
+    hipError_t e = hipMemcpyAsync(l.q_dev, l.q_pinned, n * 4, hipMemcpyHostToDevice, l.stream);
+    // a shard answered from ITS slice of the query is an unsharded respond on a database of its own slots
+    if (e == hipSuccess) status = launch_respond(child->dev, child->dtc, child->layout, l.q_dev, n, 0, 1, 1, l.r_dev, nullptr, l.stream);
+    if (e == hipSuccess && status == CPIR_OK) e = hipMemcpyAsync(l.r_pinned, l.r_dev, (size_t)C * 4, hipMemcpyDeviceToHost, l.stream);
+    if (e != hipSuccess) {
+      set_last_hip_error(e, "group respond: copy", __FILE__, __LINE__);
+      status = CPIR_ERR_HIP;
+    }
+  }
+  for (size_t g = 0; g < enqueued; g++) {  // drain every stream that got work, whatever happened
+    DeviceGuard dg(srv->shards[g]->dev->ordinal);
+    const hipError_t e = hipStreamSynchronize(ctx->lanes[g].stream);
+    if (e != hipSuccess && status == CPIR_OK) {
+      set_last_hip_error(e, "group respond: hipStreamSynchronize", __FILE__, __LINE__);
+      status = CPIR_ERR_HIP;
+    }
+  }
+  if (status != CPIR_OK) return status;
+  memcpy(r_out, ctx->lanes[0].r_pinned, (size_t)C * 4);
+  for (size_t g = 1; g < srv->shards.size(); g++) {
+    const uint32_t* p = ctx->lanes[g].r_pinned;
+    for (uint32_t c = 0; c < C; c++) r_out[c] += p[c];  // u32 wrap-around
+  }
+  return CPIR_OK;
 }
 
 static Server* server_new(Device* dev, const cpir_dtc_layout& L, uint64_t slot_offset, uint64_t total_slots) {
@@ -139,38 +263,52 @@ static Server* server_new(Device* dev, const cpir_dtc_layout& L, uint64_t slot_o
 // A stays resident (8.4 GB at 2^20 keys, 33 GB at 2^22: sized for 288 GB of HBM) so the hint is ONE matmul launch.
 class PublicMatrixUpload {
  public:
-  // col_lo / col_n: keep only columns [col_lo, col_lo + col_n) of A on the device (an N-shard); the sponge still has to
-  // be squeezed for every byte of A, only the upload shrinks
-  PublicMatrixUpload(Device* dev, uint64_t N, uint64_t col_lo = 0, uint64_t col_n = 0)
-      : dev_(dev), N_(N), col_lo_(col_lo), col_n_(col_n ? col_n : N) {}
+  // One target per device: it keeps columns [col_lo, col_lo + col_n) of A (an N-shard; col_n = 0 means all N).  The sponge has
+  // to be squeezed for every byte of A whatever is kept; with several targets ONE expansion feeds every device's slab.
+  struct Target {
+    Device* dev = nullptr;
+    uint64_t col_lo = 0, col_n = 0;
+    uint32_t* A_dev = nullptr;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+  };
+  PublicMatrixUpload(Device* dev, uint64_t N, uint64_t col_lo = 0, uint64_t col_n = 0) : N_(N) { add_target(dev, col_lo, col_n); }
+  explicit PublicMatrixUpload(uint64_t N) : N_(N) {}
+  void add_target(Device* dev, uint64_t col_lo, uint64_t col_n) {
+    Target t;
+    t.dev = dev, t.col_lo = col_lo, t.col_n = col_n ? col_n : N_;
+    targets_.push_back(t);
+  }
   ~PublicMatrixUpload() {
     join();
-    DeviceGuard g(dev_->ordinal);
-    for (int i = 0; i < 2; i++) {
-      if (pinned_[i]) (void)hipHostFree(pinned_[i]);
-      if (ev_[i]) (void)hipEventDestroy(ev_[i]);
+    for (Target& t : targets_) {
+      DeviceGuard g(t.dev->ordinal);
+      for (int i = 0; i < 2; i++)
+        if (t.ev[i]) (void)hipEventDestroy(t.ev[i]);
+      if (t.copy_stream) (void)hipStreamDestroy(t.copy_stream);
+      if (t.A_dev) (void)hipFree(t.A_dev);
     }
-    if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
-    if (A_dev_) (void)hipFree(A_dev_);
+    for (int i = 0; i < 2; i++)
+      if (pinned_[i]) (void)hipHostFree(pinned_[i]);
   }
 
   int start(const uint8_t seed[32], const uint32_t* A_host) {
-    DeviceGuard g(dev_->ordinal);
     const uint64_t rows = CPIR_LWE_DIMENSION;
-    CPIR_HIP_TRY(hipMalloc(&A_dev_, (size_t)rows * col_n_ * 4));
-    CPIR_HIP_TRY(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
-    if (A_host) {  // caller supplied A: plain upload, no XOF
-      CPIR_HIP_TRY(hipMemcpy2DAsync(A_dev_, col_n_ * 4, A_host + col_lo_, N_ * 4, col_n_ * 4, rows, hipMemcpyHostToDevice, copy_stream_));
-      return CPIR_OK;
+    for (Target& t : targets_) {
+      DeviceGuard g(t.dev->ordinal);
+      CPIR_HIP_TRY(hipMalloc(&t.A_dev, (size_t)rows * t.col_n * 4));
+      CPIR_HIP_TRY(hipStreamCreateWithFlags(&t.copy_stream, hipStreamNonBlocking));
+      if (A_host)  // caller supplied A: plain upload, no XOF
+        CPIR_HIP_TRY(hipMemcpy2DAsync(t.A_dev, t.col_n * 4, A_host + t.col_lo, N_ * 4, t.col_n * 4, rows, hipMemcpyHostToDevice, t.copy_stream));
+      else
+        for (int i = 0; i < 2; i++) CPIR_HIP_TRY(hipEventCreateWithFlags(&t.ev[i], hipEventDisableTiming));
     }
+    if (A_host) return CPIR_OK;
     // ~64 MiB staging blocks, whole rows
     rows_per_block_ = (uint64_t)(64ull << 20) / (N_ * 4);
     if (rows_per_block_ < 1) rows_per_block_ = 1;
     if (rows_per_block_ > rows) rows_per_block_ = rows;
-    for (int i = 0; i < 2; i++) {
-      CPIR_HIP_TRY(hipHostMalloc(&pinned_[i], (size_t)rows_per_block_ * N_ * 4, hipHostMallocDefault));
-      CPIR_HIP_TRY(hipEventCreateWithFlags(&ev_[i], hipEventDisableTiming));
-    }
+    for (int i = 0; i < 2; i++) CPIR_HIP_TRY(hipHostMalloc(&pinned_[i], (size_t)rows_per_block_ * N_ * 4, hipHostMallocDefault));
     memcpy(seed_, seed, 32);
     worker_ = std::thread([this] { status_ = run(); });
     return CPIR_OK;
@@ -178,13 +316,15 @@ class PublicMatrixUpload {
 
   double xof_seconds() const { return xof_seconds_; }
 
-  // wait until all of A is in HBM
-  int finish(const uint32_t** A_dev) {
+  // wait until all of A is in HBM (on every target); A_dev receives target `which`'s slab
+  int finish(const uint32_t** A_dev, size_t which = 0) {
     join();
     if (status_ != CPIR_OK) return status_;
-    DeviceGuard g(dev_->ordinal);
-    CPIR_HIP_TRY(hipStreamSynchronize(copy_stream_));
-    *A_dev = A_dev_;
+    for (Target& t : targets_) {
+      DeviceGuard g(t.dev->ordinal);
+      CPIR_HIP_TRY(hipStreamSynchronize(t.copy_stream));
+    }
+    *A_dev = targets_[which].A_dev;
     return CPIR_OK;
   }
 
@@ -193,7 +333,6 @@ class PublicMatrixUpload {
     if (worker_.joinable()) worker_.join();
   }
   int run() {
-    DeviceGuard g(dev_->ordinal);
     TurboShake128 xof;  // matrix.rs:542-544
     xof.absorb(seed_, 32);
     xof.finalize(0x1F);
@@ -202,24 +341,28 @@ class PublicMatrixUpload {
     bool used[2] = {false, false};
     for (uint64_t r0 = 0; r0 < rows; r0 += rows_per_block_, buf ^= 1) {
       const uint64_t rb = (rows - r0 < rows_per_block_) ? rows - r0 : rows_per_block_;
-      if (used[buf]) CPIR_HIP_TRY(hipEventSynchronize(ev_[buf]));  // staging buffer free again?
+      if (used[buf])  // staging buffer free again on every device?
+        for (Target& t : targets_) {
+          DeviceGuard g(t.dev->ordinal);
+          CPIR_HIP_TRY(hipEventSynchronize(t.ev[buf]));
+        }
       const double t0 = now_seconds();
       xof.squeeze(reinterpret_cast<uint8_t*>(pinned_[buf]), (size_t)rb * N_ * 4);  // matrix.rs:546-555: row-major LE u32
       xof_seconds_ += now_seconds() - t0;
-      CPIR_HIP_TRY(hipMemcpy2DAsync(A_dev_ + r0 * col_n_, col_n_ * 4, pinned_[buf] + col_lo_, N_ * 4, col_n_ * 4, rb,
-                                    hipMemcpyHostToDevice, copy_stream_));
-      CPIR_HIP_TRY(hipEventRecord(ev_[buf], copy_stream_));
+      for (Target& t : targets_) {
+        DeviceGuard g(t.dev->ordinal);
+        CPIR_HIP_TRY(hipMemcpy2DAsync(t.A_dev + r0 * t.col_n, t.col_n * 4, pinned_[buf] + t.col_lo, N_ * 4, t.col_n * 4, rb,
+                                      hipMemcpyHostToDevice, t.copy_stream));
+        CPIR_HIP_TRY(hipEventRecord(t.ev[buf], t.copy_stream));
+      }
       used[buf] = true;
     }
     return CPIR_OK;
   }
 
-  Device* dev_;
-  uint64_t N_, col_lo_, col_n_;
-  uint32_t* A_dev_ = nullptr;
+  uint64_t N_;
+  std::vector<Target> targets_;
   uint32_t* pinned_[2] = {nullptr, nullptr};
-  hipEvent_t ev_[2] = {nullptr, nullptr};
-  hipStream_t copy_stream_ = nullptr;
   uint64_t rows_per_block_ = 0;
   uint8_t seed_[32];
   std::thread worker_;
@@ -282,6 +425,116 @@ static int setup_from_host_matrix(Device* dev, PublicMatrixUpload& upA, const ui
   srv->setup_timings[6] = now_seconds() - t0;
 #undef TRY_
   *out = srv;
+  return CPIR_OK;
+}
+
+// slots per shard are multiples of this: no packed word of either layout and no 16-byte query piece straddles two shards
+static uint64_t shard_unit(const cpir_dtc_layout& L) {
+  uint64_t a = L.slots_per_chunk, b = L.compression_factor, x = a, y = b;
+  while (y) {
+    const uint64_t t = x % y;
+    x = y, y = t;
+  }
+  return a / x * b;
+}
+
+// [lo, hi) of shard g of `shards` (same rule as chalametpir_amd.distributed.shard_range); the last shard takes the ragged tail
+static void shard_bounds(uint64_t N, uint64_t unit, size_t g, size_t shards, uint64_t* lo, uint64_t* hi) {
+  const uint64_t units = (N + unit - 1) / unit;
+  const uint64_t a = units * g / shards * unit, b = units * (g + 1) / shards * unit;
+  *lo = a < N ? a : N;
+  *hi = b < N ? b : N;
+}
+
+// how many of `n_dev` devices get a (non-empty) shard
+static size_t group_size(uint64_t N, uint64_t unit, size_t n_dev) {
+  const uint64_t units = (N + unit - 1) / unit;
+  return units < n_dev ? (size_t)units : n_dev;
+}
+
+// The matrix half of setup for a group: every device uploads and packs its rows of D, multiplies its column slab of A (ONE
+// host expansion feeds all slabs: upA has one target per shard) by them, and the partial hints are summed on the host.
+static int setup_group_from_host_matrix(const std::vector<Device*>& devs, PublicMatrixUpload& upA, const uint32_t* D, uint64_t N,
+                                        uint32_t C, uint32_t b, uint32_t* hint_out, Server** out) {
+  cpir_dtc_layout Lfull;
+  CPIR_TRY(dtc_layout_for(N, C, b, &Lfull));
+  const uint64_t unit = shard_unit(Lfull);
+  const size_t G = devs.size();
+  Server* grp = server_new(devs[0], Lfull, 0, N);
+  struct Work {
+    DevBuf D_dev, flag, M_dev;
+    uint32_t ored = 0;
+  };
+  std::vector<Work> work(G);
+  auto fail = [&](int st) { server_destroy(grp); return st; };
+#define TRY_(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_last_hip_error(_e, #e, __FILE__, __LINE__); \
+    return fail(_e == hipErrorOutOfMemory ? CPIR_ERR_OUT_OF_DEVICE_MEMORY : CPIR_ERR_HIP); } } while (0)
+  double t0 = now_seconds();
+  for (size_t g = 0; g < G; g++) {  // enqueue on every device first: uploads and packs of different devices overlap
+    uint64_t lo, hi;
+    shard_bounds(N, unit, g, G, &lo, &hi);
+    cpir_dtc_layout L;
+    int st = dtc_layout_for(hi - lo, C, b, &L);
+    if (st != CPIR_OK) return fail(st);
+    DeviceGuard dg(devs[g]->ordinal);
+    Server* child = server_new(devs[g], L, lo, N);
+    grp->shards.push_back(child);
+    TRY_(hipMalloc(&child->dtc, (size_t)L.total_words * 4));
+    TRY_(hipMalloc(&work[g].D_dev.p, (size_t)(hi - lo) * C * 4));
+    TRY_(hipMalloc(&work[g].flag.p, 4));
+    TRY_(hipMalloc(&work[g].M_dev.p, (size_t)CPIR_LWE_DIMENSION * C * 4));
+    hipStream_t stream = devs[g]->stream;
+    TRY_(hipMemcpyAsync(work[g].D_dev.p, D + lo * C, (size_t)(hi - lo) * C * 4, hipMemcpyHostToDevice, stream));
+    TRY_(hipMemsetAsync(work[g].flag.p, 0, 4, stream));
+    st = launch_transpose_compress(devs[g], (const uint32_t*)work[g].D_dev.p, C, L, child->dtc, (uint32_t*)work[g].flag.p, stream);
+    if (st != CPIR_OK) return fail(st);
+    TRY_(hipMemcpyAsync(&work[g].ored, work[g].flag.p, 4, hipMemcpyDeviceToHost, stream));
+  }
+  uint32_t ored = 0;
+  for (size_t g = 0; g < G; g++) {
+    DeviceGuard dg(devs[g]->ordinal);
+    TRY_(hipStreamSynchronize(devs[g]->stream));
+    ored |= work[g].ored;
+  }
+  grp->setup_timings[2] = now_seconds() - t0;  // D upload + pack, all devices
+  const uint32_t rhs_bits = (ored >> 16) ? 32u : 16u;  // as setup_from_host_matrix
+  t0 = now_seconds();
+  const uint32_t* A_dev0 = nullptr;
+  int st = upA.finish(&A_dev0);
+  if (st != CPIR_OK) return fail(st);
+  grp->setup_timings[4] = now_seconds() - t0;
+  grp->setup_timings[1] = upA.xof_seconds();
+  t0 = now_seconds();
+  const size_t hint_words = (size_t)CPIR_LWE_DIMENSION * C;
+  std::vector<std::vector<uint32_t>> partial(G > 1 ? G - 1 : 0);
+  for (size_t g = 0; g < G; g++) {
+    const Server* child = grp->shards[g];
+    DeviceGuard dg(devs[g]->ordinal);
+    const uint32_t* A_dev = nullptr;
+    st = upA.finish(&A_dev, g);
+    if (st != CPIR_OK) return fail(st);
+    const uint64_t n = child->layout.num_slots;
+    st = launch_mat_x_mat(devs[g], A_dev, n, (const uint32_t*)work[g].D_dev.p, C, (uint32_t*)work[g].M_dev.p, C, CPIR_LWE_DIMENSION, n, C,
+                          rhs_bits, 0, devs[g]->stream);
+    if (st != CPIR_OK) return fail(st);
+    uint32_t* dst = hint_out;
+    if (g > 0) {
+      partial[g - 1].resize(hint_words);
+      dst = partial[g - 1].data();
+    }
+    TRY_(hipMemcpyAsync(dst, work[g].M_dev.p, hint_words * 4, hipMemcpyDeviceToHost, devs[g]->stream));
+  }
+  for (size_t g = 0; g < G; g++) {
+    DeviceGuard dg(devs[g]->ordinal);
+    TRY_(hipStreamSynchronize(devs[g]->stream));
+  }
+  for (size_t g = 1; g < G; g++) {  // hint = sum of the per-shard partial products (u32 wrap-around)
+    const uint32_t* p = partial[g - 1].data();
+    for (size_t i = 0; i < hint_words; i++) hint_out[i] += p[i];
+  }
+  grp->setup_timings[5] = now_seconds() - t0;  // partial matmuls + downloads + host sum
+#undef TRY_
+  *out = grp;
   return CPIR_OK;
 }
 
@@ -518,6 +771,44 @@ int cpir_server_setup(cpir_device* dev, const uint8_t seed_mu[CPIR_SEED_BYTE_LEN
   return CPIR_OK;
 }
 
+// devices -> the Device list a group really uses (no empty shards), with the upload targets of A registered in shard order
+static int group_plan(cpir_device* const* devs, uint32_t n_dev, uint64_t N, uint32_t C, uint32_t b, std::vector<Device*>* use,
+                      PublicMatrixUpload* upA) {
+  if (!devs || n_dev == 0) return CPIR_ERR_INVALID_ARGUMENT;
+  for (uint32_t i = 0; i < n_dev; i++)
+    if (!devs[i]) return CPIR_ERR_INVALID_ARGUMENT;
+  cpir_dtc_layout L;
+  CPIR_TRY(dtc_layout_for(N, C, b, &L));
+  const uint64_t unit = shard_unit(L);
+  const size_t G = group_size(N, unit, n_dev);
+  for (size_t g = 0; g < G; g++) {
+    uint64_t lo, hi;
+    shard_bounds(N, unit, g, G, &lo, &hi);
+    use->push_back(devs[g]);
+    upA->add_target(devs[g], lo, hi - lo);
+  }
+  return CPIR_OK;
+}
+
+int cpir_server_setup_multi(cpir_device* const* devs, uint32_t n_dev, const uint8_t seed_mu[CPIR_SEED_BYTE_LEN], const uint32_t* pub_mat_a,
+                            const uint32_t* D, uint64_t N, uint32_t C, uint32_t b, uint32_t* hint_out, cpir_server** out) {
+  if (!devs || n_dev == 0 || !D || !hint_out || !out || (!seed_mu && !pub_mat_a)) return CPIR_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (N == 0 || C == 0) return CPIR_ERR_INVALID_MATRIX_DIMENSION;
+  if (compression_factor(b) == 0) return CPIR_ERR_IMPOSSIBLE_ELEMENT_BIT_LENGTH;
+  const double t_begin = now_seconds();
+  PublicMatrixUpload upA(N);
+  std::vector<Device*> use;
+  CPIR_TRY(group_plan(devs, n_dev, N, C, b, &use, &upA));
+  static const uint8_t zero_seed[32] = {0};
+  CPIR_TRY(upA.start(seed_mu ? seed_mu : zero_seed, pub_mat_a));
+  Server* srv = nullptr;
+  CPIR_TRY(setup_group_from_host_matrix(use, upA, D, N, C, b, hint_out, &srv));
+  srv->setup_timings[7] = now_seconds() - t_begin;
+  *out = static_cast<cpir_server*>(srv);
+  return CPIR_OK;
+}
+
 int cpir_setup_kv_shape(uint32_t arity, const cpir_kv_db* db, uint32_t* b_out, uint64_t* N, uint32_t* C, size_t* hint_bytes_len) {
   if (!db) return CPIR_ERR_INVALID_ARGUMENT;
   if (arity != 3 && arity != 4) return CPIR_ERR_UNSUPPORTED_ARITY;
@@ -555,10 +846,13 @@ int cpir_encode_kv_database(uint32_t arity, const cpir_kv_db* db, uint32_t b, co
   return CPIR_OK;
 }
 
-int cpir_server_setup_kv(cpir_device* dev, uint32_t arity, const uint8_t seed_mu[CPIR_SEED_BYTE_LEN], const cpir_kv_db* db,
-                         const uint8_t* filter_seed_material, uint32_t max_attempts, uint8_t* hint_bytes_out, size_t hint_bytes_cap,
-                         size_t* hint_bytes_len, uint8_t filter_param_bytes_out[CPIR_FILTER_PARAM_BYTE_LEN], cpir_server** out) {
-  if (!dev || !seed_mu || !db || !hint_bytes_out || !hint_bytes_len || !filter_param_bytes_out || !out) return CPIR_ERR_INVALID_ARGUMENT;
+// Full Server::setup on one device (n_dev == 1, devs[0]) or on a group of devices
+static int setup_kv_common(cpir_device* const* devs, uint32_t n_dev, bool group, uint32_t arity, const uint8_t seed_mu[CPIR_SEED_BYTE_LEN],
+                           const cpir_kv_db* db, const uint8_t* filter_seed_material, uint32_t max_attempts, uint8_t* hint_bytes_out,
+                           size_t hint_bytes_cap, size_t* hint_bytes_len, uint8_t filter_param_bytes_out[CPIR_FILTER_PARAM_BYTE_LEN],
+                           cpir_server** out) {
+  if (!devs || n_dev == 0 || !devs[0] || !seed_mu || !db || !hint_bytes_out || !hint_bytes_len || !filter_param_bytes_out || !out)
+    return CPIR_ERR_INVALID_ARGUMENT;
   *out = nullptr;
   uint32_t b = 0, C = 0;
   uint64_t N = 0;
@@ -571,7 +865,13 @@ int cpir_server_setup_kv(cpir_device* dev, uint32_t arity, const uint8_t seed_mu
   // N is known from the key count alone, so the (sequential, seconds-long) XOF expansion of A starts right away and
   // overlaps the (also sequential) filter construction and row encoding below
   const double t_begin = now_seconds();
-  PublicMatrixUpload upA(dev, N);
+  PublicMatrixUpload upA(N);
+  std::vector<Device*> use;
+  if (group) {
+    CPIR_TRY(group_plan(devs, n_dev, N, C, b, &use, &upA));
+  } else {
+    upA.add_target(devs[0], 0, N);
+  }
   CPIR_TRY(upA.start(seed_mu, nullptr));
 
   Filter filter;
@@ -584,7 +884,9 @@ int cpir_server_setup_kv(cpir_device* dev, uint32_t arity, const uint8_t seed_mu
 
   Server* srv = nullptr;
   // hint_bytes = Matrix::to_bytes(hint): [rows][cols][elems] (matrix.rs:947-971, server.rs:62)
-  CPIR_TRY(setup_from_host_matrix(dev, upA, D.data(), N, C, b, reinterpret_cast<uint32_t*>(hint_bytes_out + 8), &srv));
+  uint32_t* hint = reinterpret_cast<uint32_t*>(hint_bytes_out + 8);
+  if (group) CPIR_TRY(setup_group_from_host_matrix(use, upA, D.data(), N, C, b, hint, &srv));
+  else CPIR_TRY(setup_from_host_matrix(devs[0], upA, D.data(), N, C, b, hint, &srv));
   const uint32_t hr = CPIR_LWE_DIMENSION, hc = C;
   memcpy(hint_bytes_out, &hr, 4);
   memcpy(hint_bytes_out + 4, &hc, 4);
@@ -594,6 +896,26 @@ int cpir_server_setup_kv(cpir_device* dev, uint32_t arity, const uint8_t seed_mu
   srv->setup_timings[7] = now_seconds() - t_begin;
   *out = static_cast<cpir_server*>(srv);
   return CPIR_OK;
+}
+
+int cpir_server_setup_kv(cpir_device* dev, uint32_t arity, const uint8_t seed_mu[CPIR_SEED_BYTE_LEN], const cpir_kv_db* db,
+                         const uint8_t* filter_seed_material, uint32_t max_attempts, uint8_t* hint_bytes_out, size_t hint_bytes_cap,
+                         size_t* hint_bytes_len, uint8_t filter_param_bytes_out[CPIR_FILTER_PARAM_BYTE_LEN], cpir_server** out) {
+  if (!dev) return CPIR_ERR_INVALID_ARGUMENT;
+  cpir_device* one[1] = {dev};
+  return setup_kv_common(one, 1, false, arity, seed_mu, db, filter_seed_material, max_attempts, hint_bytes_out, hint_bytes_cap,
+                         hint_bytes_len, filter_param_bytes_out, out);
+}
+
+int cpir_server_setup_kv_multi(cpir_device* const* devs, uint32_t n_dev, uint32_t arity, const uint8_t seed_mu[CPIR_SEED_BYTE_LEN],
+                               const cpir_kv_db* db, const uint8_t* filter_seed_material, uint32_t max_attempts, uint8_t* hint_bytes_out,
+                               size_t hint_bytes_cap, size_t* hint_bytes_len, uint8_t filter_param_bytes_out[CPIR_FILTER_PARAM_BYTE_LEN],
+                               cpir_server** out) {
+  if (devs)
+    for (uint32_t i = 0; i < n_dev; i++)
+      if (!devs[i]) return CPIR_ERR_INVALID_ARGUMENT;
+  return setup_kv_common(devs, n_dev, true, arity, seed_mu, db, filter_seed_material, max_attempts, hint_bytes_out, hint_bytes_cap,
+                         hint_bytes_len, filter_param_bytes_out, out);
 }
 
 int cpir_hint_partial_device(cpir_device* dev, const uint8_t seed_mu[CPIR_SEED_BYTE_LEN], const uint32_t* pub_mat_a, const uint32_t* D_dev,
@@ -671,6 +993,19 @@ int cpir_server_export_compressed(const cpir_server* srv, uint32_t* compressed_o
   const cpir_dtc_layout& L = srv->layout;
   const uint64_t words = (uint64_t)L.num_cols * L.words_per_row;
   if (out_words < words) return CPIR_ERR_BUFFER_TOO_SMALL;
+  if (!srv->shards.empty()) {
+    // a group: every shard starts at a multiple of cf slots, so its compressed words are a column range of the whole matrix
+    std::vector<uint32_t> part;
+    for (const Server* c : srv->shards) {
+      const cpir_dtc_layout& Lc = c->layout;
+      part.resize((size_t)Lc.num_cols * Lc.words_per_row);
+      CPIR_TRY(cpir_server_export_compressed(static_cast<const cpir_server*>(c), part.data(), part.size()));
+      const uint64_t w0 = c->slot_offset / L.compression_factor;
+      for (uint32_t r = 0; r < L.num_cols; r++)
+        memcpy(compressed_out + (size_t)r * L.words_per_row + w0, part.data() + (size_t)r * Lc.words_per_row, (size_t)Lc.words_per_row * 4);
+    }
+    return CPIR_OK;
+  }
   DeviceGuard g(srv->dev->ordinal);
   DevBuf tmp;
   CPIR_HIP_TRY(hipMalloc(&tmp.p, (size_t)words * 4));
@@ -710,6 +1045,21 @@ int cpir_server_shard(const cpir_server* srv, uint64_t* slot_offset, uint64_t* t
 
 const uint32_t* cpir_server_dtc_device_ptr(const cpir_server* srv) { return srv ? srv->dtc : nullptr; }
 
+int cpir_server_group_size(const cpir_server* srv, uint32_t* shards) {
+  if (!srv || !shards) return CPIR_ERR_INVALID_ARGUMENT;
+  *shards = (uint32_t)srv->shards.size();
+  return CPIR_OK;
+}
+
+int cpir_server_group_shard(const cpir_server* srv, uint32_t index, int* device_ordinal, uint64_t* slot_offset, uint64_t* num_slots) {
+  if (!srv || index >= srv->shards.size()) return CPIR_ERR_INVALID_ARGUMENT;
+  const Server* c = srv->shards[index];
+  if (device_ordinal) *device_ordinal = c->dev->ordinal;
+  if (slot_offset) *slot_offset = c->slot_offset;
+  if (num_slots) *num_slots = c->layout.num_slots;
+  return CPIR_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // server: respond
 // ---------------------------------------------------------------------------------------------------------------
@@ -718,6 +1068,7 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
   Server* srv = const_cast<cpir_server*>(csrv);  // the pool is the only mutable state; it is internally locked
   // matrix.rs:329-331: the query must be a 1 x N row vector
   if (!(q_rows == 1 && q_cols == srv->total_slots)) return CPIR_ERR_INCOMPATIBLE_DIM_ROWVEC_X_TRANSPOSED;
+  if (!srv->shards.empty()) return group_respond(srv, q, r_out);
   DeviceGuard g(srv->dev->ordinal);
   const size_t N = (size_t)srv->total_slots, C = srv->layout.num_cols;
 
@@ -746,8 +1097,10 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
   // in pieces, so that the DMA of one piece runs while the next is being copied into the pinned block
   hipError_t up = hipSuccess;
   const size_t piece = (size_t)1 << 18;  // 1 MiB of u32
-  for (size_t o = 0; o < N && up == hipSuccess; o += piece) {
-    const size_t n = (N - o < piece) ? N - o : piece;
+  // (a shard reads only its own slots of the query: only those are staged and uploaded)
+  const size_t q_end = (size_t)srv->slot_offset + (size_t)srv->layout.num_slots;
+  for (size_t o = (size_t)srv->slot_offset; o < q_end && up == hipSuccess; o += piece) {
+    const size_t n = (q_end - o < piece) ? q_end - o : piece;
     memcpy(a->q_pinned + seat * N + o, q + o, n * 4);
     up = hipMemcpyAsync(a->q_dev + seat * N + o, a->q_pinned + seat * N + o, n * 4, hipMemcpyHostToDevice, a->stream);
   }
@@ -825,7 +1178,7 @@ int cpir_server_respond_bytes(const cpir_server* srv, const uint8_t* query, size
 }
 
 int cpir_server_respond_device(const cpir_server* srv, const uint32_t* q_dev, uint32_t* r_dev, uint32_t* scratch_dev, void* stream) {
-  if (!srv || !q_dev || !r_dev) return CPIR_ERR_INVALID_ARGUMENT;
+  if (!srv || !q_dev || !r_dev || !srv->shards.empty()) return CPIR_ERR_INVALID_ARGUMENT;  // device pointers belong to ONE device
   DeviceGuard g(srv->dev->ordinal);
   return launch_respond(srv->dev, srv->dtc, srv->layout, q_dev, srv->total_slots, srv->slot_offset, 1, 1, r_dev, scratch_dev,
                         pick_stream(srv->dev, stream));
@@ -833,7 +1186,7 @@ int cpir_server_respond_device(const cpir_server* srv, const uint32_t* q_dev, ui
 
 int cpir_server_respond_batch_device(const cpir_server* srv, const uint32_t* q_dev, uint32_t batch, uint32_t* r_dev, uint32_t* scratch_dev,
                                      void* stream) {
-  if (!srv || !q_dev || !r_dev || batch == 0) return CPIR_ERR_INVALID_ARGUMENT;
+  if (!srv || !q_dev || !r_dev || batch == 0 || !srv->shards.empty()) return CPIR_ERR_INVALID_ARGUMENT;
   DeviceGuard g(srv->dev->ordinal);
   return respond_batched(srv->dev, srv->dtc, srv->layout, q_dev, srv->total_slots, srv->slot_offset, batch, r_dev, scratch_dev,
                          pick_stream(srv->dev, stream));

@@ -10,7 +10,7 @@ PyTorch is optional plumbing: tensors are only used to hand device memory / stre
 from __future__ import annotations
 
 import ctypes as C
-from typing import Mapping, Optional, Tuple
+from typing import Mapping, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -47,6 +47,12 @@ def _tensor_ptr(t) -> int:
     if t.element_size() != 4 or not t.is_contiguous():
         raise ValueError("expected a contiguous tensor of 4-byte elements")
     return t.data_ptr()
+
+
+def _device_array(devices: Sequence["Device"]):
+    """cpir_device* const* for the *_multi constructors"""
+    arr = (C.c_void_p * len(devices))(*[d._h for d in devices])
+    return arr
 
 
 def _stream_ptr(stream) -> Optional[int]:
@@ -222,15 +228,16 @@ class Server:
     # ---- construction -------------------------------------------------------------------------------------------------
     @staticmethod
     def setup(seed_mu: bytes, db: Mapping[bytes, bytes], arity: int = 3, *, device: Optional[Device] = None,
-              filter_seed_material: Optional[bytes] = None,
+              devices: Optional[Sequence[Device]] = None, filter_seed_material: Optional[bytes] = None,
               max_attempts: int = SERVER_SETUP_MAX_ATTEMPT_COUNT) -> Tuple["Server", bytes, bytes]:
-        """Server::setup::<ARITY>(seed_mu, db) -> (Server, hint_bytes, filter_param_bytes)   (reference server.rs:47-78 / 103-167)"""
+        """Server::setup::<ARITY>(seed_mu, db) -> (Server, hint_bytes, filter_param_bytes)   (reference server.rs:47-78 / 103-167)
+        `devices`: split the database over several devices of this process (group handle, cpir_server_setup_kv_multi)"""
         lib = _native.load()
         if arity not in (3, 4):
             raise ChalametPIRError(17, lib.cpir_strerror(17).decode())  # const { assert!(ARITY == 3 || ARITY == 4) }, matrix.rs:638
         if len(db) == 0:
             raise ChalametPIRError(8, lib.cpir_strerror(8).decode())  # EmptyKVDatabase, server.rs:48-51
-        return Server._setup_flat(seed_mu, _FlatKvDb(db), arity, device, filter_seed_material, max_attempts)
+        return Server._setup_flat(seed_mu, _FlatKvDb(db), arity, device, filter_seed_material, max_attempts, devices)
 
     @staticmethod
     def setup_flat(seed_mu: bytes, keys, key_off, values, val_off, arity: int = 3, *, device: Optional[Device] = None,
@@ -247,7 +254,7 @@ class Server:
         return Server._setup_flat(seed_mu, flat, arity, device, filter_seed_material, max_attempts)
 
     @staticmethod
-    def _setup_flat(seed_mu, flat, arity, device, filter_seed_material, max_attempts):
+    def _setup_flat(seed_mu, flat, arity, device, filter_seed_material, max_attempts, devices=None):
         lib = _native.load()
         b, N, Cc, need = C.c_uint32(), C.c_uint64(), C.c_uint32(), C.c_size_t()
         _check(lib.cpir_setup_kv_shape(arity, C.byref(flat.c), C.byref(b), C.byref(N), C.byref(Cc), C.byref(need)))
@@ -261,15 +268,20 @@ class Server:
                 raise ValueError("filter_seed_material must hold 32 bytes per attempt")
             seeds = (C.c_uint8 * len(filter_seed_material)).from_buffer_copy(filter_seed_material)
         h = C.c_void_p()
+        if devices:
+            _check(lib.cpir_server_setup_kv_multi(_device_array(devices), len(devices), arity, _seed_arg(seed_mu), C.byref(flat.c), seeds,
+                                                  max_attempts, _ptr(hint), need.value, C.byref(hint_len), fbytes, C.byref(h)))
+            return Server(h, devices[0]), hint.tobytes()[: hint_len.value], bytes(fbytes)
         _check(lib.cpir_server_setup_kv(device._h, arity, _seed_arg(seed_mu), C.byref(flat.c), seeds, max_attempts, _ptr(hint), need.value,
                                         C.byref(hint_len), fbytes, C.byref(h)))
         return Server(h, device), hint.tobytes()[: hint_len.value], bytes(fbytes)
 
     @staticmethod
     def setup_from_matrix(seed_mu: bytes, D: np.ndarray, mat_elem_bit_len: int, *, pub_mat_a: Optional[np.ndarray] = None,
-                          device: Optional[Device] = None) -> Tuple["Server", np.ndarray]:
+                          device: Optional[Device] = None, devices: Optional[Sequence[Device]] = None) -> Tuple["Server", np.ndarray]:
         """The matrix half of Server::setup (reference server.rs:59-67) from an already encoded DB matrix D (N x C).
-        Returns (Server, hint) with hint the 1774 x C matrix whose to_bytes image is `hint_bytes`."""
+        Returns (Server, hint) with hint the 1774 x C matrix whose to_bytes image is `hint_bytes`.
+        `devices`: split the database over several devices of this process (group handle, cpir_server_setup_multi)."""
         lib = _native.load()
         D = _u32_host(D)
         if D.ndim != 2:
@@ -284,6 +296,10 @@ class Server:
                 raise ChalametPIRError(2, lib.cpir_strerror(2).decode())  # IncompatibleDimensionForMatrixMultiplication
             a_ptr = _ptr(pub_mat_a)
         h = C.c_void_p()
+        if devices:
+            _check(lib.cpir_server_setup_multi(_device_array(devices), len(devices), _seed_arg(seed_mu), a_ptr, _ptr(D), N, Cc,
+                                               mat_elem_bit_len, _ptr(hint), C.byref(h)))
+            return Server(h, devices[0]), hint
         _check(lib.cpir_server_setup(device._h, _seed_arg(seed_mu), a_ptr, _ptr(D), N, Cc, mat_elem_bit_len, _ptr(hint), C.byref(h)))
         return Server(h, device), hint
 
@@ -342,6 +358,17 @@ class Server:
     @property
     def response_len(self) -> int:
         return int(self.layout.num_cols)
+
+    def group_shards(self):
+        """[(device ordinal, first slot, slots)] of a group handle (Server.setup(..., devices=[...])); [] for an ordinary server"""
+        n = C.c_uint32()
+        _check(self._lib.cpir_server_group_size(self._h, C.byref(n)))
+        out = []
+        for i in range(n.value):
+            dev, lo, cnt = C.c_int(), C.c_uint64(), C.c_uint64()
+            _check(self._lib.cpir_server_group_shard(self._h, i, C.byref(dev), C.byref(lo), C.byref(cnt)))
+            out.append((dev.value, lo.value, cnt.value))
+        return out
 
     SETUP_PHASES = ("encode", "xof_expand_A", "D_h2d", "transpose_compress", "wait_for_A", "hint_matmul", "hint_d2h", "total")
 

@@ -250,6 +250,24 @@ int cpir_server_setup_kv(cpir_device* dev, uint32_t arity, const uint8_t seed_mu
                          const uint8_t* filter_seed_material, uint32_t max_attempts, uint8_t* hint_bytes_out,
                          size_t hint_bytes_cap, size_t* hint_bytes_len, uint8_t filter_param_bytes_out[CPIR_FILTER_PARAM_BYTE_LEN],
                          cpir_server** out);
+/* The same two constructors on a GROUP of devices of this process (new: the reference has no multi-device code).
+ * The database is split along the filter slots over devs[0 .. n_dev) (fewer if it has fewer packing units than devices; a device
+ * may be listed more than once); ONE host expansion of A feeds every device's column slab, every device packs its rows of D and
+ * multiplies its slab by them, and the per-shard partial hints are summed on the host.  The handle behaves like any other in
+ * cpir_server_respond / _respond_bytes / _export_compressed / _retain / _release: a host query is SCATTERED -- device g receives only
+ * its slots of q over its own host link, answers its shard, and the C-word partial responses are summed on the host (u32
+ * wrap-around, bit-identical to one device).  The *_device entry points reject a group handle (device pointers belong to one
+ * device; multi-process callers use one ordinary shard server per rank: cpir_server_from_device_matrix). */
+int cpir_server_setup_multi(cpir_device* const* devs, uint32_t n_dev, const uint8_t seed_mu[CPIR_SEED_BYTE_LEN], const uint32_t* pub_mat_a,
+                            const uint32_t* D, uint64_t N, uint32_t C, uint32_t mat_elem_bit_len, uint32_t* hint_out, cpir_server** out);
+int cpir_server_setup_kv_multi(cpir_device* const* devs, uint32_t n_dev, uint32_t arity, const uint8_t seed_mu[CPIR_SEED_BYTE_LEN],
+                               const cpir_kv_db* db, const uint8_t* filter_seed_material, uint32_t max_attempts, uint8_t* hint_bytes_out,
+                               size_t hint_bytes_cap, size_t* hint_bytes_len,
+                               uint8_t filter_param_bytes_out[CPIR_FILTER_PARAM_BYTE_LEN], cpir_server** out);
+/* Number of shards of a group handle (0 for an ordinary server), and where shard `index` lives. */
+int cpir_server_group_size(const cpir_server* srv, uint32_t* shards);
+int cpir_server_group_shard(const cpir_server* srv, uint32_t index, int* device_ordinal, uint64_t* slot_offset, uint64_t* num_slots);
+
 /* Host-only first half of Server::setup: Matrix::from_kv_database::<ARITY> (matrix.rs:633-648, binary_fuse_filter.rs:40-456,
  * serialization.rs:22-116).  Writes D (N x C row-major, D_cap_words >= N*C from cpir_setup_kv_shape) and the 68-byte
  * filter parameters.  No device involved. */

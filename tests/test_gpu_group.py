@@ -1,0 +1,117 @@
+"""GPU parity of GROUP handles: one process, the database split along the filter slots over several devices
+(cpir_server_setup_multi / cpir_server_setup_kv_multi), host queries scattered and partial responses summed on the host.
+
+The reference has no multi-device code; the property is that a group is indistinguishable from one device: same hint, same
+packed database, same responses, bit for bit.  A GPU box for tests has ONE device, so the groups here list it several times
+(every shard still has its own packed image, streams, query slice and partial response); on a multi-GPU node the same code
+runs with distinct ordinals."""
+import threading
+
+import numpy as np
+import pytest
+
+from _cases import cf_of, random_db_matrix, random_query, wire
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("b,N,C,shards", [(9, 3 * 1536 + 700, 37, 3), (10, 9 * 1536, 64, 2), (13, 5 * 512 + 1, 21, 4), (6, 4 * 4096 + 5, 33, 3),
+                                          (9, 1000, 5, 8)])
+def test_group_setup_and_respond_match_the_oracle(b, N, C, shards, orc, device):
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(b * 100 + shards)
+    seed = rng.bytes(32)
+    D = random_db_matrix(rng, N, C, b)
+    want_hint, want_dtc = orc.server_setup_from_matrix(seed, D, b)
+    srv, hint = cp.Server.setup_from_matrix(seed, D, b, devices=[device] * shards)
+    parts = srv.group_shards()
+    assert 1 <= len(parts) <= shards and parts[0][1] == 0 and sum(p[2] for p in parts) == N
+    cf = cf_of(b)
+    for (_, lo, cnt), nxt in zip(parts, parts[1:] + [(0, N, 0)]):
+        assert cnt > 0 and lo + cnt == nxt[1] and lo % cf == 0  # contiguous, non-empty, word-aligned
+    if N >= 8 * 1536:
+        assert len(parts) == shards
+    assert np.array_equal(hint, want_hint)  # sum of the per-shard partial hints
+    assert np.array_equal(srv.export_compressed(), want_dtc)  # stitched from the shards
+    assert (srv.decompressed_num_cols, srv.mat_elem_bit_len, srv.response_len) == (N, b, C)
+    for _ in range(3):
+        q = random_query(rng, N)
+        assert srv.respond(wire(q)) == orc.server_respond(want_dtc, N, b, wire(q))
+    # wire errors are those of one device (matrix.rs:973-1010, 329-331)
+    with pytest.raises(cp.ChalametPIRError) as e:
+        srv.respond(wire(random_query(rng, N + 1)))
+    assert e.value.variant == "IncompatibleDimensionForRowVectorTransposedMatrixMultiplication"
+    # caller-supplied A, and a clone sharing the shards
+    A = orc.generate_from_seed(1774, N, seed)
+    srv2, hint2 = cp.Server.setup_from_matrix(seed, D, b, pub_mat_a=A, devices=[device] * shards)
+    assert np.array_equal(hint2, want_hint)
+    twin = srv.clone()
+    srv.close()
+    q = random_query(rng, N)
+    assert twin.respond(wire(q)) == srv2.respond(wire(q)) == orc.server_respond(want_dtc, N, b, wire(q))
+
+
+def test_group_from_kv_database_equals_one_device(orc, device):
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(4242)
+    n = 3000
+    db = {}
+    while len(db) < n:
+        db[rng.bytes(int(rng.integers(16, 33)))] = rng.bytes(int(rng.integers(1, 200)))
+    seed, fseeds = rng.bytes(32), rng.bytes(32 * 100)
+    for arity in (3, 4):
+        one, hint1, filt1 = cp.Server.setup(seed, db, arity, device=device, filter_seed_material=fseeds)
+        grp, hint2, filt2 = cp.Server.setup(seed, db, arity, devices=[device] * 3, filter_seed_material=fseeds)
+        assert hint1 == hint2 and filt1 == filt2 and len(grp.group_shards()) >= 1
+        assert np.array_equal(one.export_compressed(), grp.export_compressed())
+        N = one.decompressed_num_cols
+        for _ in range(4):
+            q = wire(random_query(rng, N))
+            assert one.respond(q) == grp.respond(q)
+        ph = grp.setup_timings()
+        assert ph["total"] > 0 and ph["encode"] > 0
+
+
+def test_group_respond_is_reentrant(orc, device):
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(99)
+    N, C, b = 6 * 1536 + 11, 29, 9
+    D = random_db_matrix(rng, N, C, b)
+    srv, _ = cp.Server.setup_from_matrix(rng.bytes(32), D, b, devices=[device] * 4)
+    dtc = orc.row_wise_compress(orc.transpose(D), b)
+    qs = [random_query(rng, N) for _ in range(16)]
+    wants = [orc.row_vector_x_compressed_transposed_matrix(q, dtc, N, b)[0] for q in qs]
+    errors = []
+
+    def work(k):
+        try:
+            for i in range(12):
+                j = (k + i) % len(qs)
+                if not np.array_equal(srv.respond_array(qs[j]), wants[j]):
+                    errors.append((k, j))
+        except Exception as exc:  # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(12)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors
+
+
+def test_device_pointer_entry_points_reject_a_group(device):
+    import torch
+
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(5)
+    N, C, b = 4 * 1536, 8, 9
+    srv, _ = cp.Server.setup_from_matrix(rng.bytes(32), random_db_matrix(rng, N, C, b), b, devices=[device, device])
+    q = torch.zeros(N, dtype=torch.int32, device="cuda")
+    r = torch.zeros(C, dtype=torch.int32, device="cuda")
+    with pytest.raises(cp.ChalametPIRError):
+        srv.respond_device(q, r)
+    with pytest.raises(cp.ChalametPIRError):
+        srv.respond_batch_device(q, 1, r)
