@@ -3,6 +3,7 @@
 // (reference chalametpir_server/src/server.rs:47-78, 103-167, 184-190).
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <functional>
 #include <memory>
 #include <thread>
@@ -78,6 +79,27 @@ struct Server {
   static constexpr int kGroupCtx = 2;  // concurrent callers served at once; further callers wait
   GroupCtx gctx[kGroupCtx];
   bool gctx_ready = false;
+  // one persistent host thread per shard does that shard's staging, enqueues and wait, so the per-device host work of a
+  // query (a few tens of microseconds each) runs side by side instead of adding up over the devices
+  struct GroupDone {  // on the caller's stack
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t remaining = 0;
+    int status = CPIR_OK;
+  };
+  struct GroupJob {
+    const uint32_t* q = nullptr;
+    GroupCtx* ctx = nullptr;
+    GroupDone* done = nullptr;
+  };
+  struct GroupWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<GroupJob> jobs;
+    bool stop = false;
+  };
+  std::vector<std::unique_ptr<GroupWorker>> workers;
 };
 
 static double now_seconds() {
@@ -130,6 +152,15 @@ static int arenas_create(Server* srv) {
 static void server_destroy(Server* srv);
 
 static void group_ctx_destroy(Server* srv) {
+  for (auto& w : srv->workers) {
+    {
+      std::lock_guard<std::mutex> lk(w->mu);
+      w->stop = true;
+    }
+    w->cv.notify_all();
+    if (w->th.joinable()) w->th.join();
+  }
+  srv->workers.clear();
   for (Server::GroupCtx& c : srv->gctx) {
     for (size_t g = 0; g < c.lanes.size(); g++) {
       Server::GroupLane& l = c.lanes[g];
@@ -159,6 +190,48 @@ static void server_destroy(Server* srv) {
   delete srv;
 }
 
+// one shard's part of a group respond: stage its slots of the query, upload, answer, download, wait
+static int group_shard_respond(const Server* child, Server::GroupLane& l, const uint32_t* q, uint32_t C) {
+  const size_t n = (size_t)child->layout.num_slots;
+  memcpy(l.q_pinned, q + child->slot_offset, n * 4);
+  hipError_t e = hipMemcpyAsync(l.q_dev, l.q_pinned, n * 4, hipMemcpyHostToDevice, l.stream);
+  int status = CPIR_OK;
+  // a shard answered from ITS slice of the query is an unsharded respond on a database of its own slots
+  if (e == hipSuccess) status = launch_respond(child->dev, child->dtc, child->layout, l.q_dev, n, 0, 1, 1, l.r_dev, nullptr, l.stream);
+  if (e == hipSuccess && status == CPIR_OK) e = hipMemcpyAsync(l.r_pinned, l.r_dev, (size_t)C * 4, hipMemcpyDeviceToHost, l.stream);
+  const hipError_t e2 = hipStreamSynchronize(l.stream);  // drain whatever was enqueued
+  if (e == hipSuccess) e = e2;
+  if (e != hipSuccess && status == CPIR_OK) {
+    set_last_hip_error(e, "group respond (shard)", __FILE__, __LINE__);
+    status = CPIR_ERR_HIP;
+  }
+  return status;
+}
+
+static void group_worker_main(Server* srv, size_t g) {
+  Server::GroupWorker& w = *srv->workers[g];
+  const Server* child = srv->shards[g];
+  (void)hipSetDevice(child->dev->ordinal);  // this thread only ever talks to its shard's device
+  const uint32_t C = srv->layout.num_cols;
+  for (;;) {
+    Server::GroupJob job;
+    {
+      std::unique_lock<std::mutex> lk(w.mu);
+      w.cv.wait(lk, [&] { return w.stop || !w.jobs.empty(); });
+      if (w.jobs.empty()) return;  // stop requested and nothing left
+      job = w.jobs.front();
+      w.jobs.pop_front();
+    }
+    const int st = group_shard_respond(child, job.ctx->lanes[g], job.q, C);
+    {
+      std::lock_guard<std::mutex> lk(job.done->mu);
+      if (st != CPIR_OK && job.done->status == CPIR_OK) job.done->status = st;
+      job.done->remaining--;
+      job.done->cv.notify_one();  // under the lock: `done` lives on the caller's stack and may go away as soon as it is released
+    }
+  }
+}
+
 // per shard: a stream, a device block (query slice + response) and a pinned block of the same shape, for every call context
 static int group_ctx_create(Server* srv) {
   const uint32_t C = srv->layout.num_cols;
@@ -178,6 +251,10 @@ static int group_ctx_create(Server* srv) {
       l.r_dev = l.q_dev + qw;
       l.r_pinned = l.q_pinned + qw;
     }
+  }
+  for (size_t g = 0; g < srv->shards.size(); g++) {
+    srv->workers.emplace_back(new Server::GroupWorker);
+    srv->workers.back()->th = std::thread(group_worker_main, srv, g);
   }
   srv->gctx_ready = true;
   return CPIR_OK;
@@ -211,30 +288,20 @@ static int group_respond(Server* srv, const uint32_t* q, uint32_t* r_out) {
       srv->cv.notify_all();
     }
   } rel{srv, ctx};
-  int status = CPIR_OK;
-  size_t enqueued = 0;
-  for (size_t g = 0; g < srv->shards.size() && status == CPIR_OK; g++, enqueued++) {
-    const Server* child = srv->shards[g];
-    Server::GroupLane& l = ctx->lanes[g];
-    DeviceGuard dg(child->dev->ordinal);
-    const size_t n = (size_t)child->layout.num_slots;
-    memcpy(l.q_pinned, q + child->slot_offset, n * 4);
-    hipError_t e = hipMemcpyAsync(l.q_dev, l.q_pinned, n * 4, hipMemcpyHostToDevice, l.stream);
-    // a shard answered from ITS slice of the query is an unsharded respond on a database of its own slots
-    if (e == hipSuccess) status = launch_respond(child->dev, child->dtc, child->layout, l.q_dev, n, 0, 1, 1, l.r_dev, nullptr, l.stream);
-    if (e == hipSuccess && status == CPIR_OK) e = hipMemcpyAsync(l.r_pinned, l.r_dev, (size_t)C * 4, hipMemcpyDeviceToHost, l.stream);
-    if (e != hipSuccess) {
-      set_last_hip_error(e, "group respond: copy", __FILE__, __LINE__);
-      status = CPIR_ERR_HIP;
+  Server::GroupDone done;
+  done.remaining = srv->shards.size();
+  for (auto& w : srv->workers) {
+    {
+      std::lock_guard<std::mutex> lk(w->mu);
+      w->jobs.push_back(Server::GroupJob{q, ctx, &done});
     }
+    w->cv.notify_one();
   }
-  for (size_t g = 0; g < enqueued; g++) {  // drain every stream that got work, whatever happened
-    DeviceGuard dg(srv->shards[g]->dev->ordinal);
-    const hipError_t e = hipStreamSynchronize(ctx->lanes[g].stream);
-    if (e != hipSuccess && status == CPIR_OK) {
-      set_last_hip_error(e, "group respond: hipStreamSynchronize", __FILE__, __LINE__);
-      status = CPIR_ERR_HIP;
-    }
+  int status;
+  {
+    std::unique_lock<std::mutex> lk(done.mu);
+    done.cv.wait(lk, [&] { return done.remaining == 0; });
+    status = done.status;
   }
   if (status != CPIR_OK) return status;
   memcpy(r_out, ctx->lanes[0].r_pinned, (size_t)C * 4);
