@@ -34,8 +34,12 @@ def test_bench_multirank_on_one_gpu(world, config):
 
 def test_bench_single_rank_verify():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "cfg1", "--steps", "2", "--warmup", "1", "--no-setup",
-           "--no-cpu-baseline", "--verify"]
+           "--no-cpu-baseline", "--verify", "--group-shards", "3"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert out["verified_vs_oracle"] is True and out["roofline"]["bound"] == "hbm"
+    # the in-process group path of the bench (three shards on the one GPU): same responses as the single-device server
+    grp = out["respond_host_path_group"]
+    assert "error" not in grp and len(grp["shards"]) == 3 and grp["responses_equal_single_device"] is True
+    assert out["batched_respond"]["queries_per_sec"] > 0 and out["respond_host_path"]["one_caller_queries_per_sec"] > 0
