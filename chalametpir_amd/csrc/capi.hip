@@ -375,7 +375,8 @@ class PublicMatrixUpload {
     rows_per_block_ = (uint64_t)(64ull << 20) / (N_ * 4);
     if (rows_per_block_ < 1) rows_per_block_ = 1;
     if (rows_per_block_ > rows) rows_per_block_ = rows;
-    for (int i = 0; i < 2; i++) CPIR_HIP_TRY(hipHostMalloc(&pinned_[i], (size_t)rows_per_block_ * N_ * 4, hipHostMallocDefault));
+    // portable: the same staging block is the source of copies to every target device
+    for (int i = 0; i < 2; i++) CPIR_HIP_TRY(hipHostMalloc(&pinned_[i], (size_t)rows_per_block_ * N_ * 4, hipHostMallocPortable));
     memcpy(seed_, seed, 32);
     worker_ = std::thread([this] { status_ = run(); });
     return CPIR_OK;
