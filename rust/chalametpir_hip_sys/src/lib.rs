@@ -80,6 +80,7 @@ unsafe extern "C" {
                              num_fingerprints: *mut u64) -> c_int;
     pub fn cpir_encoded_num_cols(max_value_byte_len: u64, mat_elem_bit_len: u32) -> u64;
     pub fn cpir_generate_from_seed(rows: u64, cols: u64, seed: *const u8, out: *mut u32) -> c_int;
+    pub fn cpir_xof_permutation() -> *const c_char;
     pub fn cpir_dtc_layout_for(num_slots: u64, num_cols: u32, mat_elem_bit_len: u32, out: *mut cpir_dtc_layout) -> c_int;
     pub fn cpir_dtc_layout_for_packing(num_slots: u64, num_cols: u32, mat_elem_bit_len: u32, packing: u32, out: *mut cpir_dtc_layout) -> c_int;
 
@@ -107,6 +108,14 @@ unsafe extern "C" {
     pub fn cpir_server_setup_kv(dev: *mut cpir_device, arity: u32, seed_mu: *const u8, db: *const cpir_kv_db,
                                 filter_seed_material: *const u8, max_attempts: u32, hint_bytes_out: *mut u8, hint_bytes_cap: usize,
                                 hint_bytes_len: *mut usize, filter_param_bytes_out: *mut u8, out: *mut *mut cpir_server) -> c_int;
+    pub fn cpir_server_setup_multi(devs: *const *mut cpir_device, n_dev: u32, seed_mu: *const u8, pub_mat_a: *const u32, d: *const u32,
+                                   n: u64, c: u32, mat_elem_bit_len: u32, hint_out: *mut u32, out: *mut *mut cpir_server) -> c_int;
+    pub fn cpir_server_setup_kv_multi(devs: *const *mut cpir_device, n_dev: u32, arity: u32, seed_mu: *const u8, db: *const cpir_kv_db,
+                                      filter_seed_material: *const u8, max_attempts: u32, hint_bytes_out: *mut u8, hint_bytes_cap: usize,
+                                      hint_bytes_len: *mut usize, filter_param_bytes_out: *mut u8, out: *mut *mut cpir_server) -> c_int;
+    pub fn cpir_server_group_size(srv: *const cpir_server, shards: *mut u32) -> c_int;
+    pub fn cpir_server_group_shard(srv: *const cpir_server, index: u32, device_ordinal: *mut c_int, slot_offset: *mut u64,
+                                   num_slots: *mut u64) -> c_int;
     pub fn cpir_encode_kv_database(arity: u32, db: *const cpir_kv_db, mat_elem_bit_len: u32, filter_seed_material: *const u8,
                                    max_attempts: u32, filter_param_bytes_out: *mut u8, d_out: *mut u32, d_cap_words: u64,
                                    n: *mut u64, c: *mut u32) -> c_int;
