@@ -14,6 +14,8 @@ static constexpr uint64_t RC[12] = {0x000000008000808bULL, 0x800000000000008bULL
 #define X3(a, b, c) _mm_ternarylogic_epi64(a, b, c, 0x96)
 #define CHI(a, b, c) _mm_ternarylogic_epi64(a, b, c, 0xD2)
 #define ROL(a, n) _mm_rol_epi64(a, n)
+#define XX(a, b) _mm_xor_si128(a, b)
+#define ROLF(a, n) _mm_shldi_epi64(a, a, n)
 #define DECL(P) __m128i P##00, P##01, P##02, P##03, P##04, P##05, P##06, P##07, P##08, P##09, P##10, P##11, P##12, P##13, P##14, P##15, P##16, P##17, P##18, P##19, P##20, P##21, P##22, P##23, P##24
 #define LOADS(P, A)                                                                                                               \
   P##00 = L(A, 0), P##01 = L(A, 1), P##02 = L(A, 2), P##03 = L(A, 3), P##04 = L(A, 4), P##05 = L(A, 5), P##06 = L(A, 6), P##07 = L(A, 7), \
@@ -51,6 +53,106 @@ static constexpr uint64_t RC[12] = {0x000000008000808bULL, 0x800000000000008bULL
     a##20 = CHI(b20, b21, b22), a##21 = CHI(b21, b22, b23), a##22 = CHI(b22, b23, b24), a##23 = CHI(b23, b24, b20), a##24 = CHI(b24, b20, b21); \
   }
 
+#define ROUND_SHLD(a, rc)                                                                                                             \
+  {                                                                                                                               \
+    const __m128i c0 = X3(X3(a##00, a##05, a##10), a##15, a##20), c1 = X3(X3(a##01, a##06, a##11), a##16, a##21),                 \
+                  c2 = X3(X3(a##02, a##07, a##12), a##17, a##22), c3 = X3(X3(a##03, a##08, a##13), a##18, a##23),                 \
+                  c4 = X3(X3(a##04, a##09, a##14), a##19, a##24);                                                                 \
+    const __m128i r0 = ROLF(c0, 1), r1 = ROLF(c1, 1), r2 = ROLF(c2, 1), r3 = ROLF(c3, 1), r4 = ROLF(c4, 1);                            \
+    const __m128i b00 = X3(a##00, c4, r1), b01 = ROLF(X3(a##06, c0, r2), 44), b02 = ROLF(X3(a##12, c1, r3), 43),                    \
+                  b03 = ROLF(X3(a##18, c2, r4), 21), b04 = ROLF(X3(a##24, c3, r0), 14);                                             \
+    const __m128i b05 = ROLF(X3(a##03, c2, r4), 28), b06 = ROLF(X3(a##09, c3, r0), 20), b07 = ROLF(X3(a##10, c4, r1), 3),            \
+                  b08 = ROLF(X3(a##16, c0, r2), 45), b09 = ROLF(X3(a##22, c1, r3), 61);                                             \
+    const __m128i b10 = ROLF(X3(a##01, c0, r2), 1), b11 = ROLF(X3(a##07, c1, r3), 6), b12 = ROLF(X3(a##13, c2, r4), 25),             \
+                  b13 = ROLF(X3(a##19, c3, r0), 8), b14 = ROLF(X3(a##20, c4, r1), 18);                                              \
+    const __m128i b15 = ROLF(X3(a##04, c3, r0), 27), b16 = ROLF(X3(a##05, c4, r1), 36), b17 = ROLF(X3(a##11, c0, r2), 10),           \
+                  b18 = ROLF(X3(a##17, c1, r3), 15), b19 = ROLF(X3(a##23, c2, r4), 56);                                             \
+    const __m128i b20 = ROLF(X3(a##02, c1, r3), 62), b21 = ROLF(X3(a##08, c2, r4), 55), b22 = ROLF(X3(a##14, c3, r0), 39),           \
+                  b23 = ROLF(X3(a##15, c4, r1), 41), b24 = ROLF(X3(a##21, c0, r2), 2);                                              \
+    a##00 = _mm_xor_si128(CHI(b00, b01, b02), _mm_cvtsi64_si128((long long)(rc)));                                                \
+    a##01 = CHI(b01, b02, b03), a##02 = CHI(b02, b03, b04), a##03 = CHI(b03, b04, b00), a##04 = CHI(b04, b00, b01);               \
+    a##05 = CHI(b05, b06, b07), a##06 = CHI(b06, b07, b08), a##07 = CHI(b07, b08, b09), a##08 = CHI(b08, b09, b05), a##09 = CHI(b09, b05, b06); \
+    a##10 = CHI(b10, b11, b12), a##11 = CHI(b11, b12, b13), a##12 = CHI(b12, b13, b14), a##13 = CHI(b13, b14, b10), a##14 = CHI(b14, b10, b11); \
+    a##15 = CHI(b15, b16, b17), a##16 = CHI(b16, b17, b18), a##17 = CHI(b17, b18, b19), a##18 = CHI(b18, b19, b15), a##19 = CHI(b19, b15, b16); \
+    a##20 = CHI(b20, b21, b22), a##21 = CHI(b21, b22, b23), a##22 = CHI(b22, b23, b24), a##23 = CHI(b23, b24, b20), a##24 = CHI(b24, b20, b21); \
+  }
+
+
+#define ROUND_MIX(a, rc)                                                                                                             \
+  {                                                                                                                               \
+    const __m128i c0 = X3(X3(a##00, a##05, a##10), a##15, a##20), c1 = X3(X3(a##01, a##06, a##11), a##16, a##21),                 \
+                  c2 = X3(X3(a##02, a##07, a##12), a##17, a##22), c3 = X3(X3(a##03, a##08, a##13), a##18, a##23),                 \
+                  c4 = X3(X3(a##04, a##09, a##14), a##19, a##24);                                                                 \
+    const __m128i r0 = ROL(c0, 1), r1 = ROL(c1, 1), r2 = ROL(c2, 1), r3 = ROL(c3, 1), r4 = ROL(c4, 1);                            \
+    const __m128i b00 = X3(a##00, c4, r1), b01 = ROL(X3(a##06, c0, r2), 44), b02 = ROL(X3(a##12, c1, r3), 43),                    \
+                  b03 = ROL(X3(a##18, c2, r4), 21), b04 = ROL(X3(a##24, c3, r0), 14);                                             \
+    const __m128i b05 = ROLF(X3(a##03, c2, r4), 28), b06 = ROLF(X3(a##09, c3, r0), 20), b07 = ROLF(X3(a##10, c4, r1), 3),            \
+                  b08 = ROLF(X3(a##16, c0, r2), 45), b09 = ROLF(X3(a##22, c1, r3), 61);                                             \
+    const __m128i b10 = ROLF(X3(a##01, c0, r2), 1), b11 = ROLF(X3(a##07, c1, r3), 6), b12 = ROLF(X3(a##13, c2, r4), 25),             \
+                  b13 = ROLF(X3(a##19, c3, r0), 8), b14 = ROLF(X3(a##20, c4, r1), 18);                                              \
+    const __m128i b15 = ROLF(X3(a##04, c3, r0), 27), b16 = ROLF(X3(a##05, c4, r1), 36), b17 = ROLF(X3(a##11, c0, r2), 10),           \
+                  b18 = ROLF(X3(a##17, c1, r3), 15), b19 = ROLF(X3(a##23, c2, r4), 56);                                             \
+    const __m128i b20 = ROL(X3(a##02, c1, r3), 62), b21 = ROL(X3(a##08, c2, r4), 55), b22 = ROL(X3(a##14, c3, r0), 39),           \
+                  b23 = ROL(X3(a##15, c4, r1), 41), b24 = ROL(X3(a##21, c0, r2), 2);                                              \
+    a##00 = _mm_xor_si128(CHI(b00, b01, b02), _mm_cvtsi64_si128((long long)(rc)));                                                \
+    a##01 = CHI(b01, b02, b03), a##02 = CHI(b02, b03, b04), a##03 = CHI(b03, b04, b00), a##04 = CHI(b04, b00, b01);               \
+    a##05 = CHI(b05, b06, b07), a##06 = CHI(b06, b07, b08), a##07 = CHI(b07, b08, b09), a##08 = CHI(b08, b09, b05), a##09 = CHI(b09, b05, b06); \
+    a##10 = CHI(b10, b11, b12), a##11 = CHI(b11, b12, b13), a##12 = CHI(b12, b13, b14), a##13 = CHI(b13, b14, b10), a##14 = CHI(b14, b10, b11); \
+    a##15 = CHI(b15, b16, b17), a##16 = CHI(b16, b17, b18), a##17 = CHI(b17, b18, b19), a##18 = CHI(b18, b19, b15), a##19 = CHI(b19, b15, b16); \
+    a##20 = CHI(b20, b21, b22), a##21 = CHI(b21, b22, b23), a##22 = CHI(b22, b23, b24), a##23 = CHI(b23, b24, b20), a##24 = CHI(b24, b20, b21); \
+  }
+
+
+#define ROUND_XORC(a, rc)                                                                                                             \
+  {                                                                                                                               \
+    const __m128i c0 = XX(XX(a##00, a##05), XX(XX(a##10, a##15), a##20)), c1 = XX(XX(a##01, a##06), XX(XX(a##11, a##16), a##21)),                 \
+                  c2 = XX(XX(a##02, a##07), XX(XX(a##12, a##17), a##22)), c3 = XX(XX(a##03, a##08), XX(XX(a##13, a##18), a##23)),                 \
+                  c4 = XX(XX(a##04, a##09), XX(XX(a##14, a##19), a##24));                                                                 \
+    const __m128i r0 = ROL(c0, 1), r1 = ROL(c1, 1), r2 = ROL(c2, 1), r3 = ROL(c3, 1), r4 = ROL(c4, 1);                            \
+    const __m128i b00 = X3(a##00, c4, r1), b01 = ROL(X3(a##06, c0, r2), 44), b02 = ROL(X3(a##12, c1, r3), 43),                    \
+                  b03 = ROL(X3(a##18, c2, r4), 21), b04 = ROL(X3(a##24, c3, r0), 14);                                             \
+    const __m128i b05 = ROL(X3(a##03, c2, r4), 28), b06 = ROL(X3(a##09, c3, r0), 20), b07 = ROL(X3(a##10, c4, r1), 3),            \
+                  b08 = ROL(X3(a##16, c0, r2), 45), b09 = ROL(X3(a##22, c1, r3), 61);                                             \
+    const __m128i b10 = ROL(X3(a##01, c0, r2), 1), b11 = ROL(X3(a##07, c1, r3), 6), b12 = ROL(X3(a##13, c2, r4), 25),             \
+                  b13 = ROL(X3(a##19, c3, r0), 8), b14 = ROL(X3(a##20, c4, r1), 18);                                              \
+    const __m128i b15 = ROL(X3(a##04, c3, r0), 27), b16 = ROL(X3(a##05, c4, r1), 36), b17 = ROL(X3(a##11, c0, r2), 10),           \
+                  b18 = ROL(X3(a##17, c1, r3), 15), b19 = ROL(X3(a##23, c2, r4), 56);                                             \
+    const __m128i b20 = ROL(X3(a##02, c1, r3), 62), b21 = ROL(X3(a##08, c2, r4), 55), b22 = ROL(X3(a##14, c3, r0), 39),           \
+                  b23 = ROL(X3(a##15, c4, r1), 41), b24 = ROL(X3(a##21, c0, r2), 2);                                              \
+    a##00 = _mm_xor_si128(CHI(b00, b01, b02), _mm_cvtsi64_si128((long long)(rc)));                                                \
+    a##01 = CHI(b01, b02, b03), a##02 = CHI(b02, b03, b04), a##03 = CHI(b03, b04, b00), a##04 = CHI(b04, b00, b01);               \
+    a##05 = CHI(b05, b06, b07), a##06 = CHI(b06, b07, b08), a##07 = CHI(b07, b08, b09), a##08 = CHI(b08, b09, b05), a##09 = CHI(b09, b05, b06); \
+    a##10 = CHI(b10, b11, b12), a##11 = CHI(b11, b12, b13), a##12 = CHI(b12, b13, b14), a##13 = CHI(b13, b14, b10), a##14 = CHI(b14, b10, b11); \
+    a##15 = CHI(b15, b16, b17), a##16 = CHI(b16, b17, b18), a##17 = CHI(b17, b18, b19), a##18 = CHI(b18, b19, b15), a##19 = CHI(b19, b15, b16); \
+    a##20 = CHI(b20, b21, b22), a##21 = CHI(b21, b22, b23), a##22 = CHI(b22, b23, b24), a##23 = CHI(b23, b24, b20), a##24 = CHI(b24, b20, b21); \
+  }
+
+
+#define ROUND_XORC_CHI2(a, rc)                                                                                                             \
+  {                                                                                                                               \
+    const __m128i c0 = XX(XX(a##00, a##05), XX(XX(a##10, a##15), a##20)), c1 = XX(XX(a##01, a##06), XX(XX(a##11, a##16), a##21)),                 \
+                  c2 = XX(XX(a##02, a##07), XX(XX(a##12, a##17), a##22)), c3 = XX(XX(a##03, a##08), XX(XX(a##13, a##18), a##23)),                 \
+                  c4 = XX(XX(a##04, a##09), XX(XX(a##14, a##19), a##24));                                                                 \
+    const __m128i r0 = ROL(c0, 1), r1 = ROL(c1, 1), r2 = ROL(c2, 1), r3 = ROL(c3, 1), r4 = ROL(c4, 1);                            \
+    const __m128i b00 = X3(a##00, c4, r1), b01 = ROL(X3(a##06, c0, r2), 44), b02 = ROL(X3(a##12, c1, r3), 43),                    \
+                  b03 = ROL(X3(a##18, c2, r4), 21), b04 = ROL(X3(a##24, c3, r0), 14);                                             \
+    const __m128i b05 = ROL(X3(a##03, c2, r4), 28), b06 = ROL(X3(a##09, c3, r0), 20), b07 = ROL(X3(a##10, c4, r1), 3),            \
+                  b08 = ROL(X3(a##16, c0, r2), 45), b09 = ROL(X3(a##22, c1, r3), 61);                                             \
+    const __m128i b10 = ROL(X3(a##01, c0, r2), 1), b11 = ROL(X3(a##07, c1, r3), 6), b12 = ROL(X3(a##13, c2, r4), 25),             \
+                  b13 = ROL(X3(a##19, c3, r0), 8), b14 = ROL(X3(a##20, c4, r1), 18);                                              \
+    const __m128i b15 = ROL(X3(a##04, c3, r0), 27), b16 = ROL(X3(a##05, c4, r1), 36), b17 = ROL(X3(a##11, c0, r2), 10),           \
+                  b18 = ROL(X3(a##17, c1, r3), 15), b19 = ROL(X3(a##23, c2, r4), 56);                                             \
+    const __m128i b20 = ROL(X3(a##02, c1, r3), 62), b21 = ROL(X3(a##08, c2, r4), 55), b22 = ROL(X3(a##14, c3, r0), 39),           \
+                  b23 = ROL(X3(a##15, c4, r1), 41), b24 = ROL(X3(a##21, c0, r2), 2);                                              \
+    a##00 = _mm_xor_si128(CHI(b00, b01, b02), _mm_cvtsi64_si128((long long)(rc)));                                                \
+    a##01 = CHI(b01, b02, b03), a##02 = CHI(b02, b03, b04), a##03 = CHI(b03, b04, b00), a##04 = CHI(b04, b00, b01);               \
+    a##05 = CHI(b05, b06, b07), a##06 = CHI(b06, b07, b08), a##07 = CHI(b07, b08, b09), a##08 = CHI(b08, b09, b05), a##09 = CHI(b09, b05, b06); \
+    a##10 = CHI(b10, b11, b12), a##11 = CHI(b11, b12, b13), a##12 = CHI(b12, b13, b14), a##13 = CHI(b13, b14, b10), a##14 = CHI(b14, b10, b11); \
+    a##15 = XX(b15, _mm_andnot_si128(b16, b17)), a##16 = XX(b16, _mm_andnot_si128(b17, b18)), a##17 = XX(b17, _mm_andnot_si128(b18, b19)), a##18 = XX(b18, _mm_andnot_si128(b19, b15)), a##19 = XX(b19, _mm_andnot_si128(b15, b16)); \
+    a##20 = XX(b20, _mm_andnot_si128(b21, b22)), a##21 = XX(b21, _mm_andnot_si128(b22, b23)), a##22 = XX(b22, _mm_andnot_si128(b23, b24)), a##23 = XX(b23, _mm_andnot_si128(b24, b20)), a##24 = XX(b24, _mm_andnot_si128(b20, b21)); \
+  }
+
+
 __attribute__((target("avx512f,avx512vl"), noinline)) void one_loop(uint64_t* A, long n) {
   DECL(a);
   LOADS(a, A);
@@ -65,6 +167,34 @@ __attribute__((target("avx512f,avx512vl"), noinline)) void one_unrolled(uint64_t
     ROUND(a, RC[0]) ROUND(a, RC[1]) ROUND(a, RC[2]) ROUND(a, RC[3]) ROUND(a, RC[4]) ROUND(a, RC[5])
     ROUND(a, RC[6]) ROUND(a, RC[7]) ROUND(a, RC[8]) ROUND(a, RC[9]) ROUND(a, RC[10]) ROUND(a, RC[11])
   }
+  STORES(a, A);
+}
+__attribute__((target("avx512f,avx512vl,avx512vbmi2"), noinline)) void one_shld(uint64_t* A, long n) {
+  DECL(a);
+  LOADS(a, A);
+  for (long k = 0; k < n; k++)
+    for (int r = 0; r < 12; r++) ROUND_SHLD(a, RC[r]);
+  STORES(a, A);
+}
+__attribute__((target("avx512f,avx512vl,avx512vbmi2"), noinline)) void one_mix(uint64_t* A, long n) {
+  DECL(a);
+  LOADS(a, A);
+  for (long k = 0; k < n; k++)
+    for (int r = 0; r < 12; r++) ROUND_MIX(a, RC[r]);
+  STORES(a, A);
+}
+__attribute__((target("avx512f,avx512vl"), noinline)) void one_xorc(uint64_t* A, long n) {
+  DECL(a);
+  LOADS(a, A);
+  for (long k = 0; k < n; k++)
+    for (int r = 0; r < 12; r++) ROUND_XORC(a, RC[r]);
+  STORES(a, A);
+}
+__attribute__((target("avx512f,avx512vl"), noinline)) void one_xorc_chi2(uint64_t* A, long n) {
+  DECL(a);
+  LOADS(a, A);
+  for (long k = 0; k < n; k++)
+    for (int r = 0; r < 12; r++) ROUND_XORC_CHI2(a, RC[r]);
   STORES(a, A);
 }
 __attribute__((target("avx512f,avx512vl"), noinline)) void two_interleaved(uint64_t* A, uint64_t* B, long n) {
@@ -97,5 +227,17 @@ int main() {
   time("one state, round loop", [&] { one_loop(s1, n); }, 1);
   time("one state, unrolled", [&] { one_unrolled(s2, n); }, 1);
   time("two states interleaved", [&] { two_interleaved(s1, s3, n); }, 2);
+  uint64_t s4[25], s5[25], s6[25];
+  for (int i = 0; i < 25; i++) s4[i] = s5[i] = s6[i] = 0x0123456789abcdefULL * (i + 1);
+  one_loop(s4, 1000), one_xorc(s5, 1000), one_xorc_chi2(s6, 1000);
+  printf("xor-parity variants match: %d %d\n", memcmp(s4, s5, 200) == 0, memcmp(s4, s6, 200) == 0);
+  uint64_t s7[25], s8[25];
+  for (int i = 0; i < 25; i++) s7[i] = s8[i] = 0x0123456789abcdefULL * (i + 1);
+  one_shld(s7, 1000), one_mix(s8, 1000);
+  printf("funnel-shift variants match: %d %d\n", memcmp(s4, s7, 200) == 0, memcmp(s4, s8, 200) == 0);
+  time("rotates by vpshldq", [&] { one_shld(s7, n); }, 1);
+  time("rotates half vpshldq", [&] { one_mix(s8, n); }, 1);
+  time("parity by xor chains", [&] { one_xorc(s5, n); }, 1);
+  time("+ chi of 2 rows andn/xor", [&] { one_xorc_chi2(s6, n); }, 1);
   printf("%llx %llx %llx\n", (unsigned long long)s1[0], (unsigned long long)s2[0], (unsigned long long)s3[0]);
 }
