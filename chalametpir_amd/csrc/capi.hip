@@ -76,7 +76,7 @@ struct Server {
     bool busy = false;
     std::vector<GroupLane> lanes;
   };
-  static constexpr int kGroupCtx = 2;  // concurrent callers served at once; further callers wait
+  static constexpr int kGroupCtx = 4;  // concurrent callers served at once; further callers wait
   GroupCtx gctx[kGroupCtx];
   bool gctx_ready = false;
   // one persistent host thread per shard does that shard's staging, enqueues and wait, so the per-device host work of a
