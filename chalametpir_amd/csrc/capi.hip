@@ -325,6 +325,28 @@ static Server* server_new(Device* dev, const cpir_dtc_layout& L, uint64_t slot_o
 // ---------------------------------------------------------------------------------------------------------------
 // setup orchestration
 // ---------------------------------------------------------------------------------------------------------------
+// Setup's large temporaries (A in HBM: 8.4 GB at 2^20 keys, the unpacked D on host and device: 4.4 GB each, pinned staging) take
+// ~0.35 s to release -- longer than the hint matmul.  They are handed to a background thread so that setup returns as soon as the
+// server and the hint exist.  Threads still running when the library is unloaded are joined first.
+class BackgroundDisposer {
+ public:
+  ~BackgroundDisposer() {
+    std::lock_guard<std::mutex> lk(mu_);
+    for (std::thread& t : threads_)
+      if (t.joinable()) t.join();
+  }
+  void run(std::function<void()> f) {
+    std::lock_guard<std::mutex> lk(mu_);
+    threads_.emplace_back(std::move(f));
+  }
+
+ private:
+  std::mutex mu_;
+  std::vector<std::thread> threads_;
+};
+static BackgroundDisposer g_disposer;
+
+// ---------------------------------------------------------------------------------------------------------------
 // Expands the public matrix A (1774 x N) on a host thread -- TurboSHAKE128 squeezed row block by row block into two
 // pinned staging buffers -- and streams it into HBM on its own copy stream while the caller encodes / uploads / packs D.
 // A stays resident (8.4 GB at 2^20 keys, 33 GB at 2^22: sized for 288 GB of HBM) so the hint is ONE matmul launch.
@@ -438,10 +460,25 @@ class PublicMatrixUpload {
   double xof_seconds_ = 0;
 };
 
+static void dispose_async(std::unique_ptr<PublicMatrixUpload> up) {
+  PublicMatrixUpload* raw = up.release();
+  if (raw) g_disposer.run([raw] { delete raw; });
+}
+
 struct DevBuf {  // scoped device allocation
   void* p = nullptr;
   ~DevBuf() {
     if (p) (void)hipFree(p);
+  }
+  // free in the background (on device `ordinal`) instead of at scope exit
+  void dispose_async(int ordinal) {
+    void* q = p;
+    p = nullptr;
+    if (q)
+      g_disposer.run([q, ordinal] {
+        DeviceGuard g(ordinal);
+        (void)hipFree(q);
+      });
   }
 };
 
@@ -492,6 +529,7 @@ static int setup_from_host_matrix(Device* dev, PublicMatrixUpload& upA, const ui
   TRY_(hipStreamSynchronize(stream));
   srv->setup_timings[6] = now_seconds() - t0;
 #undef TRY_
+  D_dev.dispose_async(dev->ordinal);  // 4*N*C bytes
   *out = srv;
   return CPIR_OK;
 }
@@ -602,6 +640,7 @@ static int setup_group_from_host_matrix(const std::vector<Device*>& devs, Public
   }
   grp->setup_timings[5] = now_seconds() - t0;  // partial matmuls + downloads + host sum
 #undef TRY_
+  for (size_t g = 0; g < G; g++) work[g].D_dev.dispose_async(devs[g]->ordinal);
   *out = grp;
   return CPIR_OK;
 }
@@ -829,11 +868,13 @@ int cpir_server_setup(cpir_device* dev, const uint8_t seed_mu[CPIR_SEED_BYTE_LEN
   if (N == 0 || C == 0) return CPIR_ERR_INVALID_MATRIX_DIMENSION;
   if (compression_factor(b) == 0) return CPIR_ERR_IMPOSSIBLE_ELEMENT_BIT_LENGTH;  // matrix.rs:99-101
   const double t_begin = now_seconds();
-  PublicMatrixUpload upA(dev, N);
+  auto upA_owner = std::make_unique<PublicMatrixUpload>(dev, N);
+  PublicMatrixUpload& upA = *upA_owner;
   static const uint8_t zero_seed[32] = {0};
   CPIR_TRY(upA.start(seed_mu ? seed_mu : zero_seed, pub_mat_a));  // server.rs:59 (runs concurrently with the D work)
   Server* srv = nullptr;
   CPIR_TRY(setup_from_host_matrix(dev, upA, D, N, C, b, hint_out, &srv));
+  dispose_async(std::move(upA_owner));  // A leaves HBM in the background
   srv->setup_timings[7] = now_seconds() - t_begin;
   *out = static_cast<cpir_server*>(srv);
   return CPIR_OK;
@@ -865,13 +906,15 @@ int cpir_server_setup_multi(cpir_device* const* devs, uint32_t n_dev, const uint
   if (N == 0 || C == 0) return CPIR_ERR_INVALID_MATRIX_DIMENSION;
   if (compression_factor(b) == 0) return CPIR_ERR_IMPOSSIBLE_ELEMENT_BIT_LENGTH;
   const double t_begin = now_seconds();
-  PublicMatrixUpload upA(N);
+  auto upA_owner = std::make_unique<PublicMatrixUpload>(N);
+  PublicMatrixUpload& upA = *upA_owner;
   std::vector<Device*> use;
   CPIR_TRY(group_plan(devs, n_dev, N, C, b, &use, &upA));
   static const uint8_t zero_seed[32] = {0};
   CPIR_TRY(upA.start(seed_mu ? seed_mu : zero_seed, pub_mat_a));
   Server* srv = nullptr;
   CPIR_TRY(setup_group_from_host_matrix(use, upA, D, N, C, b, hint_out, &srv));
+  dispose_async(std::move(upA_owner));
   srv->setup_timings[7] = now_seconds() - t_begin;
   *out = static_cast<cpir_server*>(srv);
   return CPIR_OK;
@@ -933,7 +976,8 @@ static int setup_kv_common(cpir_device* const* devs, uint32_t n_dev, bool group,
   // N is known from the key count alone, so the (sequential, seconds-long) XOF expansion of A starts right away and
   // overlaps the (also sequential) filter construction and row encoding below
   const double t_begin = now_seconds();
-  PublicMatrixUpload upA(N);
+  auto upA_owner = std::make_unique<PublicMatrixUpload>(N);
+  PublicMatrixUpload& upA = *upA_owner;
   std::vector<Device*> use;
   if (group) {
     CPIR_TRY(group_plan(devs, n_dev, N, C, b, &use, &upA));
@@ -960,6 +1004,11 @@ static int setup_kv_common(cpir_device* const* devs, uint32_t n_dev, bool group,
   memcpy(hint_bytes_out + 4, &hc, 4);
   *hint_bytes_len = need;
   filter.to_bytes(filter_param_bytes_out);  // server.rs:63
+  dispose_async(std::move(upA_owner));  // A leaves HBM, and the unpacked D (4*N*C bytes of host memory) is unmapped, in the background
+  {
+    auto* dv = new std::vector<uint32_t>(std::move(D));
+    g_disposer.run([dv] { delete dv; });
+  }
   srv->setup_timings[0] = t_encode;
   srv->setup_timings[7] = now_seconds() - t_begin;
   *out = static_cast<cpir_server*>(srv);

@@ -105,6 +105,7 @@ void turboshake128(const uint8_t* msg, size_t len, uint8_t* out, size_t out_len)
 const char* xof_permutation_name();
 
 // host_shapes.cpp
+unsigned usable_cpus();
 uint32_t compression_factor(uint32_t b);
 int find_bit_len(uint64_t n, uint32_t* b);
 int filter_shape(uint32_t arity, uint64_t n, uint32_t* seg_len, uint32_t* seg_count_len, uint64_t* num_fp);

@@ -145,9 +145,16 @@ void pack_row(const uint8_t digest[32], const uint8_t* value, size_t value_len, 
   }
 }
 
+// worker threads of the encoder: the CPUs this process may use minus one -- during Server::setup another host thread is squeezing
+// the sponge for A, which is the critical path (capi.hip), and must not be throttled by an oversubscribed CPU quota
+unsigned encoder_threads() {
+  const unsigned cpus = usable_cpus();
+  const unsigned nt = cpus > 1 ? cpus - 1 : 1;
+  return nt < 32 ? nt : 32;
+}
+
 void parallel_for(uint64_t n, const std::function<void(uint64_t, uint64_t)>& body) {
-  unsigned hw = std::thread::hardware_concurrency();
-  unsigned nt = hw ? std::min<unsigned>(hw, 32) : 4;
+  unsigned nt = encoder_threads();
   if (n < 4096) nt = 1;
   if (nt <= 1) return body(0, n);
   std::vector<std::thread> pool;
@@ -316,8 +323,7 @@ int encode_kv_database(uint32_t arity, const cpir_kv_db& db, uint32_t b, const u
     }
   });
   {
-    unsigned hw = std::thread::hardware_concurrency();
-    uint64_t blocks = hw ? std::min<unsigned>(hw, 32) : 4;
+    uint64_t blocks = encoder_threads();
     if (n < 4096) blocks = 1;
     if (blocks > cols) blocks = cols;
     auto column_block = [&](uint64_t c0, uint64_t c1) {

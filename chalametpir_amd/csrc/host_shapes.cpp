@@ -1,10 +1,37 @@
 // host_shapes.cpp -- host-only shape arithmetic of the server path (no device needed).
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 
 #include "cpir_internal.hpp"
 
+#include <sched.h>
+
+#include <cstdio>
+
 namespace cpir {
+
+// CPUs this process may really use: min(affinity mask, cgroup v2 CPU quota).  A GPU box shows a container all 256 hardware threads
+// but gives it a quota of 16: std::thread::hardware_concurrency() then oversubscribes 16x and the quota throttles EVERY thread of
+// the process -- including the one squeezing the sponge that bounds setup.
+unsigned usable_cpus() {
+  unsigned n = 0;
+#if defined(__linux__)
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = (unsigned)CPU_COUNT(&set);
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char quota[32] = {0};
+    unsigned long long period = 0;
+    if (fscanf(f, "%31s %llu", quota, &period) == 2 && quota[0] != 'm' && period > 0) {
+      const unsigned long long q = strtoull(quota, nullptr, 10);
+      const unsigned lim = (unsigned)((q + period / 2) / period);
+      if (lim >= 1 && (n == 0 || lim < n)) n = lim;
+    }
+    fclose(f);
+  }
+#endif
+  return n ? n : 4;
+}
 
 // reference chalametpir_common/src/matrix.rs:103-167: packing factor by element bit length
 uint32_t compression_factor(uint32_t b) {
