@@ -624,8 +624,9 @@ def setup_timing(cp, device, torch, sharded, N, C, b, mask, stream):
         "server_setup_wall_sec": round(wall, 3),
         "server_setup_phases_sec": {k: round(v, 4) for k, v in phases.items()},
         "server_setup_note": "setup(seed_mu, encoded D on host): A expanded by TurboSHAKE128 on one host core (sequential sponge) "
-                             "overlapped with D upload + transpose/pack; then one hint matmul launch",
-        "hint_matmul_TMACs_per_s": round(macs / max(phases["hint_matmul"], 1e-9) / 1e12, 2),
+                             "overlapped with D upload + transpose/pack and with the hint matmul of the rows already expanded",
+        "hint_matmul_note": "the hint is computed in chunks of 128 rows of A as they arrive; `hint_matmul` is what is left after the last "
+                            f"rows are there ({macs / 1e12:.2f} T multiply-adds in all: kernel time in profiles/*setup_kernel_stats.csv)",
         "setup_db_matches_bench_db": same,
         "hint_checksum": int(hint.sum(dtype=np.uint64) & 0xFFFFFFFFFFFFFFFF),
     }

@@ -359,7 +359,7 @@ class PublicMatrixUpload {
     uint64_t col_lo = 0, col_n = 0;
     uint32_t* A_dev = nullptr;
     hipStream_t copy_stream = nullptr;
-    hipEvent_t ev[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> block_ev;  // one per staging block (XOF mode) or one for the whole upload (caller-supplied A)
   };
   PublicMatrixUpload(Device* dev, uint64_t N, uint64_t col_lo = 0, uint64_t col_n = 0) : N_(N) { add_target(dev, col_lo, col_n); }
   explicit PublicMatrixUpload(uint64_t N) : N_(N) {}
@@ -372,8 +372,8 @@ class PublicMatrixUpload {
     join();
     for (Target& t : targets_) {
       DeviceGuard g(t.dev->ordinal);
-      for (int i = 0; i < 2; i++)
-        if (t.ev[i]) (void)hipEventDestroy(t.ev[i]);
+      for (hipEvent_t e : t.block_ev)
+        if (e) (void)hipEventDestroy(e);
       if (t.copy_stream) (void)hipStreamDestroy(t.copy_stream);
       if (t.A_dev) (void)hipFree(t.A_dev);
     }
@@ -383,28 +383,55 @@ class PublicMatrixUpload {
 
   int start(const uint8_t seed[32], const uint32_t* A_host) {
     const uint64_t rows = CPIR_LWE_DIMENSION;
+    // ~64 MiB staging blocks, whole rows (one block = everything when the caller supplies A)
+    rows_per_block_ = A_host ? rows : (uint64_t)(64ull << 20) / (N_ * 4);
+    if (rows_per_block_ < 1) rows_per_block_ = 1;
+    if (rows_per_block_ > rows) rows_per_block_ = rows;
+    const uint64_t nblocks = (rows + rows_per_block_ - 1) / rows_per_block_;
     for (Target& t : targets_) {
       DeviceGuard g(t.dev->ordinal);
       CPIR_HIP_TRY(hipMalloc(&t.A_dev, (size_t)rows * t.col_n * 4));
       CPIR_HIP_TRY(hipStreamCreateWithFlags(&t.copy_stream, hipStreamNonBlocking));
-      if (A_host)  // caller supplied A: plain upload, no XOF
+      t.block_ev.assign(nblocks, nullptr);
+      for (hipEvent_t& e : t.block_ev) CPIR_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      if (A_host) {  // caller supplied A: plain upload, no XOF
         CPIR_HIP_TRY(hipMemcpy2DAsync(t.A_dev, t.col_n * 4, A_host + t.col_lo, N_ * 4, t.col_n * 4, rows, hipMemcpyHostToDevice, t.copy_stream));
-      else
-        for (int i = 0; i < 2; i++) CPIR_HIP_TRY(hipEventCreateWithFlags(&t.ev[i], hipEventDisableTiming));
+        CPIR_HIP_TRY(hipEventRecord(t.block_ev[0], t.copy_stream));
+      }
     }
-    if (A_host) return CPIR_OK;
-    // ~64 MiB staging blocks, whole rows
-    rows_per_block_ = (uint64_t)(64ull << 20) / (N_ * 4);
-    if (rows_per_block_ < 1) rows_per_block_ = 1;
-    if (rows_per_block_ > rows) rows_per_block_ = rows;
+    if (A_host) {
+      std::lock_guard<std::mutex> lk(prog_mu_);
+      rows_enqueued_ = rows, run_done_ = true;
+      return CPIR_OK;
+    }
     // portable: the same staging block is the source of copies to every target device
     for (int i = 0; i < 2; i++) CPIR_HIP_TRY(hipHostMalloc(&pinned_[i], (size_t)rows_per_block_ * N_ * 4, hipHostMallocPortable));
     memcpy(seed_, seed, 32);
-    worker_ = std::thread([this] { status_ = run(); });
+    worker_ = std::thread([this] {
+      const int st = run();
+      std::lock_guard<std::mutex> lk(prog_mu_);
+      status_ = st, run_done_ = true;
+      prog_cv_.notify_all();
+    });
     return CPIR_OK;
   }
 
   double xof_seconds() const { return xof_seconds_; }
+  const uint32_t* device_ptr(size_t which = 0) const { return targets_[which].A_dev; }  // valid after start()
+
+  // Block until the upload of rows [0, row_end) of A has been ENQUEUED on target `which`'s copy stream, then make `consumer` (a
+  // stream of that device) wait for it: hint rows can be computed while the sponge is still being squeezed for the rows below.
+  int wait_rows(uint64_t row_end, hipStream_t consumer, size_t which = 0) {
+    {
+      std::unique_lock<std::mutex> lk(prog_mu_);
+      prog_cv_.wait(lk, [&] { return rows_enqueued_ >= row_end || run_done_; });
+      if (rows_enqueued_ < row_end) return status_ != CPIR_OK ? status_ : CPIR_ERR_HIP;
+    }
+    Target& t = targets_[which];
+    DeviceGuard g(t.dev->ordinal);
+    CPIR_HIP_TRY(hipStreamWaitEvent(consumer, t.block_ev[(row_end - 1) / rows_per_block_], 0));
+    return CPIR_OK;
+  }
 
   // wait until all of A is in HBM (on every target); A_dev receives target `which`'s slab
   int finish(const uint32_t** A_dev, size_t which = 0) {
@@ -428,13 +455,13 @@ class PublicMatrixUpload {
     xof.finalize(0x1F);
     const uint64_t rows = CPIR_LWE_DIMENSION;
     int buf = 0;
-    bool used[2] = {false, false};
-    for (uint64_t r0 = 0; r0 < rows; r0 += rows_per_block_, buf ^= 1) {
+    uint64_t blk = 0;
+    for (uint64_t r0 = 0; r0 < rows; r0 += rows_per_block_, buf ^= 1, blk++) {
       const uint64_t rb = (rows - r0 < rows_per_block_) ? rows - r0 : rows_per_block_;
-      if (used[buf])  // staging buffer free again on every device?
+      if (blk >= 2)  // staging buffer free again on every device? (it was the source of block blk - 2)
         for (Target& t : targets_) {
           DeviceGuard g(t.dev->ordinal);
-          CPIR_HIP_TRY(hipEventSynchronize(t.ev[buf]));
+          CPIR_HIP_TRY(hipEventSynchronize(t.block_ev[blk - 2]));
         }
       const double t0 = now_seconds();
       xof.squeeze(reinterpret_cast<uint8_t*>(pinned_[buf]), (size_t)rb * N_ * 4);  // matrix.rs:546-555: row-major LE u32
@@ -443,9 +470,13 @@ class PublicMatrixUpload {
         DeviceGuard g(t.dev->ordinal);
         CPIR_HIP_TRY(hipMemcpy2DAsync(t.A_dev + r0 * t.col_n, t.col_n * 4, pinned_[buf] + t.col_lo, N_ * 4, t.col_n * 4, rb,
                                       hipMemcpyHostToDevice, t.copy_stream));
-        CPIR_HIP_TRY(hipEventRecord(t.ev[buf], t.copy_stream));
+        CPIR_HIP_TRY(hipEventRecord(t.block_ev[blk], t.copy_stream));
       }
-      used[buf] = true;
+      {
+        std::lock_guard<std::mutex> lk(prog_mu_);
+        rows_enqueued_ = r0 + rb;
+      }
+      prog_cv_.notify_all();
     }
     return CPIR_OK;
   }
@@ -458,6 +489,10 @@ class PublicMatrixUpload {
   std::thread worker_;
   int status_ = CPIR_OK;
   double xof_seconds_ = 0;
+  std::mutex prog_mu_;
+  std::condition_variable prog_cv_;
+  uint64_t rows_enqueued_ = 0;  // rows of A whose upload is on the copy streams
+  bool run_done_ = false;
 };
 
 static void dispose_async(std::unique_ptr<PublicMatrixUpload> up) {
@@ -513,17 +548,25 @@ static int setup_from_host_matrix(Device* dev, PublicMatrixUpload& upA, const ui
   // the hint uses the UNMASKED entries of D (server.rs:61 multiplies before any masking); the packed-16 kernel is
   // exact only if every entry is < 2^16, which holds for every encoded DB (entries < 2^b <= 2^14) and is verified here
   const uint32_t rhs_bits = (ored >> 16) ? 32u : 16u;
-  const uint32_t* A_dev = nullptr;
-  t0 = now_seconds();
-  st = upA.finish(&A_dev);
-  if (st != CPIR_OK) return fail(st);
-  srv->setup_timings[4] = now_seconds() - t0;
-  srv->setup_timings[1] = upA.xof_seconds();
-  t0 = now_seconds();
-  st = launch_mat_x_mat(dev, A_dev, N, (const uint32_t*)D_dev.p, C, (uint32_t*)M_dev.p, C, CPIR_LWE_DIMENSION, N, C, rhs_bits, 0, stream);
-  if (st != CPIR_OK) return fail(st);
+  // The hint in row chunks, each launched as soon as its rows of A are on their way to HBM: hint rows [r, r + 128) need only
+  // those rows of A, so all but the last chunk's matmul hides behind the sponge (the whole hint costs ~73 ms at 2^20 keys).
+  const uint32_t* A_dev = upA.device_ptr();
+  const uint64_t chunk = 128;
+  double t_wait = 0, t_last = now_seconds();
+  for (uint64_t r0 = 0; r0 < CPIR_LWE_DIMENSION; r0 += chunk) {
+    const uint64_t rb = (CPIR_LWE_DIMENSION - r0 < chunk) ? CPIR_LWE_DIMENSION - r0 : chunk;
+    t0 = now_seconds();
+    st = upA.wait_rows(r0 + rb, stream);
+    if (st != CPIR_OK) return fail(st);
+    t_last = now_seconds();
+    t_wait += t_last - t0;
+    st = launch_mat_x_mat(dev, A_dev + r0 * N, N, (const uint32_t*)D_dev.p, C, (uint32_t*)M_dev.p + r0 * C, C, rb, N, C, rhs_bits, 0, stream);
+    if (st != CPIR_OK) return fail(st);
+  }
   TRY_(hipStreamSynchronize(stream));
-  srv->setup_timings[5] = now_seconds() - t0;
+  srv->setup_timings[4] = t_wait;                   // waiting for rows of A (the sponge)
+  srv->setup_timings[5] = now_seconds() - t_last;   // what is left of the hint matmul once the last rows of A are there
+  srv->setup_timings[1] = upA.xof_seconds();
   t0 = now_seconds();
   TRY_(hipMemcpyAsync(hint_out, M_dev.p, (size_t)CPIR_LWE_DIMENSION * C * 4, hipMemcpyDeviceToHost, stream));
   TRY_(hipStreamSynchronize(stream));
