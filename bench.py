@@ -427,6 +427,18 @@ def host_path_timing(server, q_pool, N, torch):
     for i in range(n1):
         server.respond_array(qs[i % len(qs)])
     lat = (time.perf_counter() - t0) / n1
+    # the same single caller with its query in page-locked memory (cpir_host_alloc): DMA straight from the caller's buffer
+    import chalametpir_amd as cp
+
+    pin = cp.PinnedArray(N)
+    pin.array[:] = qs[0]
+    for _ in range(3):
+        server.respond_array(pin.array)
+    t0 = time.perf_counter()
+    for i in range(n1):
+        server.respond_array(pin.array)
+    lat_pinned = (time.perf_counter() - t0) / n1
+    pin.close()
     threads, per = 8, 32
 
     def work(k):
@@ -441,6 +453,7 @@ def host_path_timing(server, q_pool, N, torch):
     return {
         "one_caller_us_per_query": round(lat * 1e6, 1),
         "one_caller_queries_per_sec": round(1.0 / lat, 1),
+        "one_caller_pinned_query_us_per_query": round(lat_pinned * 1e6, 1),
         "eight_callers_queries_per_sec": round(thr, 1),
         "query_bytes": 4 * N,
         "note": "cpir_server_respond on host buffers: pinned staging in 1 MiB pieces + H2D + respond kernel + D2H; concurrent callers are "

@@ -106,6 +106,16 @@ static double now_seconds() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// is this host address page-locked memory the HIP runtime knows (so that a copy from it is a true asynchronous DMA)?
+static bool host_pointer_is_pinned(const void* p) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();  // ordinary pageable memory: not an error worth keeping
+    return false;
+  }
+  return attr.type == hipMemoryTypeHost;
+}
+
 static void device_retain(Device* d) { d->refs.fetch_add(1); }
 static void device_release(Device* d) {
   if (d && d->refs.fetch_sub(1) == 1) {
@@ -193,8 +203,13 @@ static void server_destroy(Server* srv) {
 // one shard's part of a group respond: stage its slots of the query, upload, answer, download, wait
 static int group_shard_respond(const Server* child, Server::GroupLane& l, const uint32_t* q, uint32_t C) {
   const size_t n = (size_t)child->layout.num_slots;
-  memcpy(l.q_pinned, q + child->slot_offset, n * 4);
-  hipError_t e = hipMemcpyAsync(l.q_dev, l.q_pinned, n * 4, hipMemcpyHostToDevice, l.stream);
+  hipError_t e;
+  if (host_pointer_is_pinned(q)) {
+    e = hipMemcpyAsync(l.q_dev, q + child->slot_offset, n * 4, hipMemcpyHostToDevice, l.stream);
+  } else {
+    memcpy(l.q_pinned, q + child->slot_offset, n * 4);
+    e = hipMemcpyAsync(l.q_dev, l.q_pinned, n * 4, hipMemcpyHostToDevice, l.stream);
+  }
   int status = CPIR_OK;
   // a shard answered from ITS slice of the query is an unsharded respond on a database of its own slots
   if (e == hipSuccess) status = launch_respond(child->dev, child->dtc, child->layout, l.q_dev, n, 0, 1, 1, l.r_dev, nullptr, l.stream);
@@ -740,6 +755,18 @@ const char* cpir_last_hip_error(void) { return t_last_hip_error; }
 const char* cpir_version(void) { return "chalamet_hip 0.1.0 (gfx950)"; }
 const char* cpir_xof_permutation(void) { return xof_permutation_name(); }
 
+int cpir_host_alloc(size_t bytes, void** out) {
+  if (!out || bytes == 0) return CPIR_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (!has_device(nullptr)) return CPIR_ERR_NO_DEVICE;
+  CPIR_HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocPortable));
+  return CPIR_OK;
+}
+
+void cpir_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // device
 // ---------------------------------------------------------------------------------------------------------------
@@ -1259,10 +1286,16 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
   const size_t piece = (size_t)1 << 18;  // 1 MiB of u32
   // (a shard reads only its own slots of the query: only those are staged and uploaded)
   const size_t q_end = (size_t)srv->slot_offset + (size_t)srv->layout.num_slots;
-  for (size_t o = (size_t)srv->slot_offset; o < q_end && up == hipSuccess; o += piece) {
-    const size_t n = (q_end - o < piece) ? q_end - o : piece;
-    memcpy(a->q_pinned + seat * N + o, q + o, n * 4);
-    up = hipMemcpyAsync(a->q_dev + seat * N + o, a->q_pinned + seat * N + o, n * 4, hipMemcpyHostToDevice, a->stream);
+  if (host_pointer_is_pinned(q)) {
+    // the caller's buffer is page-locked already (cpir_host_alloc, hipHostMalloc, hipHostRegister): DMA straight from it
+    up = hipMemcpyAsync(a->q_dev + seat * N + srv->slot_offset, q + srv->slot_offset, (q_end - (size_t)srv->slot_offset) * 4,
+                        hipMemcpyHostToDevice, a->stream);
+  } else {
+    for (size_t o = (size_t)srv->slot_offset; o < q_end && up == hipSuccess; o += piece) {
+      const size_t n = (q_end - o < piece) ? q_end - o : piece;
+      memcpy(a->q_pinned + seat * N + o, q + o, n * 4);
+      up = hipMemcpyAsync(a->q_dev + seat * N + o, a->q_pinned + seat * N + o, n * 4, hipMemcpyHostToDevice, a->stream);
+    }
   }
   if (up != hipSuccess) set_last_hip_error(up, "hipMemcpyAsync(query upload)", __FILE__, __LINE__);
 

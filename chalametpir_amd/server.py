@@ -180,6 +180,30 @@ def encode_kv_database(db: Mapping[bytes, bytes], arity: int, mat_elem_bit_len: 
     return D, bytes(fbytes)
 
 
+class PinnedArray:
+    """A u32 numpy array in page-locked host memory (cpir_host_alloc): queries kept in one are uploaded by DMA straight from it.
+    `.array` is the numpy view; the memory lives as long as this object."""
+
+    def __init__(self, count: int):
+        self._lib = _native.load()
+        p = C.c_void_p()
+        _check(self._lib.cpir_host_alloc(4 * count, C.byref(p)))
+        self._p = p
+        self.array = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(count,))
+
+    def close(self) -> None:
+        if self._p:
+            self.array = None
+            self._lib.cpir_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def tuning_set(key: str, value: int) -> None:
     _check(_native.load().cpir_tuning_set(key.encode(), int(value)))
 

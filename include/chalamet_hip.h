@@ -78,6 +78,12 @@ void cpir_device_close(cpir_device* dev);
 int cpir_device_ordinal(const cpir_device* dev, int* ordinal);
 int cpir_device_synchronize(cpir_device* dev);
 
+/* Page-locked host memory for query buffers (optional): cpir_server_respond* detects a query that lies in page-locked memory
+ * (from here, hipHostMalloc or hipHostRegister) and uploads it by DMA straight from the caller's buffer instead of staging it
+ * through the library's own pinned block -- about 80 us less per 4.7 MB query.  Any other pointer works as before. */
+int cpir_host_alloc(size_t bytes, void** out);
+void cpir_host_free(void* p);
+
 /* ------------------------------------------------------------------------------------------------
  * Shape helpers (host-only arithmetic, no device needed).
  * ------------------------------------------------------------------------------------------------ */

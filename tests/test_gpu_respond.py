@@ -299,3 +299,20 @@ def test_unaligned_queries_odd_shard_offsets_and_every_batch_size(orc, device):
         dtc_shard = orc.row_wise_compress(orc.transpose(D[lo:hi]), b)
         want_part = orc.row_vector_x_compressed_transposed_matrix(Q[0][lo:hi], dtc_shard, hi - lo, b)[0]
         assert np.array_equal(part.cpu().numpy().view(np.uint32), want_part), b
+
+
+def test_query_in_page_locked_memory_takes_the_direct_upload(orc, device):
+    """cpir_host_alloc: a query in page-locked memory is uploaded straight from the caller's buffer; same answers"""
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(123)
+    N, C, b = 5 * 1536 + 3, 19, 9
+    srv, dtc = make_server(cp, orc, device, rng, N, C, b)
+    pin = cp.PinnedArray(N)
+    for _ in range(3):
+        q = random_query(rng, N)
+        pin.array[:] = q
+        want = orc.row_vector_x_compressed_transposed_matrix(q, dtc, N, b)[0]
+        assert np.array_equal(srv.respond_array(pin.array), want)
+        assert np.array_equal(srv.respond_array(q), want)
+    pin.close()
