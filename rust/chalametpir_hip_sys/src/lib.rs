@@ -81,6 +81,8 @@ unsafe extern "C" {
     pub fn cpir_encoded_num_cols(max_value_byte_len: u64, mat_elem_bit_len: u32) -> u64;
     pub fn cpir_generate_from_seed(rows: u64, cols: u64, seed: *const u8, out: *mut u32) -> c_int;
     pub fn cpir_xof_permutation() -> *const c_char;
+    pub fn cpir_host_alloc(bytes: usize, out: *mut *mut core::ffi::c_void) -> c_int;
+    pub fn cpir_host_free(p: *mut core::ffi::c_void);
     pub fn cpir_dtc_layout_for(num_slots: u64, num_cols: u32, mat_elem_bit_len: u32, out: *mut cpir_dtc_layout) -> c_int;
     pub fn cpir_dtc_layout_for_packing(num_slots: u64, num_cols: u32, mat_elem_bit_len: u32, packing: u32, out: *mut cpir_dtc_layout) -> c_int;
 
