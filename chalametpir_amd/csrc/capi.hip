@@ -34,6 +34,8 @@ void set_last_hip_error(hipError_t e, const char* what, const char* file, int li
 // idle and launches at once: no added latency.
 struct RespondArena {
   hipStream_t stream = nullptr;
+  hipStream_t kernel_stream = nullptr;  // pipelined lone query: uploads on `stream`, kernel parts here, chained by `part_ev`
+  std::vector<hipEvent_t> part_ev;
   uint32_t* q_dev = nullptr;     // kSeats x total_slots u32
   uint32_t* r_dev = nullptr;     // kSeats x C u32
   uint32_t* q_pinned = nullptr;  // kSeats x total_slots u32
@@ -127,8 +129,12 @@ static void device_release(Device* d) {
 
 // the arenas live in ONE device block and ONE pinned block (pinning is the slow call: one instead of four per server)
 static void arenas_destroy(Server* srv) {
-  for (RespondArena& a : srv->arena)
+  for (RespondArena& a : srv->arena) {
     if (a.stream) (void)hipStreamDestroy(a.stream);
+    if (a.kernel_stream) (void)hipStreamDestroy(a.kernel_stream);
+    for (hipEvent_t e : a.part_ev)
+      if (e) (void)hipEventDestroy(e);
+  }
   if (srv->arena[0].q_dev) (void)hipFree(srv->arena[0].q_dev);
   if (srv->arena[0].q_pinned) (void)hipHostFree(srv->arena[0].q_pinned);
   for (RespondArena& a : srv->arena) a = RespondArena{};
@@ -142,11 +148,18 @@ static int arenas_create(Server* srv) {
   uint32_t *dev = nullptr, *pin = nullptr;
 #define TRY_(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_last_hip_error(_e, #e, __FILE__, __LINE__); \
     if (dev) (void)hipFree(dev); if (pin) (void)hipHostFree(pin); \
-    for (RespondArena& x : srv->arena) { if (x.stream) (void)hipStreamDestroy(x.stream); x = RespondArena{}; } \
+    for (RespondArena& x : srv->arena) { if (x.stream) (void)hipStreamDestroy(x.stream); \
+      if (x.kernel_stream) (void)hipStreamDestroy(x.kernel_stream); for (hipEvent_t ev : x.part_ev) if (ev) (void)hipEventDestroy(ev); \
+      x = RespondArena{}; } \
     return _e == hipErrorOutOfMemory ? CPIR_ERR_OUT_OF_DEVICE_MEMORY : CPIR_ERR_HIP; } } while (0)
   TRY_(hipMalloc(&dev, 2 * (qw + rw) * 4));
   TRY_(hipHostMalloc(&pin, 2 * (qw + rw) * 4, hipHostMallocDefault));
-  for (int i = 0; i < 2; i++) TRY_(hipStreamCreateWithFlags(&srv->arena[i].stream, hipStreamNonBlocking));
+  for (int i = 0; i < 2; i++) {
+    TRY_(hipStreamCreateWithFlags(&srv->arena[i].stream, hipStreamNonBlocking));
+    TRY_(hipStreamCreateWithFlags(&srv->arena[i].kernel_stream, hipStreamNonBlocking));
+    srv->arena[i].part_ev.assign(64, nullptr);
+    for (hipEvent_t& ev : srv->arena[i].part_ev) TRY_(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  }
 #undef TRY_
   for (int i = 0; i < 2; i++) {
     RespondArena& a = srv->arena[i];
@@ -1278,7 +1291,54 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
   RespondArena* other = (a == &srv->arena[0]) ? &srv->arena[1] : &srv->arena[0];
   const uint32_t seat = a->joined++;
   const bool leader = (seat == 0);
+  // A caller that finds the device idle has nobody to share a launch with: it closes its arena at once and PIPELINES its own
+  // query -- the upload in pieces along the slot axis, each piece followed by the part of the respond kernel that needs only those
+  // slots (the parts add up in r) -- so that the kernel hides behind the upload instead of following it.
+  const uint64_t steps = (srv->layout.num_slots + CPIR_PLANAR_SLOTS_PER_TILE - 1) / CPIR_PLANAR_SLOTS_PER_TILE;
+  uint64_t parts = (uint64_t)respond_host_pipeline_pieces();
+  if (parts > steps / 8) parts = steps / 8;  // every part must still fill the chip
+  const bool solo = leader && other->state != RespondArena::LAUNCHED && srv->layout.packing == CPIR_PACK_PLANAR && parts >= 2;
+  if (solo) a->state = RespondArena::LAUNCHED;
   lk.unlock();
+
+  if (solo) {
+    const bool direct = host_pointer_is_pinned(q);
+    int st = CPIR_OK;
+    hipError_t e = hipSuccess;
+    uint32_t* qd = a->q_dev;  // seat 0
+    for (uint64_t i = 0; i < parts && st == CPIR_OK && e == hipSuccess; i++) {
+      const uint64_t s_lo = steps * i / parts, s_hi = steps * (i + 1) / parts;
+      const size_t n_lo = (size_t)srv->slot_offset + (size_t)s_lo * CPIR_PLANAR_SLOTS_PER_TILE;
+      size_t n_hi = (size_t)srv->slot_offset + (size_t)s_hi * CPIR_PLANAR_SLOTS_PER_TILE;
+      const size_t n_end = (size_t)srv->slot_offset + (size_t)srv->layout.num_slots;
+      if (n_hi > n_end) n_hi = n_end;
+      const uint32_t* src = q + n_lo;
+      if (!direct) {
+        memcpy(a->q_pinned + n_lo, q + n_lo, (n_hi - n_lo) * 4);
+        src = a->q_pinned + n_lo;
+      }
+      // uploads queue up back to back on the copy stream; part i of the kernel waits only for piece i
+      e = hipMemcpyAsync(qd + n_lo, src, (n_hi - n_lo) * 4, hipMemcpyHostToDevice, a->stream);
+      if (e == hipSuccess) e = hipEventRecord(a->part_ev[i], a->stream);
+      if (e == hipSuccess) e = hipStreamWaitEvent(a->kernel_stream, a->part_ev[i], 0);
+      if (e == hipSuccess)
+        st = launch_respond_planar_part(srv->dev, srv->dtc, srv->layout, qd, srv->total_slots, srv->slot_offset, a->r_dev, s_lo, s_hi,
+                                        a->kernel_stream);
+    }
+    if (st == CPIR_OK && e == hipSuccess) e = hipMemcpyAsync(a->r_pinned, a->r_dev, C * 4, hipMemcpyDeviceToHost, a->kernel_stream);
+    const hipError_t e2 = hipStreamSynchronize(a->stream), e3 = hipStreamSynchronize(a->kernel_stream);  // always drain both
+    if (e == hipSuccess) e = (e2 != hipSuccess) ? e2 : e3;
+    if (st == CPIR_OK && e != hipSuccess) {
+      set_last_hip_error(e, "pipelined respond", __FILE__, __LINE__);
+      st = CPIR_ERR_HIP;
+    }
+    if (st == CPIR_OK) memcpy(r_out, a->r_pinned, C * 4);
+    lk.lock();
+    a->state = RespondArena::FREE;
+    a->joined = a->staged = a->left = 0;
+    srv->cv.notify_all();
+    return st;
+  }
 
   // ---- stage the query: pinned copy (the reference copies too: from_bytes .to_vec(), matrix.rs:1001-1007), then its upload ----
   // in pieces, so that the DMA of one piece runs while the next is being copied into the pinned block

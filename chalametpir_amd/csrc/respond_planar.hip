@@ -50,6 +50,7 @@ struct PlanarArgs {
   uint32_t col_tiles;      // rows_padded / 16
   uint32_t tile_groups;    // ceil(col_tiles / kM)
   uint32_t ks_total;       // super-tile steps along the slots: ceil(N / 512)
+  uint32_t ks_lo, ks_hi;   // this launch covers steps [ks_lo, ks_hi) only (the whole axis unless a host query is being pipelined)
   uint32_t nx;             // slot-axis split by blockIdx % nx (8 or 1)
   uint32_t q_per_pass;     // queries answered per pass (1..8): rows 4*i .. 4*i+3 of A row set i / 4 belong to query i
   uint32_t passes;         // independent passes over the database in this launch
@@ -98,8 +99,9 @@ respond_planar_kernel(const PlanarArgs a) {
   const uint32_t xcd = blockIdx.x % nx;
   const uint32_t j = blockIdx.x / nx;
   const uint32_t nb = gridDim.x / nx;  // host guarantees gridDim.x % nx == 0
-  const uint32_t kb0 = (uint32_t)(((uint64_t)a.ks_total * xcd) / nx);
-  const uint32_t ke0 = (uint32_t)(((uint64_t)a.ks_total * (xcd + 1)) / nx);
+  const uint32_t ks_len = a.ks_hi - a.ks_lo;
+  const uint32_t kb0 = a.ks_lo + (uint32_t)(((uint64_t)ks_len * xcd) / nx);
+  const uint32_t ke0 = a.ks_lo + (uint32_t)(((uint64_t)ks_len * (xcd + 1)) / nx);
   const uint32_t span = ke0 - kb0;
   if (span == 0) return;
   const uint64_t units = (uint64_t)a.tile_groups * span;
@@ -292,12 +294,15 @@ respond_planar_kernel(const PlanarArgs a) {
 // atomic adds, so their order against the main kernel's does not matter.
 __global__ void __launch_bounds__(kThreads) planar_init_kernel(const uint32_t* __restrict__ q, uint64_t q_len, uint64_t q_slot_offset,
                                                                 uint64_t num_slots, const uint32_t* __restrict__ colsum,
-                                                                uint32_t num_cols, uint32_t* __restrict__ r, uint32_t split) {
+                                                                uint32_t num_cols, uint32_t* __restrict__ r, uint32_t split,
+                                                                uint64_t range_lo, uint64_t range_hi) {
   __shared__ uint32_t sm[kThreads / 64];
   const uint32_t qi = blockIdx.x / split, s = blockIdx.x % split;
   const uint64_t room = q_len > q_slot_offset ? q_len - q_slot_offset : 0;
   const uint64_t nvalid = num_slots < room ? num_slots : room;
-  const uint64_t lo = nvalid * s / split, hi = nvalid * (s + 1) / split;
+  // the valid slots of [range_lo, range_hi): this launch's part of the slot axis (colsum == NULL: its column term was added before)
+  const uint64_t a0 = range_lo < nvalid ? range_lo : nvalid, a1 = range_hi < nvalid ? range_hi : nvalid;
+  const uint64_t lo = a0 + (a1 - a0) * s / split, hi = a0 + (a1 - a0) * (s + 1) / split;
   const uint32_t* src = q + (uint64_t)qi * q_len + q_slot_offset;
   uint32_t sum = 0;
 #pragma unroll 8
@@ -309,7 +314,7 @@ __global__ void __launch_bounds__(kThreads) planar_init_kernel(const uint32_t* _
   sum = sm[0] + sm[1] + sm[2] + sm[3];
   const uint32_t k = 128u * sum - 0x40404000u * (uint32_t)(hi - lo);  // 128 * 0x80808080 = 0x40404000 mod 2^32
   for (uint32_t c = threadIdx.x; c < num_cols; c += kThreads) {
-    const uint32_t v = k + (s == 0 ? 0x80808080u * colsum[c] : 0u);
+    const uint32_t v = k + ((s == 0 && colsum) ? 0x80808080u * colsum[c] : 0u);
     atomicAdd(r + (uint64_t)qi * num_cols + c, v);
   }
 }
@@ -335,7 +340,7 @@ KernelFn pick(uint32_t hb, uint32_t batch, bool nt) { return batch <= 4 ? pick_h
 
 int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                           uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, int blocks_per_cu,
-                          bool nontemporal, bool xcd_split, int interleave) {
+                          bool nontemporal, bool xcd_split, int interleave, uint64_t step_lo, uint64_t step_hi) {
   // shape invariants the kernel relies on (layout already checked by the caller)
   if (L.packing != CPIR_PACK_PLANAR || batch == 0 || batch > CPIR_PLANAR_MAX_QUERIES_PER_PASS || passes == 0) return CPIR_ERR_INVALID_ARGUMENT;
   const uint32_t hb = planar_hi_planes(L.mat_elem_bit_len);
@@ -362,6 +367,11 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
   a.col_tiles = L.rows_padded / 16;
   a.tile_groups = (a.col_tiles + kM - 1) / kM;
   a.ks_total = (uint32_t)ks_total;
+  // [step_lo, step_hi) in super-tile steps; step_hi = 0 means the whole slot axis.  A partial launch ADDS its part to r: the first
+  // part (step_lo == 0) zeroes r and adds the per-column term, every part adds the per-query term of its own slots.
+  if (step_hi == 0) step_hi = ks_total;
+  if (step_lo >= step_hi || step_hi > ks_total) return CPIR_ERR_INVALID_ARGUMENT;
+  a.ks_lo = (uint32_t)step_lo, a.ks_hi = (uint32_t)step_hi;
   a.q_per_pass = batch;
   a.passes = passes;
   a.interleave = inter ? 1u : 0u;
@@ -371,9 +381,9 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
   // 1 block 273; sharing passes (interleaved) 3 blocks 107 vs 2 blocks 118.  The two-row-set kernel fits 2 blocks per CU.
   int bpc = blocks_per_cu > 0 ? blocks_per_cu : (inter ? 3 : 2);
   if (batch > 4 && bpc > 2) bpc = 2;
-  const uint64_t units = (uint64_t)a.tile_groups * a.ks_total;
+  const uint64_t units = (uint64_t)a.tile_groups * (a.ks_hi - a.ks_lo);
   uint64_t grid = (uint64_t)dev->num_cus * (uint64_t)bpc;
-  a.nx = (xcd_split && a.ks_total >= 8 && grid % 8 == 0) ? 8u : 1u;
+  a.nx = (xcd_split && (a.ks_hi - a.ks_lo) >= 8 && grid % 8 == 0) ? 8u : 1u;
   const uint64_t blocks_needed = (units + kThreads / 64 - 1) / (kThreads / 64);
   if (grid > blocks_needed) {
     grid = blocks_needed;
@@ -382,14 +392,16 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
   }
 
   const uint32_t nq = batch * passes;
-  CPIR_HIP_TRY(hipMemsetAsync(r, 0, (size_t)nq * L.num_cols * sizeof(uint32_t), stream));
-  const uint32_t* colsum = dtc + (uint64_t)L.rows_padded * L.words_per_row_padded;
+  const bool first = (step_lo == 0);
+  if (first) CPIR_HIP_TRY(hipMemsetAsync(r, 0, (size_t)nq * L.num_cols * sizeof(uint32_t), stream));
+  const uint32_t* colsum = first ? dtc + (uint64_t)L.rows_padded * L.words_per_row_padded : nullptr;
+  const uint64_t range_lo = step_lo * CPIR_PLANAR_SLOTS_PER_TILE, range_hi = step_hi * CPIR_PLANAR_SLOTS_PER_TILE;
   // slices of the query per init block: at most 64 Ki slots each (a lone query of a 2^22-key database would otherwise leave
   // 16 blocks reading 1.2 MB each in front of the main kernel)
-  uint32_t split = (uint32_t)((L.num_slots + 65535) / 65536);
+  uint32_t split = (uint32_t)((range_hi - range_lo + 65535) / 65536);
   split = split < 4 ? 4 : (split > 256 ? 256 : split);
   hipLaunchKernelGGL(planar_init_kernel, dim3(nq * split), dim3(kThreads), 0, stream, q, q_len, q_slot_offset, L.num_slots, colsum,
-                     L.num_cols, r, split);
+                     L.num_cols, r, split, range_lo, range_hi);
   hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(kThreads), 0, stream, a);
   CPIR_HIP_TRY(hipGetLastError());
   return CPIR_OK;
