@@ -396,9 +396,9 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
   if (first) CPIR_HIP_TRY(hipMemsetAsync(r, 0, (size_t)nq * L.num_cols * sizeof(uint32_t), stream));
   const uint32_t* colsum = first ? dtc + (uint64_t)L.rows_padded * L.words_per_row_padded : nullptr;
   const uint64_t range_lo = step_lo * CPIR_PLANAR_SLOTS_PER_TILE, range_hi = step_hi * CPIR_PLANAR_SLOTS_PER_TILE;
-  // slices of the query per init block: at most 64 Ki slots each (a lone query of a 2^22-key database would otherwise leave
-  // 16 blocks reading 1.2 MB each in front of the main kernel)
-  uint32_t split = (uint32_t)((range_hi - range_lo + 65535) / 65536);
+  // slices of the query per init block: at most 16 Ki slots each (a lone query must not leave a handful of blocks reading hundreds of
+  // KB each in front of the main kernel: 12.6 us with 64 Ki-slot slices at 2^20 keys)
+  uint32_t split = (uint32_t)((range_hi - range_lo + 16383) / 16384);
   split = split < 4 ? 4 : (split > 256 ? 256 : split);
   hipLaunchKernelGGL(planar_init_kernel, dim3(nq * split), dim3(kThreads), 0, stream, q, q_len, q_slot_offset, L.num_slots, colsum,
                      L.num_cols, r, split, range_lo, range_hi);
