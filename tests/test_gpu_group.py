@@ -115,3 +115,53 @@ def test_device_pointer_entry_points_reject_a_group(device):
         srv.respond_device(q, r)
     with pytest.raises(cp.ChalametPIRError):
         srv.respond_batch_device(q, 1, r)
+
+
+def test_lifecycle_stress_servers_groups_and_setups_from_many_threads(orc, device):
+    """handles created, cloned, queried and dropped concurrently from several threads -- single-device servers (coalescing arenas),
+    group handles (per-shard worker threads) and full setups (background release of A / D): every response must still be exact and
+    nothing may hang or crash"""
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(31337)
+    N, C, b = 4 * 1536 + 9, 23, 9
+    D = random_db_matrix(rng, N, C, b)
+    dtc = orc.row_wise_compress(orc.transpose(D), b)
+    seed = rng.bytes(32)
+    want_hint, _ = orc.server_setup_from_matrix(seed, D, b)
+    qs = [random_query(rng, N) for _ in range(8)]
+    wants = [orc.row_vector_x_compressed_transposed_matrix(q, dtc, N, b)[0] for q in qs]
+    errors = []
+
+    def worker(k):
+        try:
+            for it in range(6):
+                kind = (k + it) % 3
+                if kind == 0:
+                    srv = cp.Server.from_compressed(dtc, N, b, device=device)
+                elif kind == 1:
+                    srv, hint = cp.Server.setup_from_matrix(seed, D, b, devices=[device] * (2 + it % 3))
+                    if not np.array_equal(hint, want_hint):
+                        errors.append(("group hint", k, it))
+                else:
+                    srv, hint = cp.Server.setup_from_matrix(seed, D, b, device=device)
+                    if not np.array_equal(hint, want_hint):
+                        errors.append(("hint", k, it))
+                twin = srv.clone()
+                for j in range(4):
+                    i = (k + it + j) % len(qs)
+                    h = twin if j % 2 else srv
+                    if not np.array_equal(h.respond_array(qs[i]), wants[i]):
+                        errors.append(("respond", k, it, j))
+                srv.close()
+                if not np.array_equal(twin.respond_array(qs[0]), wants[0]):  # the clone keeps the database alive
+                    errors.append(("clone", k, it))
+                twin.close()
+        except Exception as exc:  # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+    [t.start() for t in threads]
+    [t.join(600) for t in threads]
+    assert not any(t.is_alive() for t in threads), "a worker hung"
+    assert not errors, errors[:5]
