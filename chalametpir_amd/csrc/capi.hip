@@ -1291,9 +1291,9 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
   RespondArena* other = (a == &srv->arena[0]) ? &srv->arena[1] : &srv->arena[0];
   const uint32_t seat = a->joined++;
   const bool leader = (seat == 0);
-  // A caller that finds the device idle has nobody to share a launch with: it closes its arena at once and PIPELINES its own
-  // query -- the upload in pieces along the slot axis, each piece followed by the part of the respond kernel that needs only those
-  // slots (the parts add up in r) -- so that the kernel hides behind the upload instead of following it.
+  // Optional (respond.host_pipeline_pieces > 1; off by default, it measured slower -- DESIGN.md section 4): a caller that finds the
+  // device idle has nobody to share a launch with, closes its arena at once and PIPELINES its own query -- the upload in pieces
+  // along the slot axis, each piece followed by the part of the respond kernel that needs only those slots (the parts add up in r).
   const uint64_t steps = (srv->layout.num_slots + CPIR_PLANAR_SLOTS_PER_TILE - 1) / CPIR_PLANAR_SLOTS_PER_TILE;
   uint64_t parts = (uint64_t)respond_host_pipeline_pieces();
   if (parts > steps / 8) parts = steps / 8;  // every part must still fill the chip
