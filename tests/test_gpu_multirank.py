@@ -43,3 +43,27 @@ def test_bench_single_rank_verify():
     grp = out["respond_host_path_group"]
     assert "error" not in grp and len(grp["shards"]) == 3 and grp["responses_equal_single_device"] is True
     assert out["batched_respond"]["queries_per_sec"] > 0 and out["respond_host_path"]["one_caller_queries_per_sec"] > 0
+
+
+def test_bench_json_contract():
+    """the one JSON line the driver parses: every key of the bench contract, with the types and relations it relies on"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "cfg1", "--steps", "3", "--warmup", "1", "--no-setup",
+           "--no-host-path", "--cpu-seconds", "1"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "rank 0 prints ONE line on stdout"
+    d = json.loads(lines[0])
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)):
+        assert isinstance(d[key], typ), key
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and d["scaling"] in ("weak", "strong")
+    assert (d["n_gpus"], d["steps"], d["warmup"], d["data"], d["dtype"]) == (1, 3, 1, "synthetic", "u32")
+    assert "workload" in d["config"] and "model" not in d["config"]
+    roof = d["roofline"]
+    assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s") and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and "traffic" in roof
+    assert abs(d["value"] - d["config"]["queries_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
+    cpu = d["cpu_baseline"]
+    assert cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1 and cpu["value"] > 0 and isinstance(cpu["sample"], str)
+    assert cpu["gpu_results_bit_exact"] is True
