@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Soak test (GPU box): for --seconds, random full-size queries through every respond path of the planar server -- device single,
+device batches (fused and unfused, both pass orders), host bytes (pageable and page-locked, 1..8 concurrent callers), a 5-shard
+in-process group -- each compared with exact 64-bit sums computed by torch from the unpacked matrix.  Prints a count and exits 1 on
+the first mismatch."""
+import argparse
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import chalametpir_amd as cp  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=120)
+args = ap.parse_args()
+dev = cp.Device(0)
+N, C, b = 1179648, 940, 9
+stream = torch.cuda.current_stream()
+D = torch.empty((N, C), dtype=torch.int32, device="cuda")
+dev.synth_fill(D, N * C, 0xD, mask=(1 << b) - 1, stream=stream)
+srv = cp.Server.from_device_matrix(D, N, C, b, device=dev, stream=stream)
+grp, _ = cp.Server.setup_from_matrix(bytes(32), D.cpu().numpy().view(np.uint32), b, devices=[dev] * 5)
+torch.cuda.synchronize()
+
+
+def exact(qs):
+    out = []
+    for q in qs:
+        acc = torch.zeros(C, dtype=torch.int64, device="cuda")
+        for lo in range(0, N, 1 << 17):
+            qq = q[lo:lo + (1 << 17)].to(torch.int64) & 0xFFFFFFFF
+            acc += (qq[:, None] * D[lo:lo + (1 << 17)].to(torch.int64)).sum(dim=0)
+        out.append((acc & 0xFFFFFFFF).cpu().numpy().astype(np.uint32))
+    return out
+
+
+t_end = time.time() + args.seconds
+rounds = checks = 0
+seed = 0x9000
+while time.time() < t_end:
+    k = 8
+    Q = torch.empty((k, N), dtype=torch.int32, device="cuda")
+    for i in range(k):
+        dev.synth_fill(Q, N, seed + i, offset_words=i * N, stream=stream)
+    seed += k
+    want = exact([Q[i] for i in range(k)])
+    got = []
+    R = torch.empty((k, C), dtype=torch.int32, device="cuda")
+    for fusion in (1, 0):
+        for order in (0, 1):
+            cp.tuning_set("respond.batch_fusion", fusion)
+            cp.tuning_set("respond.interleave_passes", order)
+            R.fill_(-1)
+            srv.respond_batch_device(Q, k, R, stream=stream)
+            torch.cuda.synchronize()
+            got.append(("batch", fusion, order, R.cpu().numpy().view(np.uint32).copy()))
+    cp.tuning_set("respond.batch_fusion", 1)
+    cp.tuning_set("respond.interleave_passes", -1)
+    for name, fusion, order, r in got:
+        for i in range(k):
+            if not np.array_equal(r[i], want[i]):
+                print("MISMATCH", name, fusion, order, i, seed)
+                sys.exit(1)
+            checks += 1
+    hq = [Q[i].cpu().numpy().view(np.uint32) for i in range(k)]
+    pin = cp.PinnedArray(N)
+    res = [None] * k
+
+    def call(i):
+        if i % 2:
+            res[i] = srv.respond_array(hq[i])
+        else:
+            res[i] = grp.respond_array(hq[i])
+
+    ts = [threading.Thread(target=call, args=(i,)) for i in range(k)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    pin.array[:] = hq[0]
+    res.append(srv.respond_array(pin.array))
+    res.append(grp.respond_array(pin.array))
+    pin.close()
+    for i, r in enumerate(res):
+        w = want[i] if i < k else want[0]
+        if not np.array_equal(r, w):
+            print("MISMATCH host", i, seed)
+            sys.exit(1)
+        checks += 1
+    rounds += 1
+print(f"soak ok: {rounds} rounds, {checks} responses checked against exact 64-bit sums")
