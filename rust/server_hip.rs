@@ -79,10 +79,23 @@ impl Server {
             return Err(map_status(st, SERVER_SETUP_MAX_ATTEMPT_COUNT));
         }
 
-        let mut dev = core::ptr::null_mut();
-        let st = unsafe { sys::cpir_device_open(0, &mut dev) }; // replaces gpu_utils::setup_gpu(), gpu_utils.rs:25
-        if st != sys::CPIR_OK {
-            return Err(map_status(st, SERVER_SETUP_MAX_ATTEMPT_COUNT));
+        // replaces gpu_utils::setup_gpu(), gpu_utils.rs:25.  CHALAMET_HIP_DEVICES=0,1,2,3 splits the database over several GPUs of
+        // this process behind the one handle (cpir_server_setup_kv_multi); default: device 0.
+        let ordinals: Vec<i32> = std::env::var("CHALAMET_HIP_DEVICES")
+            .ok()
+            .map(|s| s.split(',').filter_map(|x| x.trim().parse().ok()).collect())
+            .filter(|v: &Vec<i32>| !v.is_empty())
+            .unwrap_or_else(|| vec![0]);
+        let mut devs: Vec<*mut sys::cpir_device> = Vec::with_capacity(ordinals.len());
+        let close_all = |devs: &Vec<*mut sys::cpir_device>| devs.iter().for_each(|d| unsafe { sys::cpir_device_close(*d) });
+        for o in &ordinals {
+            let mut dev = core::ptr::null_mut();
+            let st = unsafe { sys::cpir_device_open(*o, &mut dev) };
+            if st != sys::CPIR_OK {
+                close_all(&devs);
+                return Err(map_status(st, SERVER_SETUP_MAX_ATTEMPT_COUNT));
+            }
+            devs.push(dev);
         }
 
         let mut hint_words = vec![0u32; hint_len.div_ceil(4)]; // 4-byte aligned backing store for the wire image
@@ -90,10 +103,16 @@ impl Server {
         let mut handle = core::ptr::null_mut();
         let mut written = 0usize;
         let st = unsafe {
-            sys::cpir_server_setup_kv(dev, ARITY, seed_μ.as_ptr(), &flat, core::ptr::null(), SERVER_SETUP_MAX_ATTEMPT_COUNT as u32,
-                                      hint_words.as_mut_ptr().cast(), hint_len, &mut written, filter_param_bytes.as_mut_ptr(), &mut handle)
+            if devs.len() == 1 {
+                sys::cpir_server_setup_kv(devs[0], ARITY, seed_μ.as_ptr(), &flat, core::ptr::null(), SERVER_SETUP_MAX_ATTEMPT_COUNT as u32,
+                                          hint_words.as_mut_ptr().cast(), hint_len, &mut written, filter_param_bytes.as_mut_ptr(), &mut handle)
+            } else {
+                sys::cpir_server_setup_kv_multi(devs.as_ptr(), devs.len() as u32, ARITY, seed_μ.as_ptr(), &flat, core::ptr::null(),
+                                                SERVER_SETUP_MAX_ATTEMPT_COUNT as u32, hint_words.as_mut_ptr().cast(), hint_len, &mut written,
+                                                filter_param_bytes.as_mut_ptr(), &mut handle)
+            }
         };
-        unsafe { sys::cpir_device_close(dev) }; // the server keeps its own reference on the device
+        close_all(&devs); // the server keeps its own references on the devices
         if st != sys::CPIR_OK {
             return Err(map_status(st, SERVER_SETUP_MAX_ATTEMPT_COUNT));
         }
