@@ -67,6 +67,7 @@ def main() -> int:
                     help="also time the FULL Server::setup(seed, kv database) incl. filter construction and row encoding "
                          "(builds a synthetic n-key database on the host: ~1.1 GB at cfg2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-read-ceiling", action="store_true", help="skip the live read-only-stream probe (roofline.read_ceiling_GBps)")
     ap.add_argument("--no-host-path", action="store_true", help="skip timing Server.respond on host buffers (PCIe inclusive)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
     ap.add_argument("--tune", default="", help="comma list key=value for cpir_tuning_set, e.g. respond.rows_per_unit=16")
@@ -83,6 +84,12 @@ def main() -> int:
     ap.add_argument("--verify", action="store_true",
                     help="rank 0 re-derives the step's responses with the CPU oracle from the full synthetic DB (small configs only)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` with no launcher around it: start the N ranks ourselves, as a CHILD process, before anything in this
+    # process has touched the GPU (no torch import yet, no HIP call) -- never exec, never re-launch later.  Under
+    # torch.distributed.run (WORLD_SIZE set) this is skipped and the process is one rank.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.group_child and args.shard_of <= 1:
+        return launch_ranks(args.gpus)
 
     import torch
     import torch.distributed as dist
@@ -127,9 +134,9 @@ def main() -> int:
     full_layout = cp.dtc_layout_for(N, C, b)  # packing of the resident DB (dense64 where offered)
 
     # ---- this rank's shard of the synthetic encoded DB, generated in HBM, packed, and D freed ---------------------------
-    lo, hi = shard_range(N, full_layout.slots_per_chunk, rank, world)
+    lo, hi = shard_range(N, full_layout, rank, world)
     if args.shard_of > 1 and world == 1:
-        lo, hi = shard_range(N, full_layout.slots_per_chunk, 0, args.shard_of)
+        lo, hi = shard_range(N, full_layout, 0, args.shard_of)
     t0 = time.time()
     D_dev = torch.empty(((hi - lo), C), dtype=torch.int32, device="cuda")
     if hi > lo:
@@ -241,6 +248,8 @@ def main() -> int:
         "value": round(qps, 2),
         "unit": "queries/s",
         "n_gpus": world,
+        "ranks": dist.get_world_size() if world > 1 else 1,  # what the process group itself reports
+        "backend": (dist.get_backend() if world > 1 else None),  # "nccl" = RCCL over xGMI on ROCm
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -283,18 +292,30 @@ def main() -> int:
     }
     if args.shard_of > 1 and world == 1:
         result["config"]["sharding"] = f"TUNING RUN: rank 0's shard of a {args.shard_of}-way split, alone, no collective"
-    # HBM traffic per launch cannot be sampled from inside this process (PMC counters need rocprofv3 around it); the last
-    # committed counter pass for this exact workload (scripts/profile_gpu.sh -> profiles/respond_traffic.json) is quoted.
-    traffic_file = os.path.join(ROOT, "profiles", "respond_traffic.json")
-    if world == 1 and args.config == "cfg2" and os.path.exists(traffic_file):
-        try:
-            with open(traffic_file) as fh:
-                tr = json.load(fh)
-            if int(tr.get("algorithmic_bytes_per_pass", 0)) == launch_bytes_q and tr.get("packing", "reference") == packing:
-                result["roofline"]["traffic"] = int(tr["traffic_bytes_per_pass"] * passes_per_launch)
-                result["roofline"]["traffic_source"] = "profiles/respond_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"
-        except (OSError, ValueError, KeyError):
-            pass
+    # `frac` is SURVEY.md 8(d)'s figure: ALGORITHMIC bytes (the reference packing) over the launch time, against the 8 TB/s spec.  The
+    # resident layout is tighter than the reference packing, so the bytes the kernel really moves are reported beside it, as a fraction
+    # of spec (`frac_moved`) and of what a bare read-only stream reaches on THIS device (`frac_vs_read_ceiling`, measured just now by the
+    # tool built from scripts/hbm_read_ceiling.hip, in a child process after the timed region).
+    roof = result["roofline"]
+    roof["frac_moved"] = round(roof["moved_GBps"] / HBM_PEAK_GBPS, 4)
+    roof["read_ceiling_GBps"] = None
+    roof["frac_vs_read_ceiling"] = None
+    if rank == 0 and not args.no_read_ceiling:
+        ceil = read_ceiling(min(max(4 * shard_words, 256 << 20), 4 << 30))
+        if ceil:
+            roof["read_ceiling_GBps"] = ceil["read_ceiling_GBps"]
+            roof["frac_vs_read_ceiling"] = round(roof["moved_GBps"] / ceil["read_ceiling_GBps"], 4)
+            roof["read_ceiling_note"] = f"{ceil['kernel']}; {ceil['buffer_bytes'] / 1e9:.2f} GB read once per launch, best of several launch shapes"
+    # HBM traffic per launch cannot be sampled from inside this process (PMC counters need rocprofv3 around it): the last committed
+    # counter pass for this exact workload and packing (scripts/profile_gpu.sh -> profiles/respond_traffic.json) is quoted, with the
+    # commit it was taken at and whether the kernel source has changed since.
+    if world == 1:
+        tr = committed_traffic(args.config, launch_bytes_q, packing)
+        if tr:
+            roof["traffic"] = int(tr["traffic_bytes_per_pass"] * passes_per_launch)
+            roof["traffic_source"] = ("profiles/respond_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes; "
+                                      f"NOT measured in this run) taken at commit {tr.get('git_head', 'unknown')}")
+            roof["traffic_kernel_source_unchanged"] = tr.get("kernel_source_sha256") == kernel_source_sha256()
 
     # row f3: the same queries answered 4 per pass over the database (fused batch kernel) -- reported beside the
     # headline, never as the headline: the headline streams the whole database for every single query
@@ -377,6 +398,7 @@ def main() -> int:
             result["cpu_baseline"] = cpu_baseline(sharded.local, q_pool, r_step, N, C, b, full_bytes, args.cpu_seconds, torch, stream)
         if not args.no_setup:
             result.update(setup_timing(cp, device, torch, sharded, N, C, b, mask, stream))
+            result["setup_roofline"] = setup_kernel_roofline(cp, device, torch, N, C, b, cf, mask, full_layout, stream)
         if args.setup_kv:
             result.update(setup_kv_timing(cp, device, n_keys, arity, value_bytes))
 
@@ -390,6 +412,63 @@ def main() -> int:
     if rank == 0:
         print(json.dumps(result), flush=True)
     return 0
+
+
+def launch_ranks(n: int) -> int:
+    """one rank per GPU through torch.distributed.run on 127.0.0.1 (the container hostname may not resolve); the child's stdout and
+    stderr are this process' own, so rank 0's JSON line is the only line on stdout; returns the child's exit code"""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"bench.py: --gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd)}")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def kernel_source_sha256() -> str:
+    """fingerprint of the respond kernels' sources: ties a committed counter pass to the code it measured"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ("respond_planar.hip", "respond.hip"):
+        with open(os.path.join(ROOT, "chalametpir_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(config: str, algorithmic_bytes_per_pass: int, packing: str):
+    """the record of profiles/respond_traffic.json for this workload, or None"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "respond_traffic.json")) as fh:
+            doc = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    for rec in doc.get("records", []):
+        if (rec.get("config") == config and int(rec.get("algorithmic_bytes_per_pass", 0)) == algorithmic_bytes_per_pass
+                and rec.get("packing") == packing):
+            return rec
+    return None
+
+
+def read_ceiling(nbytes: int):
+    """what a bare read-only kernel gets from this device's HBM right now (chalametpir_amd/lib/hbm_read_ceiling, a child process)"""
+    import subprocess
+
+    tool = os.path.join(ROOT, "chalametpir_amd", "lib", "hbm_read_ceiling")
+    if not os.path.exists(tool):
+        return None
+    try:
+        p = subprocess.run([tool, "--json", str(int(nbytes))], capture_output=True, text=True, timeout=60)
+        return json.loads(p.stdout.strip().splitlines()[-1]) if p.returncode == 0 else None
+    except Exception:  # noqa: BLE001 -- an optional extra must never take the headline down
+        return None
 
 
 def verify(run_step, drain, step_counter, r_step, qps_step, pool, N, C, b, mask, rank, torch):
@@ -643,6 +722,78 @@ def setup_timing(cp, device, torch, sharded, N, C, b, mask, stream):
         "setup_db_matches_bench_db": same,
         "hint_checksum": int(hint.sum(dtype=np.uint64) & 0xFFFFFFFFFFFFFFFF),
     }
+
+
+VALU_DOT2_PEAK_TMACS = 37.3  # measured issue rate of v_dot2_u32_u16 on MI355X, one lane-op per u32 MAC (scripts/valu_rate.hip)
+MFMA_I8_PEAK_TOPS = 5000.0   # dense i8 MFMA = 2 x the bf16 rate (MI355X_MICROARCH.md, Matrix cores): ~5 POP/s = 2.5e15 i8 MACs/s
+
+
+def setup_kernel_roofline(cp, device, torch, N, C, b, cf, mask, layout, stream):
+    """the two offline kernels against their roofs, each timed alone with HIP events on the launch stream, inputs resident
+    in HBM (synthetic A and D of the config's shape): the hint matmul (1774 x N by N x C, u32 wrap-around) and transpose + compress."""
+    import ctypes
+
+    R = 1774
+    D = torch.empty((N, C), dtype=torch.int32, device="cuda")
+    device.synth_fill(D, N * C, SEED_D, mask=mask, stream=stream)
+    A = torch.empty((R, N), dtype=torch.int32, device="cuda")
+    device.synth_fill(A, R * N, 0xA, stream=stream)
+    M = torch.empty((R, C), dtype=torch.int32, device="cuda")
+    dtc = torch.empty(int(layout.total_words) + int(layout.rows_padded) + 64, dtype=torch.int32, device="cuda")
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            fn()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    mm_ms = timed(lambda: device.mat_x_mat(A, D, M, R, N, C, rhs_max_bits=16, stream=stream))
+    pk_ms = timed(lambda: device.transpose_compress(D, layout, dtc, stream=stream))
+    macs = R * N * C
+    b_setup = 4 * R * N + 4 * N * C + 4 * R * C
+    b_pack_alg = 4 * N * C + 4 * C * -(-N // cf)
+    b_pack_moved = 4 * N * C + 4 * int(layout.total_words)
+    kernel = cp.mat_x_mat_kernel_name(16)
+    mfma = "mfma" in kernel
+    tmacs = macs / (mm_ms * 1e-3) / 1e12
+    out = {
+        "hint_matmul": {
+            "kernel": kernel,
+            "ms": round(mm_ms, 3),
+            "u32_TMACs_per_s": round(tmacs, 2),
+            "bound": "mfma" if mfma else "valu",
+            # one u32 x (<= 16-bit) wrap-around MAC = 4 x 2 signed-byte MACs on the matrix cores, or one v_dot2_u32_u16 lane-op on the VALU
+            "achieved": round(tmacs * 16, 1) if mfma else round(tmacs, 2),
+            "peak": MFMA_I8_PEAK_TOPS if mfma else VALU_DOT2_PEAK_TMACS,
+            "unit": "i8 TOP/s (8 i8 MACs per u32 MAC)" if mfma else "T lane-ops/s (v_dot2_u32_u16, one per u32 MAC)",
+            "frac": round(tmacs * 16 / MFMA_I8_PEAK_TOPS, 4) if mfma else round(tmacs / VALU_DOT2_PEAK_TMACS, 4),
+            "algorithmic_bytes": b_setup,
+            "hbm_GBps": round(b_setup / (mm_ms * 1e-3) / 1e9, 1),
+            "hbm_frac": round(b_setup / (mm_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+        },
+        "transpose_compress": {
+            "kernel": "planar_pack_kernel" if layout.packing == 2 else "transpose_compress_kernel",
+            "ms": round(pk_ms, 3),
+            "bound": "hbm",
+            "algorithmic_bytes": b_pack_alg,
+            "achieved": round(b_pack_alg / (pk_ms * 1e-3) / 1e9, 1),
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": round(b_pack_alg / (pk_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "moved_bytes": b_pack_moved,
+            "moved_GBps": round(b_pack_moved / (pk_ms * 1e-3) / 1e9, 1),
+        },
+        "note": "each kernel alone, one launch over the whole config, HIP events on the launch stream, synthetic A / D resident in HBM; "
+                "inside Server::setup both hide behind the host XOF (server_setup_phases_sec)",
+    }
+    del A, D, M, dtc
+    torch.cuda.empty_cache()
+    return out
 
 
 def setup_timing_sharded(cp, device, torch, dist, N, C, b, mask, lo, hi, rank, stream):

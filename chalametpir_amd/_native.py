@@ -79,8 +79,10 @@ SIGNATURES = {
     "cpir_generate_from_seed": (C.c_int, [C.c_uint64, C.c_uint64, u8p, vp]),
     "cpir_op_mat_x_mat": (C.c_int, [vp, u32p, C.c_uint64, u32p, C.c_uint64, u32p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
                                     C.c_uint32, C.c_int, vp]),
+    "cpir_mat_x_mat_kernel_name": (C.c_char_p, [C.c_uint32]),
     "cpir_dtc_layout_for": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(DtcLayout)]),
     "cpir_dtc_layout_for_packing": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(DtcLayout)]),
+    "cpir_shard_unit": (C.c_uint64, [C.POINTER(DtcLayout)]),
     "cpir_op_transpose_compress": (C.c_int, [vp, u32p, C.c_uint64, C.POINTER(DtcLayout), u32p, u32p, vp]),
     "cpir_op_dtc_import": (C.c_int, [vp, u32p, C.POINTER(DtcLayout), u32p, vp]),
     "cpir_op_dtc_export": (C.c_int, [vp, u32p, C.POINTER(DtcLayout), u32p, vp]),

@@ -5,6 +5,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <list>
 #include <memory>
 #include <thread>
 
@@ -360,17 +361,35 @@ class BackgroundDisposer {
  public:
   ~BackgroundDisposer() {
     std::lock_guard<std::mutex> lk(mu_);
-    for (std::thread& t : threads_)
-      if (t.joinable()) t.join();
+    for (Job& j : jobs_)
+      if (j.th.joinable()) j.th.join();
   }
   void run(std::function<void()> f) {
     std::lock_guard<std::mutex> lk(mu_);
-    threads_.emplace_back(std::move(f));
+    // reap what has finished since the last call: a long-lived process that rebuilds servers must not pile up joinable threads
+    for (auto it = jobs_.begin(); it != jobs_.end();) {
+      if (it->done->load(std::memory_order_acquire)) {
+        it->th.join();
+        it = jobs_.erase(it);
+      } else {
+        ++it;
+      }
+    }
+    auto done = std::make_shared<std::atomic<bool>>(false);
+    jobs_.push_back(Job{std::thread([f = std::move(f), done] {
+                          f();
+                          done->store(true, std::memory_order_release);
+                        }),
+                        done});
   }
 
  private:
+  struct Job {
+    std::thread th;
+    std::shared_ptr<std::atomic<bool>> done;
+  };
   std::mutex mu_;
-  std::vector<std::thread> threads_;
+  std::list<Job> jobs_;
 };
 static BackgroundDisposer g_disposer;
 
@@ -394,16 +413,21 @@ class PublicMatrixUpload {
   void add_target(Device* dev, uint64_t col_lo, uint64_t col_n) {
     Target t;
     t.dev = dev, t.col_lo = col_lo, t.col_n = col_n ? col_n : N_;
+    device_retain(dev);  // this object may outlive the caller's handle: it is disposed of on a background thread after setup returns
     targets_.push_back(t);
   }
   ~PublicMatrixUpload() {
+    cancel_.store(true, std::memory_order_relaxed);  // an early error return must not wait for the rest of the sponge
     join();
     for (Target& t : targets_) {
-      DeviceGuard g(t.dev->ordinal);
-      for (hipEvent_t e : t.block_ev)
-        if (e) (void)hipEventDestroy(e);
-      if (t.copy_stream) (void)hipStreamDestroy(t.copy_stream);
-      if (t.A_dev) (void)hipFree(t.A_dev);
+      {
+        DeviceGuard g(t.dev->ordinal);
+        for (hipEvent_t e : t.block_ev)
+          if (e) (void)hipEventDestroy(e);
+        if (t.copy_stream) (void)hipStreamDestroy(t.copy_stream);
+        if (t.A_dev) (void)hipFree(t.A_dev);
+      }
+      device_release(t.dev);
     }
     for (int i = 0; i < 2; i++)
       if (pinned_[i]) (void)hipHostFree(pinned_[i]);
@@ -486,6 +510,7 @@ class PublicMatrixUpload {
     uint64_t blk = 0;
     for (uint64_t r0 = 0; r0 < rows; r0 += rows_per_block_, buf ^= 1, blk++) {
       const uint64_t rb = (rows - r0 < rows_per_block_) ? rows - r0 : rows_per_block_;
+      if (cancel_.load(std::memory_order_relaxed)) return CPIR_ERR_INVALID_ARGUMENT;  // owner is being destroyed; nobody reads this
       if (blk >= 2)  // staging buffer free again on every device? (it was the source of block blk - 2)
         for (Target& t : targets_) {
           DeviceGuard g(t.dev->ordinal);
@@ -515,6 +540,7 @@ class PublicMatrixUpload {
   uint64_t rows_per_block_ = 0;
   uint8_t seed_[32];
   std::thread worker_;
+  std::atomic<bool> cancel_{false};
   int status_ = CPIR_OK;
   double xof_seconds_ = 0;
   std::mutex prog_mu_;
@@ -837,6 +863,9 @@ int cpir_dtc_layout_for(uint64_t N, uint32_t C, uint32_t b, cpir_dtc_layout* out
 int cpir_dtc_layout_for_packing(uint64_t N, uint32_t C, uint32_t b, uint32_t packing, cpir_dtc_layout* out) {
   return dtc_layout_for_packing(N, C, b, packing, out);
 }
+uint64_t cpir_shard_unit(const cpir_dtc_layout* layout) {
+  return (layout && layout->slots_per_chunk && layout->compression_factor) ? shard_unit(*layout) : 0;
+}
 
 int cpir_generate_from_seed(uint64_t rows, uint64_t cols, const uint8_t seed[CPIR_SEED_BYTE_LEN], uint32_t* out) {
   if (!seed || !out) return CPIR_ERR_INVALID_ARGUMENT;
@@ -857,6 +886,8 @@ int cpir_op_mat_x_mat(cpir_device* dev, const uint32_t* A, uint64_t lda, const u
   DeviceGuard g(dev->ordinal);
   return launch_mat_x_mat(dev, A, lda, D, ldd, M, ldm, rows, inner, cols, rhs_max_bits, accumulate, pick_stream(dev, stream));
 }
+
+const char* cpir_mat_x_mat_kernel_name(uint32_t rhs_max_bits) { return mat_x_mat_kernel_name(rhs_max_bits); }
 
 int cpir_op_transpose_compress(cpir_device* dev, const uint32_t* D, uint64_t ldd, const cpir_dtc_layout* layout, uint32_t* dtc,
                                uint32_t* or_of_entries, void* stream) {

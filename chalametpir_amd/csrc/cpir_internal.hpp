@@ -92,6 +92,8 @@ int launch_mat_x_mat(const Device* dev, const uint32_t* A, uint64_t lda, const u
                      uint64_t ldm, uint64_t rows, uint64_t inner, uint64_t cols, uint32_t rhs_max_bits, int accumulate,
                      hipStream_t stream);
 
+const char* mat_x_mat_kernel_name(uint32_t rhs_max_bits);
+
 // synth.hip
 int launch_synth_fill(const Device* dev, uint32_t* out, uint64_t count, uint64_t seed, uint64_t index0, uint32_t mask,
                       hipStream_t stream);

@@ -257,6 +257,8 @@ __global__ void __launch_bounds__(kThreads) mat_x_mat_u32_kernel(const MatArgs a
 
 }  // namespace
 
+const char* mat_x_mat_kernel_name(uint32_t rhs_max_bits) { return rhs_max_bits <= 16 ? "mat_x_mat_packed16_kernel" : "mat_x_mat_u32_kernel"; }
+
 int launch_mat_x_mat(const Device* dev, const uint32_t* A, uint64_t lda, const uint32_t* D, uint64_t ldd, uint32_t* M,
                      uint64_t ldm, uint64_t rows, uint64_t inner, uint64_t cols, uint32_t rhs_max_bits, int accumulate,
                      hipStream_t stream) {

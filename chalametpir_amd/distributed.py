@@ -19,14 +19,23 @@ from typing import Optional, Tuple
 
 from .server import Device, Server
 
-def shard_range(total_slots: int, slots_per_chunk: int, rank: int, world_size: int) -> Tuple[int, int]:
-    """Slots [begin, end) held by `rank`.  Boundaries are multiples of the packing's chunk (`cpir_dtc_layout.slots_per_chunk`:
-    cf*1024 slots for the reference packing, K*1024 for dense64) so that no packed word, 16-byte query load or chunk
-    straddles two shards; the last shard takes the ragged tail.  Shards may be empty when there are fewer chunks than
-    ranks."""
+def shard_unit(layout) -> int:
+    """Granularity of shard boundaries for a `cpir_dtc_layout`: lcm(slots_per_chunk, compression_factor) -- the same rule as
+    shard_unit() in csrc/capi.hip -- so that neither a chunk / super-tile of the device packing, nor a packed word of the reference's
+    representation (import / export), nor a 16-byte query load straddles two shards."""
+    import ctypes
+
+    from . import _native
+
+    return int(_native.load().cpir_shard_unit(ctypes.byref(layout)))
+
+
+def shard_range(total_slots: int, unit, rank: int, world_size: int) -> Tuple[int, int]:
+    """Slots [begin, end) held by `rank`.  `unit` is a `cpir_dtc_layout` (boundaries are then multiples of shard_unit(layout)) or
+    that number itself; the last shard takes the ragged tail.  Shards may be empty when there are fewer units than ranks."""
     if not (0 <= rank < world_size):
         raise ValueError("rank out of range")
-    unit = int(slots_per_chunk)
+    unit = shard_unit(unit) if hasattr(unit, "slots_per_chunk") else int(unit)
     n_units = -(-total_slots // unit)
     lo = (n_units * rank // world_size) * unit
     hi = (n_units * (rank + 1) // world_size) * unit

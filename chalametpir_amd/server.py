@@ -204,6 +204,10 @@ class PinnedArray:
             pass
 
 
+def mat_x_mat_kernel_name(rhs_max_bits: int = 16) -> str:
+    return _native.load().cpir_mat_x_mat_kernel_name(rhs_max_bits).decode()
+
+
 def tuning_set(key: str, value: int) -> None:
     _check(_native.load().cpir_tuning_set(key.encode(), int(value)))
 

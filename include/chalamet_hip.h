@@ -119,6 +119,9 @@ int cpir_op_mat_x_mat(cpir_device* dev, const uint32_t* A, uint64_t lda, const u
                       uint64_t ldm, uint64_t rows, uint64_t inner, uint64_t cols, uint32_t rhs_max_bits, int accumulate,
                       void* stream);
 
+/* Name of the kernel cpir_op_mat_x_mat runs for this rhs_max_bits (for matching rocprof traces and labelling benchmarks). */
+const char* cpir_mat_x_mat_kernel_name(uint32_t rhs_max_bits);
+
 /* Layout of the device-resident packed database ("DtC").  The logical content is exactly
  * Matrix::transpose (matrix.rs:517-527) followed by Matrix::row_wise_compress (matrix.rs:98-205): for every column c of D
  * (= row c of DtC) the N fields  f(c, n) = D[n][c] & (2^b - 1).  Two physical packings of those fields exist:
@@ -159,16 +162,23 @@ typedef struct cpir_dtc_layout {
   uint32_t rows_padded;          /* >= C, multiple of CPIR_DTC_ROW_ALIGN */
   uint64_t total_words;          /* rows_padded * words_per_row_padded (u32 words of device memory) */
   uint32_t packing;              /* CPIR_PACK_REFERENCE, CPIR_PACK_DENSE64 or CPIR_PACK_PLANAR */
-  uint32_t fields_per_word;      /* cf (per u32) for the reference packing, K (per u64) for dense64 */
-  uint32_t chunk_words;          /* u32 words of one row per chunk: 1024 (reference) or 2048 (dense64) */
-  uint64_t slots_per_chunk;      /* cf*1024 or K*1024: shard boundaries must be multiples of this */
+  uint32_t fields_per_word;      /* cf (per u32) for the reference packing, K (per u64) for dense64, 0 for planar */
+  uint32_t chunk_words;          /* u32 words of one row per chunk: 1024 (reference) or 2048 (dense64); planar: u32 words of one
+                                    super-tile = (8 + b - 8) * 256 */
+  uint64_t slots_per_chunk;      /* cf*1024 (reference), K*1024 (dense64), 512 (planar); see cpir_shard_unit */
 } cpir_dtc_layout;
 #define CPIR_DTC_WORD_ALIGN 1024u
 #define CPIR_DTC_ROW_ALIGN 16u
 
-/* Default layout for a database shape: dense64 where it is offered (b in {7, 9, 11, 12}: denser than the reference packing
- * and within the kernels' register budget), the reference packing otherwise; cpir_tuning_set("layout.dense", 0) forces the reference packing process-wide. */
+/* Default layout for a database shape: planar where it is offered (b >= 9: every BASELINE config; the matrix-core respond), else
+ * dense64 where it is offered (b = 7), else the reference packing (b in {4, 5, 6, 8}).  cpir_tuning_set("layout.planar", 0) /
+ * ("layout.dense", 0) switch the first two off process-wide (then b in {9, 11, 12} fall to dense64, the rest to the reference packing). */
 int cpir_dtc_layout_for(uint64_t num_slots, uint32_t num_cols, uint32_t mat_elem_bit_len, cpir_dtc_layout* out);
+/* Granularity of shard boundaries along the filter slots for this layout: lcm(slots_per_chunk, compression_factor).  A multi-GPU
+ * partition whose boundaries are multiples of it splits no chunk / super-tile of the device packing, no packed word of the
+ * reference's representation (import / export) and no 16-byte query load.  cpir_server_setup_multi and
+ * chalametpir_amd.distributed.shard_range both use it.  0 for a NULL / invalid layout. */
+uint64_t cpir_shard_unit(const cpir_dtc_layout* layout);
 /* Explicit packing choice (CPIR_ERR_INVALID_ARGUMENT if that packing is not offered for b). */
 int cpir_dtc_layout_for_packing(uint64_t num_slots, uint32_t num_cols, uint32_t mat_elem_bit_len, uint32_t packing,
                                 cpir_dtc_layout* out);
@@ -298,8 +308,10 @@ int cpir_hint_partial_device(cpir_device* dev, const uint8_t seed_mu[CPIR_SEED_B
 
 /* Build a server from matrices that already live on the device (multi-GPU shards, benchmarks):
  * D_dev is N_shard x C (ldd) on `dev`; the shard holds global slots [slot_offset, slot_offset + N_shard) of a
- * database with `total_slots` slots.  Shards are packed independently, so any slot_offset is valid; multiples of
- * layout.slots_per_chunk (what chalametpir_amd.distributed.shard_range produces) keep the 16-byte query loads aligned. */
+ * database with `total_slots` slots.  Shards are packed independently, so any slot_offset gives correct partial responses (the
+ * kernels fall back to guarded scalar query loads when slot_offset is not a multiple of 4); multiples of cpir_shard_unit() -- what
+ * chalametpir_amd.distributed.shard_range produces -- keep the 16-byte query loads aligned and let the shards' exported compressed
+ * matrices tile the whole one.  CPIR_ERR_SHARD_RANGE: slot_offset + N_shard > total_slots. */
 int cpir_server_from_device_matrix(cpir_device* dev, const uint32_t* D_dev, uint64_t ldd, uint64_t N_shard, uint32_t C,
                                    uint32_t mat_elem_bit_len, uint64_t slot_offset, uint64_t total_slots, void* stream,
                                    cpir_server** out);

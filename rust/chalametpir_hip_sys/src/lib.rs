@@ -85,9 +85,11 @@ unsafe extern "C" {
     pub fn cpir_host_free(p: *mut core::ffi::c_void);
     pub fn cpir_dtc_layout_for(num_slots: u64, num_cols: u32, mat_elem_bit_len: u32, out: *mut cpir_dtc_layout) -> c_int;
     pub fn cpir_dtc_layout_for_packing(num_slots: u64, num_cols: u32, mat_elem_bit_len: u32, packing: u32, out: *mut cpir_dtc_layout) -> c_int;
+    pub fn cpir_shard_unit(layout: *const cpir_dtc_layout) -> u64;
 
     pub fn cpir_op_mat_x_mat(dev: *mut cpir_device, a: *const u32, lda: u64, d: *const u32, ldd: u64, m: *mut u32, ldm: u64,
                              rows: u64, inner: u64, cols: u64, rhs_max_bits: u32, accumulate: c_int, stream: *mut c_void) -> c_int;
+    pub fn cpir_mat_x_mat_kernel_name(rhs_max_bits: u32) -> *const c_char;
     pub fn cpir_op_transpose_compress(dev: *mut cpir_device, d: *const u32, ldd: u64, layout: *const cpir_dtc_layout,
                                       dtc: *mut u32, or_of_entries: *mut u32, stream: *mut c_void) -> c_int;
     pub fn cpir_op_dtc_import(dev: *mut cpir_device, compressed: *const u32, layout: *const cpir_dtc_layout, dtc: *mut u32,

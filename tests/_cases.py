@@ -27,3 +27,16 @@ def wire(mat):
 def unwire(b):
     rows, cols = np.frombuffer(b[:8], dtype="<u4")
     return np.frombuffer(b[8:], dtype="<u4").reshape(rows, cols)
+
+
+def synth_u32_at(indices, seed, mask=0xFFFFFFFF):
+    """the counter-based synthetic generator (csrc/synth.hip, oracle or_synth_u64) at ARBITRARY indices, vectorised in numpy:
+    hi32(splitmix64 finaliser of (seed, index)) & mask.  A third, independent statement of the same function, so that tests can
+    rebuild single columns of a 30 GB matrix on the host."""
+    with np.errstate(over="ignore"):
+        idx = np.asarray(indices, dtype=np.uint64)
+        z = np.uint64(seed) * np.uint64(0xD1342543DE82EF95) + (idx + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return ((z >> np.uint64(32)).astype(np.uint32)) & np.uint32(mask)

@@ -32,6 +32,22 @@ def test_bench_multirank_on_one_gpu(world, config):
     assert out["hint_checksum"] == ref["hint_checksum"] and out["server_setup_wall_sec"] > 0
 
 
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (what the driver runs for its scaling table) must start 2 ranks by
+    itself -- as a child torch.distributed.run, before this process touches the GPU -- and print ONE line from rank 0"""
+    env = dict(os.environ, CPIR_BENCH_BACKEND="gloo", CPIR_BENCH_SHARE_DEVICE="1", OMP_NUM_THREADS="8")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "tiny", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-setup", "--verify", "--queries-per-step", "8", "--query-pool", "16"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["backend"] == "gloo" and out["verified_vs_oracle"] is True
+
+
 def test_bench_single_rank_verify():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "cfg1", "--steps", "2", "--warmup", "1", "--no-setup",
            "--no-cpu-baseline", "--verify", "--group-shards", "3"]
@@ -63,6 +79,10 @@ def test_bench_json_contract():
     roof = d["roofline"]
     assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s") and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and "traffic" in roof
+    # the bytes really moved (the resident layout is tighter than the reference packing), against spec and against a live read-only probe
+    assert abs(roof["frac_moved"] - roof["moved_GBps"] / roof["peak"]) < 1e-3 and roof["frac_moved"] <= roof["frac"] + 1e-3
+    assert roof["read_ceiling_GBps"] > 1000 and abs(roof["frac_vs_read_ceiling"] - roof["moved_GBps"] / roof["read_ceiling_GBps"]) < 1e-3
+    assert d["ranks"] == 1 and d["backend"] is None
     assert abs(d["value"] - d["config"]["queries_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
     cpu = d["cpu_baseline"]
     assert cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1 and cpu["value"] > 0 and isinstance(cpu["sample"], str)
