@@ -777,7 +777,7 @@ def setup_kernel_roofline(cp, device, torch, N, C, b, cf, mask, layout, stream):
             "hbm_frac": round(b_setup / (mm_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
         },
         "transpose_compress": {
-            "kernel": "planar_pack_kernel" if layout.packing == 2 else "transpose_compress_kernel",
+            "kernel": "planar_pack_stream_kernel" if layout.packing == 2 else "transpose_compress_kernel",
             "ms": round(pk_ms, 3),
             "bound": "hbm",
             "algorithmic_bytes": b_pack_alg,

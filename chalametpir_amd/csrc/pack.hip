@@ -335,6 +335,167 @@ __global__ void __launch_bounds__(kThreads) planar_pack_kernel(const uint32_t* _
   }
 }
 
+// ---- planar packing from D, the setup path: no LDS transpose, no block barrier -----------------------------------------------------
+// One WAVE builds one unit = 64 columns (4 column tiles) x one super-tile step (512 slots); the 4 waves of a block take 4 adjacent
+// 64-column stripes of the same rows, so a block reads 1 KiB contiguous of every D row it touches.  Lane (g, lc) owns columns
+// 4*lc .. 4*lc+3 of the stripe and the 16-slot group g: per k-block it loads 16 rows x 16 bytes (the wave: 4 rows x 256 B per
+// instruction, 16 KiB in flight), and then HOLDS, for each of its 4 columns, the 16 consecutive slots that make one 16-byte piece of the
+// MFMA operand image -- the transpose happens in registers (v_perm_b32 byte gathers).  The bit planes of a (column, group) span all 8
+// k-blocks of the step and are accumulated in registers across them.  Pieces leave through a wave-private, swizzled 4 KiB LDS window that
+// only re-orders them so that every global store instruction writes 1 KiB contiguous.
+// Per-column field sums (correction term of the signed-byte arithmetic): v_sad_u8 over the packed low bytes + popcounts of the planes.
+__device__ __forceinline__ uint32_t gather_byte4(uint32_t x, uint32_t y, uint32_t z, uint32_t w, uint32_t sel01) {
+  const uint32_t p01 = __builtin_amdgcn_perm(y, x, sel01);  // byte 0 = x.byte[k], byte 1 = y.byte[k]   (sel01 = k | (4 + k) << 8)
+  const uint32_t p23 = __builtin_amdgcn_perm(w, z, sel01);
+  return __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+}
+
+// position of 16-byte piece p = 64*T + 16*g + 4*a + i inside a wave's staging window: the low two bits are XOR-ed with (a >> 1) | (T & 1) << 1
+// so that the 8 lanes a ds_write_b128 serves per cycle (a = 0..3, two values of T; i and g fixed) hit 8 different 16-byte bank groups;
+// a permutation inside aligned groups of 4 pieces, so the linear read-back stays conflict-free
+__device__ __forceinline__ uint32_t stage_swz(uint32_t p) { return p ^ (((p >> 3) & 1u) | (((p >> 6) & 1u) << 1)); }
+
+struct PackStreamArgs {
+  const uint32_t* D;
+  uint64_t ld, N;
+  uint32_t C, col_tiles, stripe_groups, ks_total;
+  uint4* tiles;
+  uint32_t* colsum;
+  uint32_t* or_of_entries;
+};
+
+// GUARD: this step reaches past the last slot (only the last step of a database whose N is not a multiple of 512)
+template <int HB, bool VEC, bool GUARD>
+__device__ __forceinline__ void pack_stream_unit(const PackStreamArgs& a, uint4* my_stage, uint32_t lane, uint32_t stripe, uint32_t ks) {
+  constexpr uint32_t ST16 = (8 + HB) * 64;  // uint4 per super-tile
+  constexpr uint32_t HMASK = ((1u << HB) - 1u) * 0x01010101u;
+  const uint32_t g = lane >> 4, lc = lane & 15;
+  const uint32_t c0 = stripe * 64 + 4 * lc;  // this lane's first column
+  const uint64_t n0 = (uint64_t)ks * CPIR_PLANAR_SLOTS_PER_TILE;
+  bool cvalid[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) cvalid[i] = c0 + i < a.C;
+  // VEC (ld and c0 multiples of 4, D 16-byte aligned): c0 < C <= ld implies c0 + 3 < ld, so a lane either loads 16 valid bytes of its
+  // rows or lies wholly past C, reads column 0.. of the same rows instead and zeroes them
+  const uint32_t csafe = cvalid[0] ? c0 : 0;
+  const uint32_t piece0 = 64 * (lc >> 2) + 16 * g + 4 * (lc & 3);
+
+  uint32_t plane[4][HB][4];
+  uint32_t lowsum[4] = {0, 0, 0, 0}, seen = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int p = 0; p < HB; p++)
+#pragma unroll
+      for (int w = 0; w < 4; w++) plane[i][p][w] = 0;
+
+#pragma unroll
+  for (int kb = 0; kb < 8; kb++) {
+    uint32_t v[16][4];
+    const uint64_t nb = n0 + 64 * kb + 16 * g;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint64_t n = nb + j;
+      const uint64_t nr = (!GUARD || n < a.N) ? n : a.N - 1;  // clamped rows are zeroed below
+      if constexpr (VEC) {
+        const uint4 t = *reinterpret_cast<const uint4*>(a.D + nr * a.ld + csafe);
+        v[j][0] = t.x, v[j][1] = t.y, v[j][2] = t.z, v[j][3] = t.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[j][i] = a.D[nr * a.ld + (cvalid[i] ? c0 + i : 0)];
+      }
+    }
+    uint32_t seen_kb = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const bool rv = !GUARD || nb + j < a.N;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        v[j][i] = (rv && cvalid[i]) ? v[j][i] : 0u;
+        seen_kb |= v[j][i];
+      }
+    }
+    seen |= seen_kb;
+    asm volatile("" : "+v"(seen));  // materialise here: otherwise the OR tree over all 8 k-blocks is built at the end and every value lives until then
+    uint32_t W[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        const uint32_t lo = gather_byte4(v[4 * d][i], v[4 * d + 1][i], v[4 * d + 2][i], v[4 * d + 3][i], 0x0400u);
+        lowsum[i] = __builtin_amdgcn_sad_u8(lo, 0u, lowsum[i]);
+        W[i][d] = lo ^ 0x80808080u;  // signed-byte operand
+        // bits 8.. of the four fields, one per byte (fields are masked to b bits: matrix.rs:121,149,181), spread over the planes:
+        // plane p, dword kb >> 1, bit 8*jj + 4*(kb & 1) + d  <-  bit 8+p of slot 64*kb + 16*g + 4*d + jj
+        const uint32_t hi = gather_byte4(v[4 * d][i], v[4 * d + 1][i], v[4 * d + 2][i], v[4 * d + 3][i], 0x0501u) & HMASK;
+#pragma unroll
+        for (int p = 0; p < HB; p++) plane[i][p][kb >> 1] |= ((hi >> p) & 0x01010101u) << (4 * (kb & 1) + d);
+      }
+    // materialise the accumulators now (as `seen` above): the compiler would otherwise sink this k-block's plane arithmetic to where the
+    // planes are stored, after the last k-block, and keep all 64 loaded values of all 8 k-blocks alive (512 registers + scratch)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      asm volatile("" : "+v"(lowsum[i]));
+#pragma unroll
+      for (int p = 0; p < HB; p++) asm volatile("" : "+v"(plane[i][p][kb >> 1]));
+    }
+    // the four pieces of this lane -> their places in the four tiles' k-block kb, via the wave's staging window
+#pragma unroll
+    for (int i = 0; i < 4; i++) my_stage[stage_swz(piece0 + i)] = make_uint4(W[i][0], W[i][1], W[i][2], W[i][3]);
+    __builtin_amdgcn_wave_barrier();  // LDS serves a wave's accesses in order; this only pins the compiler's schedule
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint4 x = my_stage[stage_swz(64 * k + lane)];
+      const uint32_t T = stripe * 4 + k;
+      if (T < a.col_tiles) a.tiles[((uint64_t)T * a.ks_total + ks) * ST16 + kb * 64 + lane] = x;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // one k-block's 16 loads per lane in flight at a time (16 KiB per wave); the other waves of the SIMD hide the latency
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int p = 0; p < HB; p++) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) my_stage[stage_swz(piece0 + i)] = make_uint4(plane[i][p][0], plane[i][p][1], plane[i][p][2], plane[i][p][3]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint4 x = my_stage[stage_swz(64 * k + lane)];
+      const uint32_t T = stripe * 4 + k;
+      if (T < a.col_tiles) a.tiles[((uint64_t)T * a.ks_total + ks) * ST16 + 512 + p * 64 + lane] = x;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // column sums of the fields of this step: low bytes + 2^(8+p) * (ones in plane p), summed over the four slot groups
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    uint32_t sum = lowsum[i];
+#pragma unroll
+    for (int p = 0; p < HB; p++)
+      sum += (uint32_t)(__builtin_popcount(plane[i][p][0]) + __builtin_popcount(plane[i][p][1]) + __builtin_popcount(plane[i][p][2]) +
+                        __builtin_popcount(plane[i][p][3])) << (8 + p);
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    if (g == 0 && sum) atomicAdd(a.colsum + c0 + i, sum);  // sum != 0 implies c0 + i < C
+  }
+  if (a.or_of_entries) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) seen |= __shfl_xor(seen, off, 64);
+    if (lane == 0 && seen) atomicOr(a.or_of_entries, seen);
+  }
+}
+
+// GUARD = false: steps [0, ks_count) all lie inside the database; GUARD = true: the one last step of a database whose slot count is not
+// a multiple of 512 (its own launch, so that its clamps and selects do not cost the main kernel registers)
+template <int HB, bool VEC, bool GUARD>
+__global__ void __launch_bounds__(kThreads) planar_pack_stream_kernel(const PackStreamArgs a, uint32_t ks_first) {
+  __shared__ uint4 stage[kThreads / 64][256];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t sg = blockIdx.x % a.stripe_groups;  // stripe group fastest: co-resident blocks read whole rows of D
+  const uint32_t ks = ks_first + blockIdx.x / a.stripe_groups;
+  pack_stream_unit<HB, VEC, GUARD>(a, stage[wave], lane, sg * 4 + wave, ks);
+}
+
 // field (n, c) of a planar image
 __device__ __forceinline__ uint32_t planar_field(const uint8_t* bytes, uint64_t n, uint32_t c, uint32_t hb, uint32_t ks_total) {
   const uint32_t T = c >> 4, cl = c & 15;
@@ -372,13 +533,45 @@ int launch_planar_pack(const uint32_t* src, uint64_t ld, bool from_ref, const cp
   if (hb == 0 || ks_total > 0x7fffffffull || col_tiles > 65535u) return CPIR_ERR_INVALID_ARGUMENT;
   uint32_t* colsum = dtc + (uint64_t)L.rows_padded * L.words_per_row_padded;
   CPIR_HIP_TRY(hipMemsetAsync(colsum, 0, (size_t)L.rows_padded * sizeof(uint32_t), stream));
-  const dim3 grid((unsigned)ks_total, col_tiles);
-  if (from_ref)
+  if (from_ref) {
+    const dim3 grid((unsigned)ks_total, col_tiles);
     hipLaunchKernelGGL((planar_pack_kernel<true>), grid, dim3(kThreads), 0, stream, src, ld, L.num_slots, L.num_cols, L.mat_elem_bit_len,
                        L.compression_factor, hb, (uint32_t)ks_total, reinterpret_cast<uint4*>(dtc), colsum, or_of_entries);
-  else
-    hipLaunchKernelGGL((planar_pack_kernel<false>), grid, dim3(kThreads), 0, stream, src, ld, L.num_slots, L.num_cols, L.mat_elem_bit_len,
-                       L.compression_factor, hb, (uint32_t)ks_total, reinterpret_cast<uint4*>(dtc), colsum, or_of_entries);
+    CPIR_HIP_TRY(hipGetLastError());
+    return CPIR_OK;
+  }
+  const uint32_t stripe_groups = (col_tiles + 15) / 16;  // 4 waves x 4 tiles per block
+  if (ks_total * stripe_groups > 0x7fffffffull) return CPIR_ERR_INVALID_ARGUMENT;
+  const uint64_t full_steps = L.num_slots / CPIR_PLANAR_SLOTS_PER_TILE;  // steps that lie wholly inside the database
+  const bool vec = (ld % 4 == 0) && (reinterpret_cast<uintptr_t>(src) % 16 == 0);
+  PackStreamArgs pa;
+  pa.D = src, pa.ld = ld, pa.N = L.num_slots, pa.C = L.num_cols, pa.col_tiles = col_tiles, pa.stripe_groups = stripe_groups;
+  pa.ks_total = (uint32_t)ks_total, pa.tiles = reinterpret_cast<uint4*>(dtc), pa.colsum = colsum, pa.or_of_entries = or_of_entries;
+#define LAUNCH_PP2(HB_, VEC_)                                                                                                       \
+  do {                                                                                                                              \
+    if (full_steps)                                                                                                                 \
+      hipLaunchKernelGGL((planar_pack_stream_kernel<HB_, VEC_, false>), dim3((unsigned)(full_steps * stripe_groups)), dim3(kThreads), \
+                         0, stream, pa, 0u);                                                                                        \
+    if (full_steps < ks_total)                                                                                                      \
+      hipLaunchKernelGGL((planar_pack_stream_kernel<HB_, VEC_, true>), dim3(stripe_groups), dim3(kThreads), 0, stream, pa,         \
+                         (uint32_t)full_steps);                                                                                     \
+  } while (0)
+#define LAUNCH_PP(HB_)               \
+  do {                               \
+    if (vec) LAUNCH_PP2(HB_, true);  \
+    else LAUNCH_PP2(HB_, false);     \
+  } while (0)
+  switch (hb) {
+    case 1: LAUNCH_PP(1); break;
+    case 2: LAUNCH_PP(2); break;
+    case 3: LAUNCH_PP(3); break;
+    case 4: LAUNCH_PP(4); break;
+    case 5: LAUNCH_PP(5); break;
+    case 6: LAUNCH_PP(6); break;
+    default: return CPIR_ERR_INVALID_ARGUMENT;
+  }
+#undef LAUNCH_PP2
+#undef LAUNCH_PP
   CPIR_HIP_TRY(hipGetLastError());
   return CPIR_OK;
 }
