@@ -603,9 +603,17 @@ static int setup_from_host_matrix(Device* dev, PublicMatrixUpload& upA, const ui
   // exact only if every entry is < 2^16, which holds for every encoded DB (entries < 2^b <= 2^14) and is verified here
   const uint32_t rhs_bits = (ored >> 16) ? 32u : 16u;
   // The hint in row chunks, each launched as soon as its rows of A are on their way to HBM: hint rows [r, r + 128) need only
-  // those rows of A, so all but the last chunk's matmul hides behind the sponge (the whole hint costs ~73 ms at 2^20 keys).
+  // those rows of A, so all but the last chunk's matmul hides behind the sponge.
   const uint32_t* A_dev = upA.device_ptr();
   const uint64_t chunk = 128;
+  // matrix-core path: D is turned into its operand form ONCE and every chunk multiplies against that
+  DevBuf rhs;
+  const bool mfma = mfma_matmul_enabled() && mfma_matmul_applicable(A_dev, N, N, C, rhs_bits);
+  if (mfma) {
+    TRY_(hipMalloc(&rhs.p, (size_t)mfma_rhs_workspace_bytes(N, C, chunk)));
+    st = launch_rhs_split(dev, (const uint32_t*)D_dev.p, C, N, C, rhs.p, stream);
+    if (st != CPIR_OK) return fail(st);
+  }
   double t_wait = 0, t_last = now_seconds();
   for (uint64_t r0 = 0; r0 < CPIR_LWE_DIMENSION; r0 += chunk) {
     const uint64_t rb = (CPIR_LWE_DIMENSION - r0 < chunk) ? CPIR_LWE_DIMENSION - r0 : chunk;
@@ -614,7 +622,8 @@ static int setup_from_host_matrix(Device* dev, PublicMatrixUpload& upA, const ui
     if (st != CPIR_OK) return fail(st);
     t_last = now_seconds();
     t_wait += t_last - t0;
-    st = launch_mat_x_mat(dev, A_dev + r0 * N, N, (const uint32_t*)D_dev.p, C, (uint32_t*)M_dev.p + r0 * C, C, rb, N, C, rhs_bits, 0, stream);
+    if (mfma) st = launch_mat_x_mat_mfma(dev, A_dev + r0 * N, N, rhs.p, N, C, (uint32_t*)M_dev.p + r0 * C, C, rb, chunk, 0, stream);
+    else st = launch_mat_x_mat(dev, A_dev + r0 * N, N, (const uint32_t*)D_dev.p, C, (uint32_t*)M_dev.p + r0 * C, C, rb, N, C, rhs_bits, 0, stream);
     if (st != CPIR_OK) return fail(st);
   }
   TRY_(hipStreamSynchronize(stream));
@@ -627,6 +636,7 @@ static int setup_from_host_matrix(Device* dev, PublicMatrixUpload& upA, const ui
   srv->setup_timings[6] = now_seconds() - t0;
 #undef TRY_
   D_dev.dispose_async(dev->ordinal);  // 4*N*C bytes
+  rhs.dispose_async(dev->ordinal);
   *out = srv;
   return CPIR_OK;
 }

@@ -93,6 +93,16 @@ int launch_mat_x_mat(const Device* dev, const uint32_t* A, uint64_t lda, const u
                      hipStream_t stream);
 
 const char* mat_x_mat_kernel_name(uint32_t rhs_max_bits);
+// matmul_mfma.hip: the same product on the i8 matrix cores, for right-hand sides below 2^16 (every encoded database).  The right-hand
+// side is prepared ONCE (launch_rhs_split: byte planes in MFMA operand order + column sums, into a caller-owned workspace of
+// mfma_rhs_workspace_bytes) and then multiplied by any number of row blocks of A of at most `max_rows` rows each.
+bool mfma_matmul_applicable(const uint32_t* A, uint64_t lda, uint64_t inner, uint64_t cols, uint32_t rhs_max_bits);
+uint64_t mfma_rhs_workspace_bytes(uint64_t inner, uint64_t cols, uint64_t max_rows);
+int launch_rhs_split(const Device* dev, const uint32_t* D, uint64_t ldd, uint64_t inner, uint64_t cols, void* workspace, hipStream_t stream);
+int launch_mat_x_mat_mfma(const Device* dev, const uint32_t* A, uint64_t lda, const void* workspace, uint64_t inner, uint64_t cols,
+                          uint32_t* M, uint64_t ldm, uint64_t rows, uint64_t ws_max_rows, int accumulate, hipStream_t stream);
+bool mfma_matmul_enabled();
+void set_mfma_matmul(bool on);
 
 // synth.hip
 int launch_synth_fill(const Device* dev, uint32_t* out, uint64_t count, uint64_t seed, uint64_t index0, uint32_t mask,

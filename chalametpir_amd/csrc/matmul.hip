@@ -257,7 +257,13 @@ __global__ void __launch_bounds__(kThreads) mat_x_mat_u32_kernel(const MatArgs a
 
 }  // namespace
 
-const char* mat_x_mat_kernel_name(uint32_t rhs_max_bits) { return rhs_max_bits <= 16 ? "mat_x_mat_packed16_kernel" : "mat_x_mat_u32_kernel"; }
+static std::atomic<int> g_use_mfma{1};  // cpir_tuning_set("matmul.mfma", 0) keeps the VALU kernels (A/B timing, tests of both paths)
+bool mfma_matmul_enabled() { return g_use_mfma.load() != 0; }
+void set_mfma_matmul(bool on) { g_use_mfma.store(on ? 1 : 0); }
+
+const char* mat_x_mat_kernel_name(uint32_t rhs_max_bits) {
+  return rhs_max_bits > 16 ? "mat_x_mat_u32_kernel" : (mfma_matmul_enabled() ? "mat_x_mat_mfma_kernel" : "mat_x_mat_packed16_kernel");
+}
 
 int launch_mat_x_mat(const Device* dev, const uint32_t* A, uint64_t lda, const uint32_t* D, uint64_t ldd, uint32_t* M,
                      uint64_t ldm, uint64_t rows, uint64_t inner, uint64_t cols, uint32_t rhs_max_bits, int accumulate,
@@ -266,6 +272,19 @@ int launch_mat_x_mat(const Device* dev, const uint32_t* A, uint64_t lda, const u
   if (rows == 0 || inner == 0 || cols == 0) return CPIR_ERR_INVALID_MATRIX_DIMENSION;  // Matrix::new, matrix.rs:45-55
   if (lda < inner || ldd < cols || ldm < cols) return CPIR_ERR_INVALID_ARGUMENT;
   if (rhs_max_bits == 0 || rhs_max_bits > 32) return CPIR_ERR_INVALID_ARGUMENT;
+  if (mfma_matmul_enabled() && mfma_matmul_applicable(A, lda, inner, cols, rhs_max_bits)) {
+    // the matrix-core path (matmul_mfma.hip); its prepared right-hand side lives in a stream-ordered scratch allocation
+    void* ws = nullptr;
+    CPIR_HIP_TRY(hipMallocAsync(&ws, mfma_rhs_workspace_bytes(inner, cols, rows), stream));
+    int st = launch_rhs_split(dev, D, ldd, inner, cols, ws, stream);
+    if (st == CPIR_OK) st = launch_mat_x_mat_mfma(dev, A, lda, ws, inner, cols, M, ldm, rows, rows, accumulate, stream);
+    const hipError_t fe = hipFreeAsync(ws, stream);
+    if (st == CPIR_OK && fe != hipSuccess) {
+      set_last_hip_error(fe, "hipFreeAsync", __FILE__, __LINE__);
+      st = CPIR_ERR_HIP;
+    }
+    return st;
+  }
   const bool packed = rhs_max_bits <= 16;
   const uint64_t ks = packed ? 32 : 16;
 

@@ -1,0 +1,399 @@
+// matmul_mfma.hip -- the offline hint product  M = A . D  (u32, wrap-around) on the i8 matrix cores.
+//
+// Replaces gpu_utils::mat_x_mat + shaders/mat_x_mat.glsl (reference chalametpir_server/src/gpu/gpu_utils.rs:156-220,
+// chalametpir_server/shaders/mat_x_mat.glsl:26-46) == impl Mul for &Matrix (chalametpir_common/src/matrix.rs:1040-1059) whenever every entry
+// of D is below 2^16 (any encoded database: entries < 2^b <= 2^14); matmul.hip keeps the VALU kernels for general u32 right-hand sides and
+// for operands that are not 16-byte loadable.
+//
+// u32 wrap-around products are not an MFMA type, but the product splits exactly into signed-byte products (the same split as
+// respond_planar.hip, with BOTH bytes of D offset):
+//
+//   A[r][k] = sum_{i<4} 2^(8i) (as_i + 128)          as_i = byte i of A[r][k] XOR 0x80, read as a signed byte
+//   D[k][c] = (d_0 + 128) + 256 (d_1 + 128)          d_j  = byte j of D[k][c] XOR 0x80
+//
+//   sum_k A D = sum_{s<4} 2^(8s) * [ sum_{i+j=s} sum_k as_i d_j ]          <- 7 MFMAs per 16 rows x 16 columns x 64 k (i + j = 4 vanishes mod 2^32)
+//             + 0x8080 * sum_k A[r][k]  +  0x80808080 * sum_k D[k][c]  -  K * 0x80808080 * 0x8080            (mod 2^32)
+//
+// The i32 accumulators of v_mfma_i32_16x16x64_i8 wrap (scripts/mfma_i8_probe.hip), so everything is exact mod 2^32.  Products that share
+// the shift s = i + j share an accumulator, so a 16 x 16 output tile costs 4 accumulators, not 8.
+//
+// Three launches:
+//   1. rhs_split_kernel: D (inner x cols, u32 row-major) -> two byte planes in MFMA B-operand order ([column tile of 16][k-step of 64]
+//      [byte j][1 KiB]: lane 16*g + c holds bytes d_j of column c, k = 64*ks + 16*g + 0..15), zero bytes as padding, plus the column sums.
+//      Once per right-hand side: Server::setup multiplies many row blocks of A by the same D.
+//   2. mat_x_mat_mfma_kernel: 128 x 128 output tile per 512-thread block (8 waves as 2 x 4, 64 x 32 per wave, 128 accumulator registers),
+//      K in steps of 64 through double-buffered LDS (96 KiB): the D planes arrive by LDS-DMA (global_load_lds, 1 KiB pieces as stored),
+//      A is loaded 128 B per row segment, split into its four byte limbs in registers (v_perm_b32) and written as MFMA A-operand pieces;
+//      blocks that own column tile 0 also sum the rows of A.  Persistent grid: the K axis is split 8 ways by blockIdx % 8 (blocks that
+//      share an XCD then work on the same K range and share their A and D tiles in that XCD's L2), inside an XCD the 32 blocks take
+//      (row tile, column tile) pairs of one K sub-range at a time.  Results leave through u32 atomics (order-independent, exact).
+//   3. hint_fixup_kernel: adds the three correction terms.
+#include "cpir_internal.hpp"
+#include "device_bytes.hpp"
+
+namespace cpir {
+namespace {
+
+constexpr int kThreads = 256;   // rhs_split_kernel
+constexpr int kMT = 512;        // mat_x_mat_mfma_kernel: 8 waves
+constexpr uint32_t kBM = 128, kBN = 128, kBK = 64;
+constexpr uint32_t kPiecesA = 8 * 4, kPiecesB = 8 * 2;  // 1 KiB pieces per LDS buffer: [8 row tiles of 16][4 limbs], [8 column tiles of 16][2 bytes]
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------------------------
+// 1. right-hand side -> byte planes + column sums
+// ---------------------------------------------------------------------------------------------------------------
+struct SplitArgs {
+  const uint32_t* D;
+  uint64_t ld, inner;
+  uint32_t cols, ct16, stripe_groups, ks_total;  // ct16: column tiles of 16 in the planes (padded to whole 128-column block tiles)
+  uint4* planes;
+  uint32_t* colsum;
+};
+
+// One wave = 64 columns (4 column tiles) x 8 consecutive k-steps; structure and staging window as planar_pack_stream_kernel (pack.hip):
+// lane (g, lc) loads 16 rows x 16 bytes per k-step and holds, for each of its 4 columns, the 16 consecutive k of one operand piece.
+template <bool VEC>
+__global__ void __launch_bounds__(kThreads) rhs_split_kernel(const SplitArgs a) {
+  __shared__ uint4 stage[kThreads / 64][256];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t g = lane >> 4, lc = lane & 15;
+  const uint32_t sg = blockIdx.x % a.stripe_groups;
+  const uint32_t ks0 = (blockIdx.x / a.stripe_groups) * 8;
+  const uint32_t stripe = sg * 4 + wave;
+  const uint32_t c0 = stripe * 64 + 4 * lc;
+  bool cvalid[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) cvalid[i] = c0 + i < a.cols;
+  const uint32_t csafe = cvalid[0] ? c0 : 0;  // VEC: c0 < cols <= ld with c0 and ld multiples of 4, so 16 bytes at c0 are inside the row
+  uint4* const my_stage = stage[wave];
+  const uint32_t piece0 = 64 * (lc >> 2) + 16 * g + 4 * (lc & 3);
+  uint32_t sum[4] = {0, 0, 0, 0};
+
+#pragma unroll
+  for (int kk = 0; kk < 8; kk++) {
+    const uint32_t ks = ks0 + kk;
+    if (ks >= a.ks_total) break;  // wave-uniform
+    uint32_t v[16][4];
+    const uint64_t nb = (uint64_t)ks * kBK + 16 * g;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint64_t n = nb + j;
+      const uint64_t nr = n < a.inner ? n : a.inner - 1;
+      if constexpr (VEC) {
+        const uint4 t = *reinterpret_cast<const uint4*>(a.D + nr * a.ld + csafe);
+        v[j][0] = t.x, v[j][1] = t.y, v[j][2] = t.z, v[j][3] = t.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[j][i] = a.D[nr * a.ld + (cvalid[i] ? c0 + i : 0)];
+      }
+    }
+    // padding (k >= inner or column >= cols) must contribute nothing: its plane bytes are 0, i.e. the entry reads 0x8080 before the XOR
+    uint32_t W[4][2][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        uint32_t e[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const bool ok = cvalid[i] && nb + 4 * d + t < a.inner;
+          const uint32_t x = v[4 * d + t][i];
+          sum[i] += ok ? x : 0u;
+          e[t] = ok ? x : 0x8080u;
+        }
+        W[i][0][d] = gather_byte4(e[0], e[1], e[2], e[3], 0x0400u) ^ 0x80808080u;
+        W[i][1][d] = gather_byte4(e[0], e[1], e[2], e[3], 0x0501u) ^ 0x80808080u;
+      }
+#pragma unroll
+    for (int i = 0; i < 4; i++) asm volatile("" : "+v"(sum[i]));  // keep this k-step's values from living on (see pack.hip)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) my_stage[stage_swz(piece0 + i)] = make_uint4(W[i][j][0], W[i][j][1], W[i][j][2], W[i][j][3]);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint4 x = my_stage[stage_swz(64 * k + lane)];
+        const uint32_t T = stripe * 4 + k;
+        if (T < a.ct16) a.planes[(((uint64_t)T * a.ks_total + ks) * 2 + j) * 64 + lane] = x;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    uint32_t s = sum[i];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (g == 0 && s) atomicAdd(a.colsum + c0 + i, s);  // s != 0 implies c0 + i < cols
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 2. the product
+// ---------------------------------------------------------------------------------------------------------------
+struct MfmaArgs {
+  const uint32_t* A;
+  uint64_t lda;
+  const uint4* planes;
+  uint32_t* M;
+  uint64_t ldm;
+  uint32_t* rowsum;
+  uint64_t rows, inner, cols;
+  uint32_t RT, CT, KS;  // row tiles of 128, column tiles of 128, k-steps of 64
+  uint32_t S;           // K sub-ranges per XCD range
+  uint32_t nx;          // K axis split by blockIdx % nx (8, or 1 for tiny grids)
+};
+
+__global__ void __launch_bounds__(kMT) __attribute__((amdgpu_waves_per_eu(2, 2))) mat_x_mat_mfma_kernel(const MfmaArgs a) {
+  __shared__ uint4 lds[2][(kPiecesA + kPiecesB) * 64];  // 2 x 48 KiB
+
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t wm = wave >> 2, wn = wave & 3;  // this wave's 64 x 32 part of the block tile
+  const uint32_t xcd = blockIdx.x % a.nx, slot = blockIdx.x / a.nx, slots = gridDim.x / a.nx;  // host: gridDim.x % nx == 0
+  const uint32_t ksx0 = (uint32_t)(((uint64_t)a.KS * xcd) / a.nx), ksx1 = (uint32_t)(((uint64_t)a.KS * (xcd + 1)) / a.nx);
+  const uint32_t pairs = a.RT * a.CT;
+  const uint64_t units = (uint64_t)pairs * a.S;
+
+  // ---- A staging roles: wave-instruction x = 8*j + wave (j < 4) covers 8 rows x 128 bytes: half h = x & 1 of the 64 k, rows 8*(x >> 1) .. + 7
+  const uint32_t r8 = lane >> 3, q8 = lane & 7;
+  uint32_t row_l[4], wdw[4];
+  uint32_t kq[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t x = 8 * j + wave, h = x & 1, rb = x >> 1;
+    row_l[j] = 8 * rb + r8;
+    const uint32_t q = 8 * h + q8;  // 16-byte quad of the row's 256 bytes: k = 4q .. 4q + 3
+    kq[j] = 4 * q;
+    // dword index (inside the A region of a buffer) of limb 0: piece (row tile of 16, limb), slot 16*(q >> 2) + row % 16, dword q & 3
+    wdw[j] = (((row_l[j] >> 4) * 4) * 64 + 16 * (q >> 2) + (row_l[j] & 15)) * 4 + (q & 3);
+  }
+
+  for (uint64_t u = slot; u < units; u += slots) {
+    const uint32_t sub = (uint32_t)(u / pairs), pair = (uint32_t)(u % pairs), rt = pair / a.CT, ct = pair % a.CT;
+    const uint32_t k0 = ksx0 + (uint32_t)(((uint64_t)(ksx1 - ksx0) * sub) / a.S);
+    const uint32_t k1 = ksx0 + (uint32_t)(((uint64_t)(ksx1 - ksx0) * (sub + 1)) / a.S);
+    if (k0 >= k1) continue;  // block-uniform
+
+    const uint32_t* arow[4];
+    bool rvalid[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint64_t r = (uint64_t)rt * kBM + row_l[j];
+      rvalid[j] = r < a.rows;
+      arow[j] = a.A + (rvalid[j] ? r : a.rows - 1) * a.lda;  // rows past the end re-read the last row; their outputs are dropped
+    }
+    const bool sum_rows = (ct == 0);  // exactly one block per (row tile, K sub-range) adds up the rows of A
+    uint32_t rs[4] = {0, 0, 0, 0};
+
+    v4i acc[4][2][4];
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+      for (int n = 0; n < 2; n++)
+#pragma unroll
+        for (int s = 0; s < 4; s++) acc[m][n][s] = v4i{0, 0, 0, 0};
+
+    uint4 ra[4];
+    auto load_a = [&](uint32_t ks) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint64_t k = (uint64_t)ks * kBK + kq[j];
+        // inner % 4 == 0 (host): a quad lies wholly inside or wholly outside; outside it meets zero plane bytes, so any readable address does
+        ra[j] = *reinterpret_cast<const uint4*>(arow[j] + (k < a.inner ? k : 0));
+      }
+    };
+    auto dma_b = [&](uint32_t ks, uint32_t buf) {
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        const uint4* src = a.planes + (((uint64_t)(ct * 8 + wave) * a.KS + ks) * 2 + e) * 64 + lane;
+        uint4* dst = &lds[buf][(kPiecesA + wave * 2 + e) * 64];  // wave-uniform base; the DMA adds lane * 16
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    };
+    auto store_a = [&](uint32_t ks, uint32_t buf) {
+      uint32_t* base = reinterpret_cast<uint32_t*>(&lds[buf][0]);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint4 t = ra[j];
+        if (sum_rows) {
+          const bool in = rvalid[j] && (uint64_t)ks * kBK + kq[j] < a.inner;
+          rs[j] += in ? t.x + t.y + t.z + t.w : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          base[wdw[j] + i * 256] = gather_byte4(t.x, t.y, t.z, t.w, (uint32_t)i | ((4u + i) << 8)) ^ 0x80808080u;
+      }
+    };
+    auto mfma_step = [&](uint32_t buf) {
+      const uint4* A_ = &lds[buf][0];
+      const uint4* B_ = &lds[buf][kPiecesA * 64];
+      v4i bf[2][2];
+#pragma unroll
+      for (int n = 0; n < 2; n++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const uint4 t = B_[((wn * 2 + n) * 2 + j) * 64 + lane];
+          bf[n][j] = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
+        }
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        v4i af[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const uint4 t = A_[((wm * 4 + m) * 4 + i) * 64 + lane];
+          af[i] = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
+        }
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+          acc[m][n][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[0], bf[n][0], acc[m][n][0], 0, 0, 0);
+          acc[m][n][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[1], bf[n][0], acc[m][n][1], 0, 0, 0);
+          acc[m][n][2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[2], bf[n][0], acc[m][n][2], 0, 0, 0);
+          acc[m][n][3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[3], bf[n][0], acc[m][n][3], 0, 0, 0);
+          acc[m][n][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[0], bf[n][1], acc[m][n][1], 0, 0, 0);
+          acc[m][n][2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[1], bf[n][1], acc[m][n][2], 0, 0, 0);
+          acc[m][n][3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[2], bf[n][1], acc[m][n][3], 0, 0, 0);
+        }
+      }
+    };
+
+    // prologue: first k-step into buffer 0
+    load_a(k0);
+    dma_b(k0, 0);
+    store_a(k0, 0);
+    __syncthreads();  // also drains the DMA (vmcnt(0)) before anybody reads
+    for (uint32_t ks = k0; ks < k1; ks++) {
+      const uint32_t buf = (ks - k0) & 1;
+      const bool more = ks + 1 < k1;
+      if (more) {
+        load_a(ks + 1);
+        dma_b(ks + 1, buf ^ 1);  // that buffer was last read in the previous iteration, which ended with a barrier
+      }
+      mfma_step(buf);
+      if (more) store_a(ks + 1, buf ^ 1);
+      __syncthreads();
+    }
+
+    // ---- this unit's part of the output tile: sum_s acc_s << 8s, one u32 atomic per element ----
+    const uint32_t fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+      for (int n = 0; n < 2; n++) {
+        const uint64_t c = (uint64_t)ct * kBN + wn * 32 + n * 16 + fr;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const uint64_t r = (uint64_t)rt * kBM + wm * 64 + m * 16 + fq * 4 + i;
+          const uint32_t v = (uint32_t)acc[m][n][0][i] + ((uint32_t)acc[m][n][1][i] << 8) + ((uint32_t)acc[m][n][2][i] << 16) +
+                             ((uint32_t)acc[m][n][3][i] << 24);
+          if (r < a.rows && c < a.cols) atomicAdd(a.M + r * a.ldm + c, v);
+        }
+      }
+    if (sum_rows) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        uint32_t s = rs[j];
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        if (q8 == 0 && rvalid[j] && s) atomicAdd(a.rowsum + (uint64_t)rt * kBM + row_l[j], s);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3. correction terms
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) hint_fixup_kernel(uint32_t* __restrict__ M, uint64_t ldm, uint64_t rows, uint64_t cols,
+                                                               const uint32_t* __restrict__ rowsum, const uint32_t* __restrict__ colsum,
+                                                               uint32_t k_term) {
+  const uint64_t total = rows * cols;
+  for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (uint64_t)gridDim.x * kThreads) {
+    const uint64_t r = i / cols, c = i % cols;
+    M[r * ldm + c] += 0x8080u * rowsum[r] + 0x80808080u * colsum[c] - k_term;  // after the product kernel on the same stream
+  }
+}
+
+uint32_t round_up(uint32_t x, uint32_t m) { return (x + m - 1) / m * m; }
+
+}  // namespace
+
+// ---- workspace: [planes][colsum][rowsum] ------------------------------------------------------------------------------------------
+static uint64_t rhs_planes_bytes(uint64_t inner, uint64_t cols) {
+  const uint64_t ct16 = (cols + kBN - 1) / kBN * 8, ks = (inner + kBK - 1) / kBK;
+  return ct16 * ks * 2048;
+}
+static uint64_t rhs_colsum_words(uint64_t cols) { return (cols + kBN - 1) / kBN * kBN; }
+
+uint64_t mfma_rhs_workspace_bytes(uint64_t inner, uint64_t cols, uint64_t max_rows) {
+  return rhs_planes_bytes(inner, cols) + 4 * rhs_colsum_words(cols) + 4 * ((max_rows + kBM - 1) / kBM * kBM);
+}
+
+bool mfma_matmul_applicable(const uint32_t* A, uint64_t lda, uint64_t inner, uint64_t cols, uint32_t rhs_max_bits) {
+  if (rhs_max_bits > 16 || inner % 4 != 0 || lda % 4 != 0 || reinterpret_cast<uintptr_t>(A) % 16 != 0) return false;
+  const uint64_t ks = (inner + kBK - 1) / kBK, ct = (cols + kBN - 1) / kBN;
+  return ks <= 0x7fffffffull && ct * 8 <= 0xffffffu;
+}
+
+int launch_rhs_split(const Device* dev, const uint32_t* D, uint64_t ldd, uint64_t inner, uint64_t cols, void* workspace, hipStream_t stream) {
+  (void)dev;
+  if (!D || !workspace || inner == 0 || cols == 0 || ldd < cols) return CPIR_ERR_INVALID_ARGUMENT;
+  SplitArgs sa;
+  sa.D = D, sa.ld = ldd, sa.inner = inner, sa.cols = (uint32_t)cols;
+  sa.ct16 = (uint32_t)((cols + kBN - 1) / kBN * 8);
+  sa.stripe_groups = (sa.ct16 + 15) / 16;
+  sa.ks_total = (uint32_t)((inner + kBK - 1) / kBK);
+  sa.planes = reinterpret_cast<uint4*>(workspace);
+  sa.colsum = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(workspace) + rhs_planes_bytes(inner, cols));
+  CPIR_HIP_TRY(hipMemsetAsync(sa.colsum, 0, 4 * rhs_colsum_words(cols), stream));
+  const uint64_t blocks = (uint64_t)((sa.ks_total + 7) / 8) * sa.stripe_groups;
+  if (blocks > 0x7fffffffull) return CPIR_ERR_INVALID_ARGUMENT;
+  const bool vec = (ldd % 4 == 0) && (reinterpret_cast<uintptr_t>(D) % 16 == 0);
+  if (vec) hipLaunchKernelGGL(rhs_split_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, sa);
+  else hipLaunchKernelGGL(rhs_split_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, sa);
+  CPIR_HIP_TRY(hipGetLastError());
+  return CPIR_OK;
+}
+
+int launch_mat_x_mat_mfma(const Device* dev, const uint32_t* A, uint64_t lda, const void* workspace, uint64_t inner, uint64_t cols,
+                          uint32_t* M, uint64_t ldm, uint64_t rows, uint64_t ws_max_rows, int accumulate, hipStream_t stream) {
+  if (!A || !workspace || !M || rows == 0 || rows > ws_max_rows || lda < inner || ldm < cols) return CPIR_ERR_INVALID_ARGUMENT;
+  const uint8_t* ws = reinterpret_cast<const uint8_t*>(workspace);
+  MfmaArgs a;
+  a.A = A, a.lda = lda, a.M = M, a.ldm = ldm, a.rows = rows, a.inner = inner, a.cols = cols;
+  a.planes = reinterpret_cast<const uint4*>(ws);
+  const uint32_t* colsum = reinterpret_cast<const uint32_t*>(ws + rhs_planes_bytes(inner, cols));
+  a.rowsum = const_cast<uint32_t*>(colsum) + rhs_colsum_words(cols);
+  a.RT = (uint32_t)((rows + kBM - 1) / kBM), a.CT = (uint32_t)((cols + kBN - 1) / kBN), a.KS = (uint32_t)((inner + kBK - 1) / kBK);
+  // persistent grid, one block per CU (96 KiB of LDS and 2 waves per SIMD each)
+  uint32_t grid = (uint32_t)dev->num_cus;
+  a.nx = (grid % 8 == 0 && a.KS >= 64) ? 8u : 1u;
+  const uint32_t slots = grid / a.nx;
+  // K sub-ranges per XCD range: as few as make the (pair, sub-range) units a whole number of rounds of the XCD's blocks
+  const uint64_t pairs = (uint64_t)a.RT * a.CT;
+  uint64_t g = pairs, h = slots;
+  while (h) {
+    const uint64_t t = g % h;
+    g = h, h = t;
+  }
+  uint64_t S = slots / g;
+  const uint64_t ks_per_x = (a.KS + a.nx - 1) / a.nx;
+  while (S > 1 && ks_per_x / S < 8) S /= 2;  // a unit shorter than 8 k-steps is all prologue and flush
+  a.S = (uint32_t)(S ? S : 1);
+
+  CPIR_HIP_TRY(hipMemsetAsync(a.rowsum, 0, 4 * round_up((uint32_t)rows, kBM), stream));
+  if (!accumulate) CPIR_HIP_TRY(hipMemset2DAsync(M, ldm * sizeof(uint32_t), 0, cols * sizeof(uint32_t), rows, stream));
+  hipLaunchKernelGGL(mat_x_mat_mfma_kernel, dim3(grid), dim3(kMT), 0, stream, a);
+  const uint32_t k_term = (uint32_t)inner * (0x80808080u * 0x8080u);
+  uint64_t fb = (rows * cols + kThreads - 1) / kThreads;
+  if (fb > (uint64_t)dev->num_cus * 8) fb = (uint64_t)dev->num_cus * 8;
+  hipLaunchKernelGGL(hint_fixup_kernel, dim3((unsigned)fb), dim3(kThreads), 0, stream, M, ldm, rows, cols, a.rowsum, colsum, k_term);
+  CPIR_HIP_TRY(hipGetLastError());
+  return CPIR_OK;
+}
+
+}  // namespace cpir

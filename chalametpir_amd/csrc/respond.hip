@@ -376,6 +376,8 @@ extern "C" int cpir_tuning_set(const char* key, int value) {
     set_default_dense(value != 0);
   } else if (!strcmp(key, "layout.planar")) {
     set_default_planar(value != 0);
+  } else if (!strcmp(key, "matmul.mfma")) {
+    set_mfma_matmul(value != 0);
   } else {
     return CPIR_ERR_INVALID_ARGUMENT;
   }

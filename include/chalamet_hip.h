@@ -112,8 +112,10 @@ const char* cpir_xof_permutation(void);
 
 /* gpu_utils::mat_x_mat + shaders/mat_x_mat.glsl (gpu_utils.rs:156-220) == impl Mul for &Matrix (matrix.rs:1040-1059):
  *   M[r][c] (+)= sum_k A[r][k] *wrap D[k][c],  A rows x inner (leading dim lda), D inner x cols (ldd), M rows x cols (ldm).
- * rhs_max_bits: an upper bound on the bit width of every D entry (<= 16 selects the packed 16-bit dot-product
- * kernel, 32 the general u32 kernel; results are identical whenever the bound is true).
+ * rhs_max_bits: an upper bound on the bit width of every D entry: <= 16 selects the matrix-core kernel (exact signed-byte split,
+ * csrc/matmul_mfma.hip; it needs A 16-byte aligned with lda and inner multiples of 4, else the packed 16-bit dot-product kernel on
+ * the VALU runs), 32 the general u32 kernel; results are identical whenever the bound is true.  The matrix-core path keeps its
+ * prepared right-hand side (2 bytes per entry of D) in a stream-ordered scratch allocation (hipMallocAsync on `stream`).
  * accumulate != 0 adds into M (used for K-sharded / row-block pipelined hints), else M is overwritten. */
 int cpir_op_mat_x_mat(cpir_device* dev, const uint32_t* A, uint64_t lda, const uint32_t* D, uint64_t ldd, uint32_t* M,
                       uint64_t ldm, uint64_t rows, uint64_t inner, uint64_t cols, uint32_t rhs_max_bits, int accumulate,
@@ -224,7 +226,8 @@ int cpir_op_synth_fill(cpir_device* dev, uint32_t* out, uint64_t count, uint64_t
  *   (order in which one launch walks its passes; -1 = by shard size), "respond.planar_blocks_per_cu" 0..8, "respond.multi_pass_limit_mb"
  *   (unfused batches on databases above this size get one launch per query), "respond.host_pipeline_pieces" 1..64 (a lone host
  *   query is uploaded in that many pieces, each followed by the part of the kernel that needs only those slots; 1 = off, the default),
- *   "layout.dense" {0,1} and "layout.planar" {0,1}
+ *   "matmul.mfma" {0,1} (1, the default: cpir_op_mat_x_mat and the setup paths run right-hand sides below 2^16 on the i8 matrix cores;
+ *   0: on the integer VALU), "layout.dense" {0,1} and "layout.planar" {0,1}
  *   (default packing chosen by cpir_dtc_layout_for and therefore by every cpir_server_* constructor: planar where it is
  *   offered and enabled, else dense64 where offered and enabled, else the reference packing).
  * Process-wide; results are bit-identical for every setting. */
