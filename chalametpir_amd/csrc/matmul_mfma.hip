@@ -146,6 +146,7 @@ struct MfmaArgs {
   uint32_t RT, CT, KS;  // row tiles of 128, column tiles of 128, k-steps of 64
   uint32_t S;           // K sub-ranges per XCD range
   uint32_t nx;          // K axis split by blockIdx % nx (8, or 1 for tiny grids)
+  uint32_t ablate;      // diagnosis only (results are garbage): 1 no MFMA, 2 no A conversion / LDS writes, 4 no A loads, 8 no D DMA
 };
 
 __global__ void __launch_bounds__(kMT) __attribute__((amdgpu_waves_per_eu(2, 2))) mat_x_mat_mfma_kernel(const MfmaArgs a) {
@@ -269,11 +270,11 @@ __global__ void __launch_bounds__(kMT) __attribute__((amdgpu_waves_per_eu(2, 2))
       const uint32_t buf = (ks - k0) & 1;
       const bool more = ks + 1 < k1;
       if (more) {
-        load_a(ks + 1);
-        dma_b(ks + 1, buf ^ 1);  // that buffer was last read in the previous iteration, which ended with a barrier
+        if (!(a.ablate & 4)) load_a(ks + 1);
+        if (!(a.ablate & 8)) dma_b(ks + 1, buf ^ 1);  // that buffer was last read in the previous iteration, which ended with a barrier
       }
-      mfma_step(buf);
-      if (more) store_a(ks + 1, buf ^ 1);
+      if (!(a.ablate & 1)) mfma_step(buf);
+      if (more && !(a.ablate & 2)) store_a(ks + 1, buf ^ 1);
       __syncthreads();
     }
 
@@ -384,6 +385,7 @@ int launch_mat_x_mat_mfma(const Device* dev, const uint32_t* A, uint64_t lda, co
   const uint64_t ks_per_x = (a.KS + a.nx - 1) / a.nx;
   while (S > 1 && ks_per_x / S < 8) S /= 2;  // a unit shorter than 8 k-steps is all prologue and flush
   a.S = (uint32_t)(S ? S : 1);
+  a.ablate = (uint32_t)mfma_ablate();
 
   CPIR_HIP_TRY(hipMemsetAsync(a.rowsum, 0, 4 * round_up((uint32_t)rows, kBM), stream));
   if (!accumulate) CPIR_HIP_TRY(hipMemset2DAsync(M, ldm * sizeof(uint32_t), 0, cols * sizeof(uint32_t), rows, stream));

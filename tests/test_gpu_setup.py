@@ -155,6 +155,61 @@ def test_mat_x_mat_matches_oracle_random(orc, device):
             assert np.array_equal(_host(M), want), ("accumulate", rows, inner, cols, bits)
 
 
+def test_mat_x_mat_on_the_matrix_cores(orc, device):
+    """the i8 matrix-core kernel (csrc/matmul_mfma.hip) against the oracle's impl Mul (matrix.rs:1040-1059) and against the VALU kernel:
+    ragged rows / columns / k tails, padded leading dimensions, extreme byte patterns in both operands (every limb 0x00, 0x7f, 0x80,
+    0xff), full 16-bit right-hand sides, accumulate mode"""
+    import torch
+
+    import chalametpir_amd as cp
+
+    assert cp.mat_x_mat_kernel_name(16) == "mat_x_mat_mfma_kernel" and cp.mat_x_mat_kernel_name(32) == "mat_x_mat_u32_kernel"
+    rng = np.random.default_rng(47)
+    stream = torch.cuda.current_stream()
+    extremes_a = np.array([0, 0xFFFFFFFF, 0x80808080, 0x7F7F7F7F, 0x00FF807F, 0x80000000, 1, 0x01010101], dtype=np.uint32)
+    extremes_d = np.array([0, 0xFFFF, 0x8080, 0x7F7F, 0x00FF, 0xFF00, 0x0080, 0x8000, 1], dtype=np.uint32)
+    for rows, inner, cols, pad in ((1, 4, 1, 0), (128, 64, 128, 0), (129, 64 * 5 + 4, 17, 4), (257, 8192 + 60, 940, 8), (1774, 64 * 9, 130, 0),
+                                   (300, 4 * 33333, 33, 12), (16, 1 << 18, 16, 0)):
+        A = random_query(rng, rows * inner).reshape(rows, inner)
+        D = rng.integers(0, 1 << 16, size=(inner, cols), dtype=np.uint64).astype(np.uint32)
+        A.reshape(-1)[rng.integers(0, A.size, size=min(A.size, 4096))] = rng.choice(extremes_a, size=min(A.size, 4096))
+        D.reshape(-1)[rng.integers(0, D.size, size=min(D.size, 4096))] = rng.choice(extremes_d, size=min(D.size, 4096))
+        if rows >= 3:
+            A[1] = 0xFFFFFFFF
+            A[2] = 0x80808080
+        if cols >= 3:
+            D[:, 1] = 0xFFFF
+            D[:, 2] = 0
+        want = orc.mul(A, D)
+        lda, ldd, ldm = inner + pad, cols + pad, cols + (pad // 4)
+        A_dev = torch.full((rows, lda), -1, dtype=torch.int32, device="cuda")
+        D_dev = torch.full((inner, ldd), -1, dtype=torch.int32, device="cuda")
+        A_dev[:, :inner] = _dev(A)
+        D_dev[:, :cols] = _dev(D)
+        got = {}
+        try:
+            for mfma in (1, 0):
+                cp.tuning_set("matmul.mfma", mfma)
+                M = torch.full((rows, ldm), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+                device.mat_x_mat(A_dev, D_dev, M, rows, inner, cols, lda=lda, ldd=ldd, ldm=ldm, rhs_max_bits=16, stream=stream)
+                torch.cuda.synchronize()
+                got[mfma] = _host(M)
+                assert np.array_equal(got[mfma][:, :cols], want), (rows, inner, cols, mfma)
+                assert np.all(got[mfma][:, cols:] == 0x5A5A5A5A)  # padding of M untouched
+        finally:
+            cp.tuning_set("matmul.mfma", 1)
+        # accumulate: the K axis in two unequal parts (multiples of 4) adds up to the product on top of what M held
+        h = (inner // 3) // 4 * 4
+        if h:
+            base = random_query(rng, rows * cols).reshape(rows, cols)
+            M = _dev(base).clone()
+            device.mat_x_mat(A_dev[:, :h].contiguous(), D_dev[:h], M, rows, h, cols, ldd=ldd, rhs_max_bits=16, accumulate=True, stream=stream)
+            device.mat_x_mat(A_dev[:, h:inner].contiguous(), D_dev[h:], M, rows, inner - h, cols, ldd=ldd, rhs_max_bits=16, accumulate=True,
+                             stream=stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(_host(M), base + want), ("accumulate", rows, inner, cols)
+
+
 def test_mat_x_mat_dimension_errors(device):
     import torch
 
