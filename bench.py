@@ -494,9 +494,30 @@ def verify(run_step, drain, step_counter, r_step, qps_step, pool, N, C, b, mask,
 
 def host_path_timing(server, q_pool, N, torch):
     """Server::respond as the drop-in sees it (cpir_server_respond: host query in, host response out, PCIe both ways):
-    latency of one caller, and throughput with 8 concurrent callers on the one handle (the reference serves an
-    Arc<Server> from many tokio tasks).  Never the headline `value`: the headline has q resident in HBM."""
+    latency of one caller, and throughput with 8 and 16 concurrent callers on the one handle (the reference serves an
+    Arc<Server> from many tokio tasks), from pageable and from page-locked query buffers; next to it the host link itself
+    (one large page-locked copy each way).  Never the headline `value`: the headline has q resident in HBM."""
     import threading
+
+    import chalametpir_amd as cp
+
+    # the link: 256 MiB page-locked <-> device, HIP events on the copy stream
+    nbig = 64 << 20
+    hp = torch.empty(nbig, dtype=torch.int32).pin_memory()
+    dv = torch.empty(nbig, dtype=torch.int32, device="cuda")
+    cs = torch.cuda.Stream()
+    rates = {}
+    for name, src, dst in (("h2d", hp, dv), ("d2h", dv, hp)):
+        with torch.cuda.stream(cs):
+            dst.copy_(src, non_blocking=True)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cs)
+            for _ in range(4):
+                dst.copy_(src, non_blocking=True)
+            e1.record(cs)
+        cs.synchronize()
+        rates[name] = 4 * nbig * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del hp, dv
 
     qs = [q_pool[i].cpu().numpy().view(np.uint32) for i in range(min(16, q_pool.shape[0]))]
     for q in qs[:4]:
@@ -507,37 +528,47 @@ def host_path_timing(server, q_pool, N, torch):
         server.respond_array(qs[i % len(qs)])
     lat = (time.perf_counter() - t0) / n1
     # the same single caller with its query in page-locked memory (cpir_host_alloc): DMA straight from the caller's buffer
-    import chalametpir_amd as cp
-
-    pin = cp.PinnedArray(N)
-    pin.array[:] = qs[0]
+    pins = [cp.PinnedArray(N) for _ in range(16)]
+    for i, p in enumerate(pins):
+        p.array[:] = qs[i % len(qs)]
     for _ in range(3):
-        server.respond_array(pin.array)
+        server.respond_array(pins[0].array)
     t0 = time.perf_counter()
     for i in range(n1):
-        server.respond_array(pin.array)
+        server.respond_array(pins[0].array)
     lat_pinned = (time.perf_counter() - t0) / n1
-    pin.close()
-    threads, per = 8, 32
 
-    def work(k):
-        for i in range(per):
-            server.respond_array(qs[(k + i) % len(qs)])
+    def throughput(threads, per, pinned):
+        def work(k):
+            for i in range(per):
+                server.respond_array(pins[k].array if pinned else qs[(k + i) % len(qs)])
 
-    ts = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
-    t0 = time.perf_counter()
-    [t.start() for t in ts]
-    [t.join() for t in ts]
-    thr = threads * per / (time.perf_counter() - t0)
-    return {
+        ts = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
+        t0 = time.perf_counter()
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        return threads * per / (time.perf_counter() - t0)
+
+    throughput(8, 4, False)  # warm-up (first use of every arena)
+    out = {
         "one_caller_us_per_query": round(lat * 1e6, 1),
         "one_caller_queries_per_sec": round(1.0 / lat, 1),
         "one_caller_pinned_query_us_per_query": round(lat_pinned * 1e6, 1),
-        "eight_callers_queries_per_sec": round(thr, 1),
+        "eight_callers_queries_per_sec": round(throughput(8, 48, False), 1),
+        "eight_callers_pinned_queries_per_sec": round(throughput(8, 48, True), 1),
+        "sixteen_callers_queries_per_sec": round(throughput(16, 24, False), 1),
+        "sixteen_callers_pinned_queries_per_sec": round(throughput(16, 24, True), 1),
         "query_bytes": 4 * N,
-        "note": "cpir_server_respond on host buffers: pinned staging in 1 MiB pieces + H2D + respond kernel + D2H; concurrent callers are "
-                "coalesced into batched launches on two alternating arenas (one arena's uploads overlap the other's kernel); PCIe-bound",
+        "h2d_GBps": round(rates["h2d"], 1),
+        "d2h_GBps": round(rates["d2h"], 1),
+        "link_bound_queries_per_sec": round(rates["h2d"] * 1e9 / (4 * N), 1),
+        "note": "cpir_server_respond on host buffers: pinned staging (skipped for page-locked queries) + H2D + respond kernel + D2H; concurrent "
+                "callers are coalesced into batched launches: arenas of up to 8 seats, uploads in single file on one stream, kernels back to back on "
+                "another; link_bound = h2d_GBps / query_bytes",
     }
+    for p in pins:
+        p.close()
+    return out
 
 
 def group_child(cp, torch, device, args):

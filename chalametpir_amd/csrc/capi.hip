@@ -26,25 +26,28 @@ void set_last_hip_error(hipError_t e, const char* what, const char* file, int li
 // ---------------------------------------------------------------------------------------------------------------
 // Server handle
 // ---------------------------------------------------------------------------------------------------------------
-// Host callers of respond(&self) are COALESCED: queries that arrive while the device is busy share the next launch
-// (row f3 behind the thread-safe ABI; the reference serves an Arc<Server> from many tokio tasks, examples/server.rs:45,55,85).
-// Two arenas alternate.  A caller takes a seat in the OPEN arena (the first one in becomes its leader), copies its query into the
-// arena's pinned block and enqueues the host->device copy of its seat on the arena's stream -- these copies overlap with the other
-// arena's kernel.  The leader launches one batched respond for all seats as soon as the other arena is not on the device any more
-// (or the arena is full), waits for it, and wakes the followers, who copy their responses out.  A lone caller finds the device
-// idle and launches at once: no added latency.
+// Host callers of respond(&self) are COALESCED and PIPELINED (row f3 behind the thread-safe ABI; the reference serves an Arc<Server>
+// from many tokio tasks, examples/server.rs:45,55,85).  What a query costs on the host path is its upload (4.7 MB at 2^20 keys) more
+// than its kernel, so the front end is built around the host link:
+//   * a caller takes a seat in the OPEN arena (opening a free one if need be; the first one in is the arena's leader), copies its query
+//     into the arena's pinned block -- unless it already lies in page-locked memory -- and enqueues the upload on ONE upload stream
+//     shared by all arenas: queries cross the link one after the other, whole, in the order they were staged, so the first seats of an
+//     arena are in HBM early instead of every concurrent upload finishing at the same late moment;
+//   * the leader keeps its arena open until the device is free of the previous arena's launch (or the arena is full) and every seat
+//     taken so far is staged, then closes it and enqueues ONE batched respond for those seats on the run stream, behind the seats' upload
+//     events; callers that arrive later open the next arena and upload while this kernel runs;
+//   * a lone caller finds everything idle: upload (in pieces, so the DMA of one piece overlaps the pinned copy of the next), one launch.
 struct RespondArena {
-  hipStream_t stream = nullptr;
-  hipStream_t kernel_stream = nullptr;  // pipelined lone query: uploads on `stream`, kernel parts here, chained by `part_ev`
-  std::vector<hipEvent_t> part_ev;
   uint32_t* q_dev = nullptr;     // kSeats x total_slots u32
   uint32_t* r_dev = nullptr;     // kSeats x C u32
   uint32_t* q_pinned = nullptr;  // kSeats x total_slots u32
   uint32_t* r_pinned = nullptr;  // kSeats x C u32
+  std::vector<hipEvent_t> seat_ev;  // upload of seat i has crossed the link
+  hipEvent_t done_ev = nullptr;     // the arena's responses are in r_pinned
   // guarded by Server::mu
   enum State { FREE, OPEN, LAUNCHED, DONE } state = FREE;
   uint32_t joined = 0;  // seats taken
-  uint32_t staged = 0;  // seats whose query is copied and whose upload is enqueued
+  uint32_t staged = 0;  // seats whose upload is enqueued
   uint32_t left = 0;    // seats whose caller has taken its response
   int status = CPIR_OK; // outcome of the launch (shared by every seat)
 };
@@ -58,13 +61,27 @@ struct Server {
   uint64_t total_slots = 0;
   double setup_timings[CPIR_SETUP_TIMING_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
 
-  // 4, not the 8 the matrix-core kernel could fuse: a query costs ~170 us of PCIe against 30-50 us of kernel, so what matters is
-  // that one arena's uploads overlap the other arena's kernel -- 8 closed-loop callers then split 4 + 4 instead of convoying
-  static constexpr uint32_t kSeats = 4;
+  // 3 arenas of 8 seats: a batch of up to 8 rides ONE stream of the database on the matrix cores (a respond kernel takes about as
+  // long for 8 queries as for 1, so throughput is batch size over kernel time); one arena is on the device, one is filling, one spare
+  static constexpr uint32_t kSeats = 8;
+  static constexpr uint32_t kArenas = 4;
+  // An arena takes its first kSpread callers freely; further callers prefer to open another arena (so that one arena's uploads overlap
+  // another's kernel: 8 concurrent callers split 4 + 4 instead of convoying) and fill seats kSpread.. only once no arena is free.
+  static constexpr uint32_t kSpread = 4;
+  // CPIR_RESPOND_TRACE=1: per-phase wall time of the host path, printed when the server is destroyed (diagnosis)
+  struct Trace {
+    std::atomic<uint64_t> calls{0}, batches{0}, ns_seat{0}, ns_stage{0}, ns_gate{0}, ns_enqueue{0}, ns_gpu{0}, ns_follow{0}, ns_out{0};
+    std::atomic<uint64_t> batch_hist[9] = {};
+  } trace;
+  bool trace_on = false;
   std::mutex mu;
   std::condition_variable cv;
-  RespondArena arena[2];
-  bool arenas_ready = false;
+  RespondArena arena[kArenas];  // each allocated on first use (a lone caller only ever needs the first)
+  bool streams_ready = false;
+  hipStream_t up_stream = nullptr;   // every query upload, FIFO
+  hipStream_t run_stream = nullptr;  // every batched respond + response download, FIFO
+  std::mutex upload_mu;              // one query's upload is enqueued at a time (whole queries, not interleaved pieces)
+  std::mutex launch_mu;              // one arena's launch sequence is enqueued at a time
 
   // ---- group handle (cpir_server_setup_multi): the database is split along the filter slots over several devices of this
   // process; `shards` then holds one ordinary server per device and this handle owns no packed database itself.  A host query is
@@ -119,6 +136,22 @@ static bool host_pointer_is_pinned(const void* p) {
   return attr.type == hipMemoryTypeHost;
 }
 
+// Wait for an event the device will signal within a few hundred microseconds: poll it for a while (a blocking wait costs tens of
+// microseconds of wake-up latency, a tenth of a lone query), then fall back to the blocking wait.
+static hipError_t wait_for_event(hipEvent_t ev) {
+  const double t0 = now_seconds();
+  for (;;) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e != hipErrorNotReady) return e;
+    if (now_seconds() - t0 > 2e-3) break;
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  (void)hipGetLastError();  // hipErrorNotReady is sticky-free, but keep the thread's error state clean
+  return hipEventSynchronize(ev);
+}
+
 static void device_retain(Device* d) { d->refs.fetch_add(1); }
 static void device_release(Device* d) {
   if (d && d->refs.fetch_sub(1) == 1) {
@@ -128,48 +161,67 @@ static void device_release(Device* d) {
   }
 }
 
-// the arenas live in ONE device block and ONE pinned block (pinning is the slow call: one instead of four per server)
-static void arenas_destroy(Server* srv) {
-  for (RespondArena& a : srv->arena) {
-    if (a.stream) (void)hipStreamDestroy(a.stream);
-    if (a.kernel_stream) (void)hipStreamDestroy(a.kernel_stream);
-    for (hipEvent_t e : a.part_ev)
-      if (e) (void)hipEventDestroy(e);
-  }
-  if (srv->arena[0].q_dev) (void)hipFree(srv->arena[0].q_dev);
-  if (srv->arena[0].q_pinned) (void)hipHostFree(srv->arena[0].q_pinned);
-  for (RespondArena& a : srv->arena) a = RespondArena{};
-  srv->arenas_ready = false;
+// is this host address page-locked memory the HIP runtime knows (so that a copy from it is a true asynchronous DMA)?  The answer for
+// the last buffer asked about is remembered per thread: a server loop hands over the same query buffer again and again.  (A stale
+// answer is harmless: hipMemcpyAsync accepts pageable memory, and a pinned buffer taken for pageable is merely staged.)
+static bool host_pointer_is_pinned_cached(const void* p, size_t bytes) {
+  struct Last {
+    const char* lo = nullptr;
+    const char* hi = nullptr;
+    bool pinned = false;
+  };
+  static thread_local Last last;
+  const char* c = static_cast<const char*>(p);
+  if (last.lo && c >= last.lo && c + bytes <= last.hi) return last.pinned;
+  last.lo = c, last.hi = c + bytes, last.pinned = host_pointer_is_pinned(p);
+  return last.pinned;
 }
 
-// both arenas, on first use (caller holds Server::mu)
-static int arenas_create(Server* srv) {
-  // per arena: kSeats queries, then kSeats responses (query block first: it stays 16-byte aligned)
+// an arena's query and response seats live in ONE device block and ONE pinned block (pinning is the slow call)
+static void arena_free(RespondArena& a) {
+  for (hipEvent_t e : a.seat_ev)
+    if (e) (void)hipEventDestroy(e);
+  if (a.done_ev) (void)hipEventDestroy(a.done_ev);
+  if (a.q_dev) (void)hipFree(a.q_dev);
+  if (a.q_pinned) (void)hipHostFree(a.q_pinned);
+  a = RespondArena{};
+}
+
+static void arenas_destroy(Server* srv) {
+  for (RespondArena& a : srv->arena) arena_free(a);
+  if (srv->up_stream) (void)hipStreamDestroy(srv->up_stream);
+  if (srv->run_stream) (void)hipStreamDestroy(srv->run_stream);
+  srv->up_stream = srv->run_stream = nullptr;
+  srv->streams_ready = false;
+}
+
+// on first use of this arena (caller holds Server::mu).  A shard stages only its own slots of a query, but seats keep the full stride.
+static int arena_create(Server* srv, RespondArena& a) {
+  // kSeats queries, then kSeats responses (query block first: it stays 16-byte aligned)
   const size_t qw = (size_t)srv->total_slots * Server::kSeats, rw = ((size_t)srv->layout.num_cols * Server::kSeats + 3) / 4 * 4;
-  uint32_t *dev = nullptr, *pin = nullptr;
-#define TRY_(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_last_hip_error(_e, #e, __FILE__, __LINE__); \
-    if (dev) (void)hipFree(dev); if (pin) (void)hipHostFree(pin); \
-    for (RespondArena& x : srv->arena) { if (x.stream) (void)hipStreamDestroy(x.stream); \
-      if (x.kernel_stream) (void)hipStreamDestroy(x.kernel_stream); for (hipEvent_t ev : x.part_ev) if (ev) (void)hipEventDestroy(ev); \
-      x = RespondArena{}; } \
-    return _e == hipErrorOutOfMemory ? CPIR_ERR_OUT_OF_DEVICE_MEMORY : CPIR_ERR_HIP; } } while (0)
-  TRY_(hipMalloc(&dev, 2 * (qw + rw) * 4));
-  TRY_(hipHostMalloc(&pin, 2 * (qw + rw) * 4, hipHostMallocDefault));
-  for (int i = 0; i < 2; i++) {
-    TRY_(hipStreamCreateWithFlags(&srv->arena[i].stream, hipStreamNonBlocking));
-    TRY_(hipStreamCreateWithFlags(&srv->arena[i].kernel_stream, hipStreamNonBlocking));
-    srv->arena[i].part_ev.assign(64, nullptr);
-    for (hipEvent_t& ev : srv->arena[i].part_ev) TRY_(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  auto fail = [&](hipError_t e, const char* what) {
+    set_last_hip_error(e, what, __FILE__, __LINE__);
+    arena_free(a);
+    return e == hipErrorOutOfMemory ? CPIR_ERR_OUT_OF_DEVICE_MEMORY : CPIR_ERR_HIP;
+  };
+  hipError_t e = hipSuccess;
+  if (!srv->streams_ready) {
+    e = hipStreamCreateWithFlags(&srv->up_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&srv->run_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      if (srv->up_stream) (void)hipStreamDestroy(srv->up_stream);
+      srv->up_stream = srv->run_stream = nullptr;
+      return fail(e, "hipStreamCreateWithFlags");
+    }
+    srv->streams_ready = true;
   }
-#undef TRY_
-  for (int i = 0; i < 2; i++) {
-    RespondArena& a = srv->arena[i];
-    a.q_dev = dev + (size_t)i * qw;
-    a.r_dev = dev + 2 * qw + (size_t)i * rw;
-    a.q_pinned = pin + (size_t)i * qw;
-    a.r_pinned = pin + 2 * qw + (size_t)i * rw;
-  }
-  srv->arenas_ready = true;
+  if ((e = hipMalloc(&a.q_dev, (qw + rw) * 4)) != hipSuccess) return fail(e, "hipMalloc(respond arena)");
+  if ((e = hipHostMalloc(&a.q_pinned, (qw + rw) * 4, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc(respond arena)");
+  a.r_dev = a.q_dev + qw, a.r_pinned = a.q_pinned + qw;
+  a.seat_ev.assign(Server::kSeats, nullptr);
+  for (hipEvent_t& ev : a.seat_ev)
+    if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreateWithFlags");
+  if ((e = hipEventCreateWithFlags(&a.done_ev, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreateWithFlags");
   return CPIR_OK;
 }
 
@@ -200,6 +252,16 @@ static void group_ctx_destroy(Server* srv) {
 
 static void server_destroy(Server* srv) {
   if (!srv) return;
+  if (srv->trace_on && srv->trace.calls.load()) {
+    const Server::Trace& t = srv->trace;
+    const double n = (double)t.calls.load(), nb = (double)(t.batches.load() ? t.batches.load() : 1);
+    fprintf(stderr, "[cpir respond trace] %.0f calls in %.0f batches; us per call: seat wait %.1f, staging %.1f, copy out %.1f; followers wait %.1f; "
+                    "us per batch (leader): gate %.1f, enqueue %.1f, device %.1f; batch sizes",
+            n, nb, t.ns_seat.load() / n / 1e3, t.ns_stage.load() / n / 1e3, t.ns_out.load() / n / 1e3,
+            t.ns_follow.load() / (n - nb > 0 ? n - nb : 1) / 1e3, t.ns_gate.load() / nb / 1e3, t.ns_enqueue.load() / nb / 1e3, t.ns_gpu.load() / nb / 1e3);
+    for (int i = 1; i <= 8; i++) fprintf(stderr, " %d:%llu", i, (unsigned long long)t.batch_hist[i].load());
+    fprintf(stderr, "\n");
+  }
   if (!srv->shards.empty()) {
     group_ctx_destroy(srv);
     for (Server* c : srv->shards) server_destroy(c);
@@ -348,6 +410,8 @@ static Server* server_new(Device* dev, const cpir_dtc_layout& L, uint64_t slot_o
   s->layout = L;
   s->slot_offset = slot_offset;
   s->total_slots = total_slots;
+  const char* tr = getenv("CPIR_RESPOND_TRACE");
+  s->trace_on = tr && tr[0] == '1';
   return s;
 }
 
@@ -1314,119 +1378,110 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
   const size_t N = (size_t)srv->total_slots, C = srv->layout.num_cols;
 
   // ---- take a seat ----------------------------------------------------------------------------------------------
+  const bool tr = srv->trace_on;
+  const double t_enter = tr ? now_seconds() : 0;
   std::unique_lock<std::mutex> lk(srv->mu);
-  if (!srv->arenas_ready) CPIR_TRY(arenas_create(srv));
   RespondArena* a = nullptr;
   for (;;) {
-    for (RespondArena& x : srv->arena)
-      if (x.state == RespondArena::OPEN && x.joined < Server::kSeats) a = &x;
-    if (!a) {
-      const bool any_open = srv->arena[0].state == RespondArena::OPEN || srv->arena[1].state == RespondArena::OPEN;
-      if (!any_open)  // (a full OPEN arena is about to launch: wait for it rather than opening a second one)
-        for (RespondArena& x : srv->arena)
-          if (!a && x.state == RespondArena::FREE) a = &x, x.state = RespondArena::OPEN, x.status = CPIR_OK;
-    }
+    for (RespondArena& x : srv->arena)  // 1. an open arena that is still spreading
+      if (!a && x.state == RespondArena::OPEN && x.joined < Server::kSpread) a = &x;
+    if (!a)
+      for (RespondArena& x : srv->arena)  // 2. a free arena
+        if (!a && x.state == RespondArena::FREE) {
+          if (!x.q_dev) CPIR_TRY(arena_create(srv, x));
+          a = &x, x.state = RespondArena::OPEN, x.status = CPIR_OK;
+        }
+    if (!a)
+      for (RespondArena& x : srv->arena)  // 3. no arena free: fill the open one up
+        if (!a && x.state == RespondArena::OPEN && x.joined < Server::kSeats) a = &x;
     if (a) break;
-    srv->cv.wait(lk);
+    srv->cv.wait(lk);  // every arena is full or in flight
   }
-  RespondArena* other = (a == &srv->arena[0]) ? &srv->arena[1] : &srv->arena[0];
   const uint32_t seat = a->joined++;
   const bool leader = (seat == 0);
-  // Optional (respond.host_pipeline_pieces > 1; off by default, it measured slower -- DESIGN.md section 4): a caller that finds the
-  // device idle has nobody to share a launch with, closes its arena at once and PIPELINES its own query -- the upload in pieces
-  // along the slot axis, each piece followed by the part of the respond kernel that needs only those slots (the parts add up in r).
-  const uint64_t steps = (srv->layout.num_slots + CPIR_PLANAR_SLOTS_PER_TILE - 1) / CPIR_PLANAR_SLOTS_PER_TILE;
-  uint64_t parts = (uint64_t)respond_host_pipeline_pieces();
-  if (parts > steps / 8) parts = steps / 8;  // every part must still fill the chip
-  const bool solo = leader && other->state != RespondArena::LAUNCHED && srv->layout.packing == CPIR_PACK_PLANAR && parts >= 2;
-  if (solo) a->state = RespondArena::LAUNCHED;
   lk.unlock();
+  const double t_seated = tr ? now_seconds() : 0;
 
-  if (solo) {
-    const bool direct = host_pointer_is_pinned(q);
-    int st = CPIR_OK;
-    hipError_t e = hipSuccess;
-    uint32_t* qd = a->q_dev;  // seat 0
-    for (uint64_t i = 0; i < parts && st == CPIR_OK && e == hipSuccess; i++) {
-      const uint64_t s_lo = steps * i / parts, s_hi = steps * (i + 1) / parts;
-      const size_t n_lo = (size_t)srv->slot_offset + (size_t)s_lo * CPIR_PLANAR_SLOTS_PER_TILE;
-      size_t n_hi = (size_t)srv->slot_offset + (size_t)s_hi * CPIR_PLANAR_SLOTS_PER_TILE;
-      const size_t n_end = (size_t)srv->slot_offset + (size_t)srv->layout.num_slots;
-      if (n_hi > n_end) n_hi = n_end;
-      const uint32_t* src = q + n_lo;
-      if (!direct) {
-        memcpy(a->q_pinned + n_lo, q + n_lo, (n_hi - n_lo) * 4);
-        src = a->q_pinned + n_lo;
-      }
-      // uploads queue up back to back on the copy stream; part i of the kernel waits only for piece i
-      e = hipMemcpyAsync(qd + n_lo, src, (n_hi - n_lo) * 4, hipMemcpyHostToDevice, a->stream);
-      if (e == hipSuccess) e = hipEventRecord(a->part_ev[i], a->stream);
-      if (e == hipSuccess) e = hipStreamWaitEvent(a->kernel_stream, a->part_ev[i], 0);
-      if (e == hipSuccess)
-        st = launch_respond_planar_part(srv->dev, srv->dtc, srv->layout, qd, srv->total_slots, srv->slot_offset, a->r_dev, s_lo, s_hi,
-                                        a->kernel_stream);
-    }
-    if (st == CPIR_OK && e == hipSuccess) e = hipMemcpyAsync(a->r_pinned, a->r_dev, C * 4, hipMemcpyDeviceToHost, a->kernel_stream);
-    const hipError_t e2 = hipStreamSynchronize(a->stream), e3 = hipStreamSynchronize(a->kernel_stream);  // always drain both
-    if (e == hipSuccess) e = (e2 != hipSuccess) ? e2 : e3;
-    if (st == CPIR_OK && e != hipSuccess) {
-      set_last_hip_error(e, "pipelined respond", __FILE__, __LINE__);
-      st = CPIR_ERR_HIP;
-    }
-    if (st == CPIR_OK) memcpy(r_out, a->r_pinned, C * 4);
-    lk.lock();
-    a->state = RespondArena::FREE;
-    a->joined = a->staged = a->left = 0;
-    srv->cv.notify_all();
-    return st;
-  }
-
-  // ---- stage the query: pinned copy (the reference copies too: from_bytes .to_vec(), matrix.rs:1001-1007), then its upload ----
-  // in pieces, so that the DMA of one piece runs while the next is being copied into the pinned block
-  hipError_t up = hipSuccess;
-  const size_t piece = (size_t)1 << 18;  // 1 MiB of u32
+  // ---- stage the query (the reference copies too: from_bytes .to_vec(), matrix.rs:1001-1007) and enqueue its upload -----------------
   // (a shard reads only its own slots of the query: only those are staged and uploaded)
-  const size_t q_end = (size_t)srv->slot_offset + (size_t)srv->layout.num_slots;
-  if (host_pointer_is_pinned(q)) {
+  hipError_t up = hipSuccess;
+  const size_t q_lo = (size_t)srv->slot_offset, q_hi = q_lo + (size_t)srv->layout.num_slots;
+  uint32_t* const qd = a->q_dev + seat * N;
+  if (host_pointer_is_pinned_cached(q + q_lo, (q_hi - q_lo) * 4)) {
     // the caller's buffer is page-locked already (cpir_host_alloc, hipHostMalloc, hipHostRegister): DMA straight from it
-    up = hipMemcpyAsync(a->q_dev + seat * N + srv->slot_offset, q + srv->slot_offset, (q_end - (size_t)srv->slot_offset) * 4,
-                        hipMemcpyHostToDevice, a->stream);
+    std::lock_guard<std::mutex> ul(srv->upload_mu);
+    up = hipMemcpyAsync(qd + q_lo, q + q_lo, (q_hi - q_lo) * 4, hipMemcpyHostToDevice, srv->up_stream);
+    if (up == hipSuccess) up = hipEventRecord(a->seat_ev[seat], srv->up_stream);
   } else {
-    for (size_t o = (size_t)srv->slot_offset; o < q_end && up == hipSuccess; o += piece) {
-      const size_t n = (q_end - o < piece) ? q_end - o : piece;
-      memcpy(a->q_pinned + seat * N + o, q + o, n * 4);
-      up = hipMemcpyAsync(a->q_dev + seat * N + o, a->q_pinned + seat * N + o, n * 4, hipMemcpyHostToDevice, a->stream);
+    uint32_t* const qp = a->q_pinned + seat * N;
+    const size_t piece = (size_t)1 << 18;  // 1 MiB of u32
+    std::unique_lock<std::mutex> ul(srv->upload_mu, std::try_to_lock);
+    if (ul.owns_lock()) {
+      // nobody else is uploading: in pieces, so that the DMA of one piece runs while the next is being copied into the pinned block
+      for (size_t o = q_lo; o < q_hi && up == hipSuccess; o += piece) {
+        const size_t n = (q_hi - o < piece) ? q_hi - o : piece;
+        memcpy(qp + o, q + o, n * 4);
+        up = hipMemcpyAsync(qd + o, qp + o, n * 4, hipMemcpyHostToDevice, srv->up_stream);
+      }
+    } else {
+      // the link is busy with somebody else's query: copy while waiting, then upload in one piece when it is this query's turn
+      memcpy(qp + q_lo, q + q_lo, (q_hi - q_lo) * 4);
+      ul.lock();
+      up = hipMemcpyAsync(qd + q_lo, qp + q_lo, (q_hi - q_lo) * 4, hipMemcpyHostToDevice, srv->up_stream);
     }
+    if (up == hipSuccess) up = hipEventRecord(a->seat_ev[seat], srv->up_stream);
   }
   if (up != hipSuccess) set_last_hip_error(up, "hipMemcpyAsync(query upload)", __FILE__, __LINE__);
 
+  const double t_staged = tr ? now_seconds() : 0;
   lk.lock();
   if (up != hipSuccess) a->status = CPIR_ERR_HIP;
   a->staged++;
   srv->cv.notify_all();
   if (leader) {
-    // launch when every seat taken so far is staged AND the device is free of the other arena's launch (or we are full);
+    // launch when every seat taken so far is staged AND the device is free of the previous arena's launch (or this one is full);
     // callers keep joining until then
     srv->cv.wait(lk, [&] {
-      return a->staged == a->joined && (other->state != RespondArena::LAUNCHED || a->joined == Server::kSeats);
+      if (a->staged != a->joined) return false;
+      if (a->joined == Server::kSeats) return true;
+      for (const RespondArena& x : srv->arena)
+        if (x.state == RespondArena::LAUNCHED) return false;
+      return true;
     });
-    a->state = RespondArena::LAUNCHED;  // closed: later callers open the other arena
+    a->state = RespondArena::LAUNCHED;  // closed: later callers open the next arena
     srv->cv.notify_all();
     const uint32_t k = a->joined;
     int st = a->status;
     lk.unlock();
+    const double t_gate = tr ? now_seconds() : 0;
+    hipError_t e = hipSuccess;
     if (st == CPIR_OK) {
-      st = respond_batched(srv->dev, srv->dtc, srv->layout, a->q_dev, srv->total_slots, srv->slot_offset, k, a->r_dev, nullptr, a->stream);
-      hipError_t e = hipSuccess;
-      if (st == CPIR_OK) e = hipMemcpyAsync(a->r_pinned, a->r_dev, (size_t)k * C * 4, hipMemcpyDeviceToHost, a->stream);
-      const hipError_t e2 = hipStreamSynchronize(a->stream);  // always drain the stream before the arena is reused
-      if (e == hipSuccess) e = e2;
-      if (st == CPIR_OK && e != hipSuccess) {
-        set_last_hip_error(e, "respond launch / download", __FILE__, __LINE__);
-        st = CPIR_ERR_HIP;
-      }
+      std::lock_guard<std::mutex> ll(srv->launch_mu);  // the launch sequences of two arenas must not interleave on the run stream
+      for (uint32_t i = 0; i < k && e == hipSuccess; i++) e = hipStreamWaitEvent(srv->run_stream, a->seat_ev[i], 0);
+      if (e == hipSuccess)
+        st = respond_batched(srv->dev, srv->dtc, srv->layout, a->q_dev, srv->total_slots, srv->slot_offset, k, a->r_dev, nullptr, srv->run_stream);
+      if (e == hipSuccess && st == CPIR_OK) e = hipMemcpyAsync(a->r_pinned, a->r_dev, (size_t)k * C * 4, hipMemcpyDeviceToHost, srv->run_stream);
+      if (e == hipSuccess) e = hipEventRecord(a->done_ev, srv->run_stream);
+    }
+    const double t_enq = tr ? now_seconds() : 0;
+    // always wait for what was enqueued for this arena before it can be reused: the uploads (they may have failed half way) and the launch
+    hipError_t e2 = hipSuccess;
+    if (st == CPIR_OK && e == hipSuccess) {
+      e2 = wait_for_event(a->done_ev);
     } else {
-      (void)hipStreamSynchronize(a->stream);
+      (void)hipStreamSynchronize(srv->up_stream);
+      (void)hipStreamSynchronize(srv->run_stream);
+    }
+    if (e == hipSuccess) e = e2;
+    if (st == CPIR_OK && e != hipSuccess) {
+      set_last_hip_error(e, "respond launch / download", __FILE__, __LINE__);
+      st = CPIR_ERR_HIP;
+    }
+    if (tr) {
+      const double t_done = now_seconds();
+      srv->trace.batches++, srv->trace.batch_hist[k]++;
+      srv->trace.ns_gate += (uint64_t)((t_gate - t_staged) * 1e9), srv->trace.ns_enqueue += (uint64_t)((t_enq - t_gate) * 1e9);
+      srv->trace.ns_gpu += (uint64_t)((t_done - t_enq) * 1e9);
     }
     lk.lock();
     a->status = st;
@@ -1434,10 +1489,17 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
     srv->cv.notify_all();
   } else {
     srv->cv.wait(lk, [&] { return a->state == RespondArena::DONE; });
+    if (tr) srv->trace.ns_follow += (uint64_t)((now_seconds() - t_staged) * 1e9);
   }
   const int status = a->status;
   lk.unlock();
+  const double t_out0 = tr ? now_seconds() : 0;
   if (status == CPIR_OK) memcpy(r_out, a->r_pinned + seat * C, C * 4);
+  if (tr) {
+    srv->trace.calls++;
+    srv->trace.ns_seat += (uint64_t)((t_seated - t_enter) * 1e9), srv->trace.ns_stage += (uint64_t)((t_staged - t_seated) * 1e9);
+    srv->trace.ns_out += (uint64_t)((now_seconds() - t_out0) * 1e9);
+  }
   lk.lock();
   if (++a->left == a->joined) {  // last one out frees the arena
     a->state = RespondArena::FREE;

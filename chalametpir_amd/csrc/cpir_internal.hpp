@@ -73,13 +73,8 @@ constexpr uint32_t CPIR_PLANAR_MAX_QUERIES_PER_PASS = 8;
 int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                           uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, int blocks_per_cu,
                           bool nontemporal, bool xcd_split, int interleave, uint64_t step_lo = 0, uint64_t step_hi = 0);
-// one query on a planar database, restricted to super-tile steps [step_lo, step_hi) of the slot axis (512 slots each): the parts of
-// one query may be launched one after the other as its pieces arrive from the host; they add up in r (respond.hip)
-int launch_respond_planar_part(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
-                               uint64_t q_slot_offset, uint32_t* r, uint64_t step_lo, uint64_t step_hi, hipStream_t stream);
 bool respond_batch_fusion();
 uint64_t respond_multi_pass_limit_bytes();
-int respond_host_pipeline_pieces();
 
 // pack.hip
 int launch_transpose_compress(const Device* dev, const uint32_t* D, uint64_t ldd, const cpir_dtc_layout& L, uint32_t* dtc,

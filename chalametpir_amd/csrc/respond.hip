@@ -294,9 +294,6 @@ struct Tuning {
   int interleave_passes = -1;  // order of the passes of one launch: 0 slice order, 1 interleaved, -1 by shard size
   int planar_blocks_per_cu = 0;  // the matrix-core kernel (respond_planar.hip): 0 = by pass order (2 streaming, 3 sharing)
   int multi_pass_limit_mb = 2560;  // unfused batches: databases above this size get one launch per query
-  int host_pipeline_pieces = 1;    // a lone host query: upload pieces, each followed by its part of the kernel (1 = off, the default:
-                                   // every part costs ~25 us of kernel fill/drain and launch gaps, which eats the overlap -- measured
-                                   // 421 / 400 / 398 / 404 / 477 us per pageable query with 1 / 2 / 4 / 6 / 12 pieces, 311 -> 354 pinned)
 };
 Tuning g_tuning;
 std::mutex g_tuning_mu;
@@ -359,9 +356,6 @@ extern "C" int cpir_tuning_set(const char* key, int value) {
   } else if (!strcmp(key, "respond.planar_blocks_per_cu")) {
     if (value < 0 || value > 8) return CPIR_ERR_INVALID_ARGUMENT;
     g_tuning.planar_blocks_per_cu = value;
-  } else if (!strcmp(key, "respond.host_pipeline_pieces")) {
-    if (value < 1 || value > 64) return CPIR_ERR_INVALID_ARGUMENT;
-    g_tuning.host_pipeline_pieces = value;
   } else if (!strcmp(key, "respond.multi_pass_limit_mb")) {
     if (value < 0) return CPIR_ERR_INVALID_ARGUMENT;
     g_tuning.multi_pass_limit_mb = value;
@@ -386,11 +380,6 @@ extern "C" int cpir_tuning_set(const char* key, int value) {
   return CPIR_OK;
 }
 
-int respond_host_pipeline_pieces() {
-  std::lock_guard<std::mutex> lk(g_tuning_mu);
-  return g_tuning.host_pipeline_pieces;
-}
-
 uint64_t respond_multi_pass_limit_bytes() {
   std::lock_guard<std::mutex> lk(g_tuning_mu);
   return (uint64_t)g_tuning.multi_pass_limit_mb << 20;
@@ -399,21 +388,6 @@ uint64_t respond_multi_pass_limit_bytes() {
 bool respond_batch_fusion() {
   std::lock_guard<std::mutex> lk(g_tuning_mu);
   return g_tuning.batch_fusion != 0;
-}
-
-int launch_respond_planar_part(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
-                               uint64_t q_slot_offset, uint32_t* r, uint64_t step_lo, uint64_t step_hi, hipStream_t stream) {
-  if (!dtc || !q || !r || L.packing != CPIR_PACK_PLANAR) return CPIR_ERR_INVALID_ARGUMENT;
-  CPIR_TRY(check_layout(L));
-  if (q_slot_offset + L.num_slots > q_len) return CPIR_ERR_SHARD_RANGE;
-  if (reinterpret_cast<uintptr_t>(dtc) % 16 != 0) return CPIR_ERR_INVALID_ARGUMENT;
-  Tuning t;
-  {
-    std::lock_guard<std::mutex> lk(g_tuning_mu);
-    t = g_tuning;
-  }
-  return launch_respond_planar(dev, dtc, L, q, q_len, q_slot_offset, 1, 1, r, stream, t.planar_blocks_per_cu, t.nontemporal != 0,
-                               t.xcd_split != 0, t.interleave_passes, step_lo, step_hi);
 }
 
 uint64_t respond_scratch_words(const cpir_dtc_layout&, uint32_t) {

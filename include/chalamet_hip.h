@@ -224,10 +224,10 @@ int cpir_op_synth_fill(cpir_device* dev, uint32_t* out, uint64_t count, uint64_t
  *   "respond.xcd_split" {0,1}, "respond.batch_fusion" {0,1} (0: every query of a batch call streams the database on its
  *   own, i.e. a batch call is only a cheaper way to enqueue independent responds), "respond.interleave_passes" {-1,0,1}
  *   (order in which one launch walks its passes; -1 = by shard size), "respond.planar_blocks_per_cu" 0..8, "respond.multi_pass_limit_mb"
- *   (unfused batches on databases above this size get one launch per query), "respond.host_pipeline_pieces" 1..64 (a lone host
- *   query is uploaded in that many pieces, each followed by the part of the kernel that needs only those slots; 1 = off, the default),
- *   "matmul.mfma" {0,1} (1, the default: cpir_op_mat_x_mat and the setup paths run right-hand sides below 2^16 on the i8 matrix cores;
- *   0: on the integer VALU), "layout.dense" {0,1} and "layout.planar" {0,1}
+ *   (unfused batches on databases above this size get one launch per query), "matmul.mfma" {0,1} (1, the default:
+ *   cpir_op_mat_x_mat and the setup paths run right-hand sides below 2^16 on the i8 matrix cores; 0: on the integer VALU),
+ *   "matmul.ablate" (diagnosis only, results are WRONG while it is non-zero: bit mask of parts of the matrix-core matmul to skip),
+ *   "layout.dense" {0,1} and "layout.planar" {0,1}
  *   (default packing chosen by cpir_dtc_layout_for and therefore by every cpir_server_* constructor: planar where it is
  *   offered and enabled, else dense64 where offered and enabled, else the reference packing).
  * Process-wide; results are bit-identical for every setting. */

@@ -152,19 +152,14 @@ def test_both_packings_and_the_oracle_agree_on_a_full_size_query(full, device, o
     query = np.array([1, f.N], dtype="<u4").tobytes() + q_host.tobytes()
     assert len(query) == 4718600
     want_bytes = np.array([1, f.C], dtype="<u4").tobytes() + want.tobytes()
-    for name in PACKINGS:  # on the planar server a lone host query is uploaded in pieces, each followed by its part of the kernel
+    for name in PACKINGS:
         resp = f.servers[name].respond(query)
         assert len(resp) == 3768 and resp == want_bytes, name
     import chalametpir_amd as cp
 
-    pin = cp.PinnedArray(f.N)  # page-locked query: DMA straight from the caller's buffer, same pipeline
+    pin = cp.PinnedArray(f.N)  # page-locked query: DMA straight from the caller's buffer
     pin.array[:] = q_host
     assert np.array_equal(f.servers["planar"].respond_array(pin.array), want)
-    for pieces in (2, 6, 9):  # off by default (1): a lone host query uploaded in pieces, each followed by its part of the kernel
-        cp.tuning_set("respond.host_pipeline_pieces", pieces)
-        assert np.array_equal(f.servers["planar"].respond_array(q_host), want), pieces
-        assert np.array_equal(f.servers["planar"].respond_array(pin.array), want), pieces
-    cp.tuning_set("respond.host_pipeline_pieces", 1)
     pin.close()
 
 
