@@ -403,7 +403,7 @@ def main() -> int:
             result.update(setup_kv_timing(cp, device, n_keys, arity, value_bytes))
 
     if world > 1 and not args.no_setup:
-        extra = setup_timing_sharded(cp, device, torch, dist, N, C, b, mask, lo, hi, rank, stream)
+        extra = setup_timing_sharded(cp, device, torch, dist, N, C, b, mask, lo, hi, rank, stream, full_layout)
         if rank == 0:
             result.update(extra)
     if world > 1:
@@ -827,11 +827,12 @@ def setup_kernel_roofline(cp, device, torch, N, C, b, cf, mask, layout, stream):
     return out
 
 
-def setup_timing_sharded(cp, device, torch, dist, N, C, b, mask, lo, hi, rank, stream):
-    """server_setup on the N-sharded database: every rank expands A from the seed on its own host core (the sponge is
-    sequential, so this cannot be split), uploads only its column slab, multiplies it with its shard of D, packs its shard,
-    and the partial hints are sum-reduced to rank 0.  Wall time = max over ranks, barrier to barrier."""
-    from chalametpir_amd.distributed import reduce_u32_
+def setup_timing_sharded(cp, device, torch, dist, N, C, b, mask, lo, hi, rank, stream, unit):
+    """server_setup on the N-sharded database with ONE expansion of A per node: rank 0 squeezes the sponge block by block (it is
+    sequential, so this is the floor of setup whatever the number of GPUs), uploads each block and sends every rank its column slab over
+    the process group (RCCL send/recv over xGMI); every rank multiplies its slab with its shard of D on the matrix cores and packs its
+    shard; the partial hints are sum-reduced to rank 0.  Wall time = max over ranks, barrier to barrier."""
+    from chalametpir_amd.distributed import reduce_u32_, scatter_public_matrix
 
     D_dev = torch.empty(((hi - lo), C), dtype=torch.int32, device="cuda")
     if hi > lo:
@@ -840,21 +841,29 @@ def setup_timing_sharded(cp, device, torch, dist, N, C, b, mask, lo, hi, rank, s
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
-    if hi > lo:
-        device.hint_partial(SEED_MU, D_dev, lo, hi - lo, N, C, M, stream=stream)
+    if hi > lo:  # the shard is packed while the sponge is still being squeezed
         srv = cp.Server.from_device_matrix(D_dev, hi - lo, C, b, device=device, slot_offset=lo, total_slots=N, stream=stream)
+    slab, lo2, hi2 = scatter_public_matrix(SEED_MU, N, unit, device=torch.device("cuda", torch.cuda.current_device()))
+    assert (lo2, hi2) == (lo, hi)
+    t_scatter = time.perf_counter() - t0
+    if hi > lo:
+        device.mat_x_mat(slab, D_dev, M, 1774, hi - lo, C, rhs_max_bits=16, stream=stream)
+    torch.cuda.synchronize()
     t_local = time.perf_counter() - t0
     reduce_u32_(M, dst=0)
     torch.cuda.synchronize()
     dist.barrier()
     wall = time.perf_counter() - t0
-    t = torch.tensor([wall, t_local], dtype=torch.float64, device="cuda")
+    t = torch.tensor([wall, t_local, t_scatter], dtype=torch.float64, device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     out = {
         "server_setup_wall_sec": round(float(t[0].item()), 3),
-        "server_setup_note": "sharded setup from (seed_mu, encoded D shards in HBM): per rank XOF expansion of A on one host core + its "
-                             "column slab uploaded + partial hint matmul + shard pack; partial hints sum-reduced (RCCL) to rank 0",
+        "server_setup_note": "sharded setup from (seed_mu, encoded D shards in HBM), ONE XOF expansion of A per node: rank 0 squeezes, uploads and "
+                             "sends column slabs block by block (RCCL send/recv), every rank: shard pack, partial hint matmul (matrix cores) on its "
+                             "slab; partial hints sum-reduced (RCCL) to rank 0",
         "server_setup_max_rank_local_sec": round(float(t[1].item()), 3),
+        "server_setup_expand_and_scatter_sec": round(float(t[2].item()), 3),
+        "xof_expansions_per_node": 1,
     }
     if rank == 0:
         hint = M.cpu().numpy().view(np.uint32)

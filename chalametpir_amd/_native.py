@@ -77,6 +77,9 @@ SIGNATURES = {
     "cpir_filter_shape": (C.c_int, [C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "cpir_encoded_num_cols": (C.c_uint64, [C.c_uint64, C.c_uint32]),
     "cpir_generate_from_seed": (C.c_int, [C.c_uint64, C.c_uint64, u8p, vp]),
+    "cpir_xof_open": (C.c_int, [u8p, C.POINTER(vp)]),
+    "cpir_xof_squeeze": (C.c_int, [vp, vp, C.c_size_t]),
+    "cpir_xof_close": (None, [vp]),
     "cpir_op_mat_x_mat": (C.c_int, [vp, u32p, C.c_uint64, u32p, C.c_uint64, u32p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
                                     C.c_uint32, C.c_int, vp]),
     "cpir_mat_x_mat_kernel_name": (C.c_char_p, [C.c_uint32]),

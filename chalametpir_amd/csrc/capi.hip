@@ -833,6 +833,7 @@ using namespace cpir;
 
 struct cpir_device : Device {};
 struct cpir_server : Server {};
+struct cpir_xof : TurboShake128 {};
 
 extern "C" {
 
@@ -950,6 +951,23 @@ int cpir_generate_from_seed(uint64_t rows, uint64_t cols, const uint8_t seed[CPI
   xof.squeeze(reinterpret_cast<uint8_t*>(out), (size_t)(rows * cols) * 4);
   return CPIR_OK;
 }
+
+int cpir_xof_open(const uint8_t seed[CPIR_SEED_BYTE_LEN], cpir_xof** out) {
+  if (!seed || !out) return CPIR_ERR_INVALID_ARGUMENT;
+  cpir_xof* x = new cpir_xof;
+  x->absorb(seed, CPIR_SEED_BYTE_LEN);  // matrix.rs:542-544
+  x->finalize(0x1F);
+  *out = x;
+  return CPIR_OK;
+}
+
+int cpir_xof_squeeze(cpir_xof* xof, void* out, size_t bytes) {
+  if (!xof || (!out && bytes)) return CPIR_ERR_INVALID_ARGUMENT;
+  xof->squeeze(static_cast<uint8_t*>(out), bytes);
+  return CPIR_OK;
+}
+
+void cpir_xof_close(cpir_xof* xof) { delete xof; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // low-level device operations

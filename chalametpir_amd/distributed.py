@@ -59,6 +59,74 @@ def reduce_u32_(t, dst: int = 0, group=None):
     return dist.reduce(view, dst=dst, op=dist.ReduceOp.SUM, group=group)
 
 
+def scatter_public_matrix(seed_mu: bytes, total_slots: int, unit, device=None, group=None, rows: int = 1774, block_bytes: int = 64 << 20):
+    """This rank's column slab  A[:, n_g : n_{g+1}]  of the public matrix A = generate_from_seed(rows, total_slots, seed_mu)
+    (reference matrix.rs:541-558, server.rs:59), with ONE expansion of the sponge per process group instead of one per rank: rank 0
+    squeezes A block of rows by block of rows (the XOF is sequential: ~2 GB/s on one core) into page-locked memory, uploads the block
+    and sends every other rank its column slab of the block (point-to-point: RCCL send/recv over xGMI under the "nccl" backend) while it
+    squeezes the next block;
+    every rank receives straight into the rows of its slab.  `unit` as in shard_range.  Returns (slab [rows x n_g] int32 on `device`,
+    lo, hi).  Works on CPU tensors under gloo (device=None): that is how the CPU test drives it."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from .server import SeedExpander
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    bounds = [shard_range(total_slots, unit, r, world) for r in range(world)]
+    lo, hi = bounds[rank]
+    dev = torch.device("cpu") if device is None else torch.device(device)
+    slab = torch.empty((rows, hi - lo), dtype=torch.int32, device=dev)
+    rb = max(1, min(rows, block_bytes // (4 * total_slots)))
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    if rank == 0:
+        xof = SeedExpander(seed_mu)
+        host = [torch.empty((rb, total_slots), dtype=torch.int32) for _ in range(2)]
+        if dev.type == "cuda":
+            host = [h.pin_memory() for h in host]
+        staged = [None, None]  # event after the upload that last read host buffer i
+    pending = []
+    for i, r0 in enumerate(range(0, rows, rb)):
+        n = min(rb, rows - r0)
+        recv = slab[r0:r0 + n]  # n whole rows of the slab: contiguous
+        if rank == 0:
+            b = i & 1
+            if staged[b] is not None:  # the upload that read this host buffer two blocks ago must be done before it is overwritten
+                if dev.type == "cuda":
+                    staged[b][0].synchronize()
+                staged[b] = None
+            xof.squeeze_into(host[b].numpy().view(np.uint32)[:n])  # releases the GIL: the previous block's upload + scatter run meanwhile
+            blk = host[b][:n].to(dev, non_blocking=True) if dev.type == "cuda" else host[b][:n].clone()  # never send from the staging buffer itself
+            if dev.type == "cuda":
+                ev = torch.cuda.Event()
+                ev.record()
+                staged[b] = (ev,)
+            recv.copy_(blk[:, lo:hi])  # rank 0's own slab
+            works, keep = [], []
+            parts = {g: blk[:, bounds[g][0]:bounds[g][1]].contiguous() for g in range(1, world) if bounds[g][1] > bounds[g][0]}
+            if dev.type == "cuda" and dist.get_backend(group) != "nccl":
+                torch.cuda.current_stream().synchronize()  # a host-staged backend (gloo: the one-GPU test hook) must not read a slab still being written
+            for g in range(1, world):  # shards differ in size (ragged tail, empty shards), so point-to-point rather than dist.scatter
+                a_, z_ = bounds[g]
+                if z_ > a_:
+                    part = parts[g]
+                    keep.append(part)
+                    works.append(dist.isend(part, dst=dist.get_global_rank(group, g) if group is not None else g, group=group))
+            pending.append((works, keep))
+        elif hi > lo:
+            pending.append(([dist.irecv(recv, src=src, group=group)], None))
+        while len(pending) > 4:  # bounded queue of transfers in flight
+            for w in pending.pop(0)[0]:
+                w.wait()
+    for works, _ in pending:
+        for w in works:
+            w.wait()
+    if rank == 0:
+        xof.close()
+    return slab, lo, hi
+
+
 class ShardedServer:
     """One rank's shard of a database plus the collective that completes a response.
 

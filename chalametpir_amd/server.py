@@ -157,6 +157,33 @@ def generate_from_seed(rows: int, cols: int, seed: bytes) -> np.ndarray:
     return out
 
 
+class SeedExpander:
+    """The XOF stream behind Matrix::generate_from_seed (reference matrix.rs:541-558), squeezed piecemeal (cpir_xof_*): `squeeze_into(a)`
+    fills the u32 array `a` with the next a.size words of the row-major matrix."""
+
+    def __init__(self, seed: bytes):
+        self._lib = _native.load()
+        h = C.c_void_p()
+        _check(self._lib.cpir_xof_open(_seed_arg(seed), C.byref(h)))
+        self._h = h
+
+    def squeeze_into(self, out: np.ndarray) -> None:
+        if out.dtype != np.uint32 or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("expected a contiguous uint32 array")
+        _check(self._lib.cpir_xof_squeeze(self._h, _ptr(out), out.nbytes))
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.cpir_xof_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def encode_kv_database(db: Mapping[bytes, bytes], arity: int, mat_elem_bit_len: int, filter_seed_material: Optional[bytes] = None,
                        max_attempts: int = SERVER_SETUP_MAX_ATTEMPT_COUNT) -> Tuple[np.ndarray, bytes]:
     """Matrix::from_kv_database::<ARITY> (reference matrix.rs:633-648) on the host -> (D as N x C u32, filter_param_bytes)"""

@@ -100,6 +100,14 @@ uint64_t cpir_encoded_num_cols(uint64_t max_value_byte_len, uint32_t mat_elem_bi
 /* Matrix::generate_from_seed (matrix.rs:541-558): TurboSHAKE128(seed || 0x1F) squeezed into rows*cols LE u32.
  * Host-side, sequential by construction of the sponge. */
 int cpir_generate_from_seed(uint64_t rows, uint64_t cols, const uint8_t seed[CPIR_SEED_BYTE_LEN], uint32_t* out);
+/* The same stream, squeezed piecemeal: open = TurboSHAKE128 absorbed seed || 0x1F, every squeeze continues where the last one stopped
+ * (so rows * cols * 4 bytes squeezed in any pieces are generate_from_seed's matrix).  Lets ONE process of a node expand A block by block
+ * and hand column slabs to the ranks that hold the shards (chalametpir_amd.distributed.scatter_public_matrix) instead of every rank
+ * squeezing the whole sponge.  Not thread-safe per handle. */
+typedef struct cpir_xof cpir_xof;
+int cpir_xof_open(const uint8_t seed[CPIR_SEED_BYTE_LEN], cpir_xof** out);
+int cpir_xof_squeeze(cpir_xof* xof, void* out, size_t bytes);
+void cpir_xof_close(cpir_xof* xof);
 /* Which Keccak-p[1600,12] implementation this host runs for the XOF ("scalar" or "avx512vl (lane per xmm)"); picked once at
  * load time from the CPU's features, CPIR_XOF_SCALAR=1 in the environment forces the scalar one. */
 const char* cpir_xof_permutation(void);

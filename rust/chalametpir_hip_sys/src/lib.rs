@@ -36,6 +36,10 @@ pub struct cpir_device {
 pub struct cpir_server {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct cpir_xof {
+    _private: [u8; 0],
+}
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
@@ -80,6 +84,9 @@ unsafe extern "C" {
                              num_fingerprints: *mut u64) -> c_int;
     pub fn cpir_encoded_num_cols(max_value_byte_len: u64, mat_elem_bit_len: u32) -> u64;
     pub fn cpir_generate_from_seed(rows: u64, cols: u64, seed: *const u8, out: *mut u32) -> c_int;
+    pub fn cpir_xof_open(seed: *const u8, out: *mut *mut cpir_xof) -> c_int;
+    pub fn cpir_xof_squeeze(xof: *mut cpir_xof, out: *mut c_void, bytes: usize) -> c_int;
+    pub fn cpir_xof_close(xof: *mut cpir_xof);
     pub fn cpir_xof_permutation() -> *const c_char;
     pub fn cpir_host_alloc(bytes: usize, out: *mut *mut core::ffi::c_void) -> c_int;
     pub fn cpir_host_free(p: *mut core::ffi::c_void);
