@@ -98,6 +98,8 @@ int launch_mat_x_mat_mfma(const Device* dev, const uint32_t* A, uint64_t lda, co
                           uint32_t* M, uint64_t ldm, uint64_t rows, uint64_t ws_max_rows, int accumulate, hipStream_t stream);
 bool mfma_matmul_enabled();
 void set_mfma_matmul(bool on);
+int mfma_pipeline();
+void set_mfma_pipeline(int on);
 int mfma_ablate();
 void set_mfma_ablate(int bits);
 

@@ -260,6 +260,9 @@ __global__ void __launch_bounds__(kThreads) mat_x_mat_u32_kernel(const MatArgs a
 static std::atomic<int> g_use_mfma{1};  // cpir_tuning_set("matmul.mfma", 0) keeps the VALU kernels (A/B timing, tests of both paths)
 bool mfma_matmul_enabled() { return g_use_mfma.load() != 0; }
 void set_mfma_matmul(bool on) { g_use_mfma.store(on ? 1 : 0); }
+static std::atomic<int> g_mfma_pipeline{1};
+int mfma_pipeline() { return g_mfma_pipeline.load(); }
+void set_mfma_pipeline(int on) { g_mfma_pipeline.store(on); }
 static std::atomic<int> g_mfma_ablate{0};
 int mfma_ablate() { return g_mfma_ablate.load(); }
 void set_mfma_ablate(int bits) { g_mfma_ablate.store(bits); }

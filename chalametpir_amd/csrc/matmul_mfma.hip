@@ -307,6 +307,399 @@ __global__ void __launch_bounds__(kMT) __attribute__((amdgpu_waves_per_eu(2, 2))
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// 2b. the same product, software-pipelined by hand (the default)
+// ---------------------------------------------------------------------------------------------------------------
+// What the kernel above leaves on the table (measured at 2^20 keys: 16.9 ms against 8.4 ms for its MFMA + LDS-read loop alone): hipcc puts
+// `s_waitcnt vmcnt(0)` in front of the first LDS read that follows a global_load_lds (the DMA may alias it) and in front of every
+// __syncthreads(), so each k-step waits for the loads it has just issued, and the A conversion (VALU + LDS writes) runs after the MFMAs
+// instead of beside them.  Here every vector-memory operation of the loop is inline asm, which the compiler does not track, and the
+// waits are counted by hand:
+//   * A tiles are requested TWO k-steps ahead into two register sets (a quad of a set is re-requested as soon as it has been converted),
+//     the D planes two k-steps ahead into a ring of three LDS stages; a wave counts the vector-memory operations it has issued, so
+//     "wait until operation X has completed" is `s_waitcnt vmcnt(n)` with n = operations issued after X;
+//   * inside a k-step every wave interleaves its 56 MFMAs of k-step t (four groups of 14, one per 16-row tile) with the conversion of
+//     its four quads of A(t + 1) (one quad behind each group): the two waves of a SIMD then always have both matrix and vector work to
+//     issue, and the conversion hides in the shadow of the MFMAs (a 16-pass MFMA leaves the SIMD's vector issue free half the time);
+//   * ONE raw s_barrier per k-step: LDS writes are drained (lgkmcnt(0)) before it, and a wave has waited for its own DMA pieces of
+//     D(t + 1) before it.  A(t + 1) goes to the A buffer (t + 1) & 1, last read during k-step t - 1; D(t + 2) to stage (t + 2) % 3, ditto.
+constexpr uint32_t kStagesB = 3;
+constexpr uint32_t kPipePieces = 2 * kPiecesA + kStagesB * kPiecesB;  // 112 KiB
+
+// Wait until at most `n` of this wave's vector-memory operations are outstanding.  In steady state n is always the same small number
+// (8 in front of the conversions, 10 behind the MFMAs); anything else (the first and last k-steps of a unit) simply drains.
+template <int STEADY>
+__device__ __forceinline__ void wait_vm_at_most(uint32_t n) {
+  if (n >= STEADY) {
+    if constexpr (STEADY == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (STEADY == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+}
+
+// a pointer the compiler must keep in scalar registers (it is wave-uniform by construction; readfirstlane makes that provable)
+template <typename T>
+__device__ __forceinline__ const T* uniform_ptr(const T* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<const T*>(((uint64_t)hi << 32) | lo);
+}
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct PipeLane {  // per-lane constants of the A staging roles (as in the kernel above: wave-instruction x = 8*j + wave, j < 4)
+  uint32_t row_l[4], kq[4], wdw[4];
+  uint32_t q8;
+};
+
+struct PipeUnit {  // per-unit state of one wave
+  const uint32_t* a_base;   // first row of the block's row tile (wave-uniform)
+  const uint4* b_base;      // this wave's column tile of 16 in the planes, k-step 0 (wave-uniform)
+  uint32_t a_off[4];        // byte offset of this lane's row inside the row tile (rows past the end re-read the last row)
+  bool rvalid[4];
+  uint32_t rs[4];           // row sums of A (only kept by blocks with column tile 0)
+  bool sum_rows;
+  uint32_t issued;          // vector-memory operations this wave has issued in this unit
+};
+
+// request quad j of A(ks) (16 bytes of this lane's row) into `reg`
+__device__ __forceinline__ void pipe_load_quad(const MfmaArgs& a, const PipeLane& pl, PipeUnit& u, v4i& reg, int j, uint32_t ks) {
+  // inner % 4 == 0 (host): a quad lies wholly inside or wholly outside the row; outside (only possible in the last k-step of the K axis) it
+  // meets zero plane bytes, so any readable address does: the start of the row
+  const uint32_t* const base = uniform_ptr(u.a_base);
+  uint32_t off = u.a_off[j] + ks * (kBK * 4u) + pl.kq[j] * 4u;
+  if ((uint64_t)(ks + 1) * kBK > a.inner && (uint64_t)ks * kBK + pl.kq[j] >= a.inner) off = u.a_off[j];
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(reg) : "v"(off), "s"(base) : "memory");
+  u.issued += 1;
+}
+
+// request this wave's two 1 KiB pieces of D(ks) into stage `st` of the LDS ring (LDS-DMA: the destination is M0 + lane * 16); returns the
+// value of `issued` after the request
+__device__ __forceinline__ uint32_t pipe_dma_b(const MfmaArgs& a, PipeUnit& u, uint32_t lds_b0, uint32_t lane, uint32_t wave, uint32_t ks, uint32_t st) {
+  const uint4* const base = uniform_ptr(u.b_base);
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    const uint32_t off = (ks * 2u + (uint32_t)e) * 1024u + lane * 16u;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_b0 + ((st * kPiecesB + wave * 2 + (uint32_t)e) * 1024u));
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(off), "s"(dst), "s"(base)
+                 : "memory");
+  }
+  u.issued += 2;
+  return u.issued;
+}
+
+// the four byte limbs of four consecutive words: limb i = bytes i of (x, y, z, w), eight v_perm_b32 (a 4 x 4 byte transpose in two stages)
+__device__ __forceinline__ void byte_limbs(uint32_t x, uint32_t y, uint32_t z, uint32_t w, uint32_t (&limb)[4]) {
+  const uint32_t a = __builtin_amdgcn_perm(y, x, 0x05010400u);  // x0 y0 x1 y1
+  const uint32_t b = __builtin_amdgcn_perm(y, x, 0x07030602u);  // x2 y2 x3 y3
+  const uint32_t c = __builtin_amdgcn_perm(w, z, 0x05010400u);  // z0 w0 z1 w1
+  const uint32_t d = __builtin_amdgcn_perm(w, z, 0x07030602u);  // z2 w2 z3 w3
+  limb[0] = __builtin_amdgcn_perm(c, a, 0x05040100u);
+  limb[1] = __builtin_amdgcn_perm(c, a, 0x07060302u);
+  limb[2] = __builtin_amdgcn_perm(d, b, 0x05040100u);
+  limb[3] = __builtin_amdgcn_perm(d, b, 0x07060302u);
+}
+
+// split quad j of A (k-step ks_abs = k0 + k) into its four byte limbs and write them into the A buffer k & 1
+__device__ __forceinline__ void pipe_store_quad(const MfmaArgs& a, const PipeLane& pl, PipeUnit& u, uint4* lds, const v4i& reg, int j, uint32_t k,
+                                                uint32_t ks_abs) {
+  uint32_t* base = reinterpret_cast<uint32_t*>(lds + (k & 1) * kPiecesA * 64);
+  const uint32_t x = (uint32_t)reg[0], y = (uint32_t)reg[1], z = (uint32_t)reg[2], w = (uint32_t)reg[3];
+  if (u.sum_rows) {
+    const bool in = u.rvalid[j] && (uint64_t)ks_abs * kBK + pl.kq[j] < a.inner;
+    u.rs[j] += in ? x + y + z + w : 0u;
+  }
+  uint32_t limb[4];
+  byte_limbs(x ^ 0x80808080u, y ^ 0x80808080u, z ^ 0x80808080u, w ^ 0x80808080u, limb);
+#pragma unroll
+  for (int i = 0; i < 4; i++) base[pl.wdw[j] + i * 256] = limb[i];
+}
+
+// One MFMA and two micro-operations of the conversion of a quad, alternating, the order pinned by sched_barriers: a 16-pass MFMA keeps the
+// SIMD's vector issue busy for only half of its cycles, so the conversion hides behind the MFMAs of the SAME wave (the two waves of a
+// SIMD run in lockstep between barriers: left to itself the compiler issues the 14 MFMAs of a group back to back and both waves then
+// convert at the same time, with the matrix pipe idle).  LDS reads may still move across the pins (the next group's A fragments).
+// (x, y, z, w) = the quad; wbase = where limb 0 of this lane's dword goes; limbs i are 256 dwords apart.
+template <bool SUM>
+__device__ __forceinline__ void mfma_group_with_conversion(v4i (&acc)[2][4], const v4i (&af)[4], const v4i (&bf)[2][2], uint32_t x, uint32_t y,
+                                                           uint32_t z, uint32_t w, uint32_t* wbase, bool store, bool rin, uint32_t& rs) {
+  uint32_t pa = 0, pb = 0, pc = 0, pd = 0, l0 = 0, l1 = 0, l2 = 0, l3 = 0, r1 = 0, r2 = 0;
+  auto micro = [&](int k) {
+    switch (k) {
+      case 0: if constexpr (SUM) r1 = x + y; break;
+      case 1: if constexpr (SUM) r2 = z + w; break;
+      case 2: x ^= 0x80808080u; break;
+      case 3: y ^= 0x80808080u; break;
+      case 4: z ^= 0x80808080u; break;
+      case 5: w ^= 0x80808080u; break;
+      case 6: pa = __builtin_amdgcn_perm(y, x, 0x05010400u); break;  // x0 y0 x1 y1
+      case 7: pb = __builtin_amdgcn_perm(y, x, 0x07030602u); break;  // x2 y2 x3 y3
+      case 8: pc = __builtin_amdgcn_perm(w, z, 0x05010400u); break;
+      case 9: pd = __builtin_amdgcn_perm(w, z, 0x07030602u); break;
+      case 10: l0 = __builtin_amdgcn_perm(pc, pa, 0x05040100u); break;
+      case 11: l1 = __builtin_amdgcn_perm(pc, pa, 0x07060302u); break;
+      case 12: l2 = __builtin_amdgcn_perm(pd, pb, 0x05040100u); break;
+      case 13: l3 = __builtin_amdgcn_perm(pd, pb, 0x07060302u); break;
+      case 14: if constexpr (SUM) r1 += r2; break;
+      case 15: if constexpr (SUM) rs += rin ? r1 : 0u; break;
+      case 16:
+        if (store) wbase[0] = l0, wbase[256] = l1;
+        break;
+      case 17:
+        if (store) wbase[512] = l2, wbase[768] = l3;
+        break;
+      default: break;
+    }
+  };
+#pragma unroll
+  for (int n = 0; n < 2; n++)
+#pragma unroll
+    for (int q = 0; q < 7; q++) {
+      const int sidx = q < 4 ? q : q - 3, ai = q < 4 ? q : q - 4, bj = q < 4 ? 0 : 1, step = n * 7 + q;
+      acc[n][sidx] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[ai], bf[n][bj], acc[n][sidx], 0, 0, 0);
+      if (step < 9) {
+        __builtin_amdgcn_sched_barrier(0x100);
+        micro(2 * step);
+        micro(2 * step + 1);
+        __builtin_amdgcn_sched_barrier(0x100);
+      }
+    }
+}
+
+// One (row tile, column tile, K sub-range) unit for one wave.  Register set S0 carries the even k-steps (relative to k0), S1 the odd ones.
+template <bool SUM>
+__device__ __forceinline__ void mfma_pipe_unit(const MfmaArgs& a, const PipeLane& pl, PipeUnit& u, uint4* lds, uint32_t lds_b0, uint32_t lane,
+                                               uint32_t wave, uint32_t k0, uint32_t T, v4i (&acc)[4][2][4]) {
+  const uint32_t wm = wave >> 2, wn = wave & 3;
+  v4i S0[4], S1[4];
+  // ---- prologue: the first two k-steps are requested, A(0) is converted, A(2) requested behind it ----
+#pragma unroll
+  for (int j = 0; j < 4; j++) pipe_load_quad(a, pl, u, S0[j], j, k0);
+  const uint32_t bm0 = pipe_dma_b(a, u, lds_b0, lane, wave, k0, 0);
+  uint32_t bm_next = 0;  // `issued` after the request for the D stage of the NEXT k-step
+  if (T > 1) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) pipe_load_quad(a, pl, u, S1[j], j, k0 + 1);
+    bm_next = pipe_dma_b(a, u, lds_b0, lane, wave, k0 + 1, 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(S0[0]), "+v"(S0[1]), "+v"(S0[2]), "+v"(S0[3])::"memory");
+  (void)bm0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    pipe_store_quad(a, pl, u, lds, S0[j], j, 0, k0);
+    if (T > 2) pipe_load_quad(a, pl, u, S0[j], j, k0 + 2);
+  }
+  uint32_t set_mark = u.issued;  // `issued` after the last request into the set that is converted NEXT ... (tracked per parity below)
+  uint32_t mark0 = u.issued, mark1 = (T > 1) ? bm_next - 2 : 0;  // after the loads of S0 (A(2)) / S1 (A(1))
+  (void)set_mark;
+  lds_barrier();
+
+  // k-step t: MFMAs of t from A buffer t & 1 and D stage t % 3, with the conversion of A(t + 1) (register set of parity (t + 1) & 1, re-requested
+  // quad by quad with A(t + 3)) interleaved behind the four MFMA groups
+  auto step = [&](uint32_t t, v4i(&set)[4], uint32_t& mark) {
+    uint32_t bm_new = 0;
+    if (t + 2 < T) bm_new = pipe_dma_b(a, u, lds_b0, lane, wave, k0 + t + 2, (t + 2) % kStagesB);
+    const bool conv = t + 1 < T;
+    if (conv) {
+      wait_vm_at_most<8>(u.issued - mark);
+      asm volatile("" : "+v"(set[0]), "+v"(set[1]), "+v"(set[2]), "+v"(set[3])::"memory");
+    }
+    const uint4* A_ = lds + (t & 1) * kPiecesA * 64;
+    const uint4* B_ = lds + (2 * kPiecesA + (t % kStagesB) * kPiecesB) * 64;
+    v4i bf[2][2];
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const uint4 q = B_[((wn * 2 + n) * 2 + j) * 64 + lane];
+        bf[n][j] = v4i{(int)q.x, (int)q.y, (int)q.z, (int)q.w};
+      }
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      v4i af[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const uint4 q = A_[((wm * 4 + m) * 4 + i) * 64 + lane];
+        af[i] = v4i{(int)q.x, (int)q.y, (int)q.z, (int)q.w};
+      }
+      uint32_t* const wbase = reinterpret_cast<uint32_t*>(lds + ((t + 1) & 1) * kPiecesA * 64) + pl.wdw[m];
+      const bool rin = conv && u.rvalid[m] && (uint64_t)(k0 + t + 1) * kBK + pl.kq[m] < a.inner;
+      mfma_group_with_conversion<SUM>(acc[m], af, bf, (uint32_t)set[m][0], (uint32_t)set[m][1], (uint32_t)set[m][2], (uint32_t)set[m][3], wbase,
+                                      conv, rin, u.rs[m]);
+      if (conv && t + 3 < T) pipe_load_quad(a, pl, u, set[m], m, k0 + t + 3);
+    }
+    if (conv) mark = u.issued;
+    if (t + 1 < T) wait_vm_at_most<10>(u.issued - bm_next);  // this wave's pieces of D(t + 1) have landed
+    bm_next = bm_new;
+    lds_barrier();
+  };
+  // ---- steady state: k-steps t with t + 3 inside the unit and no ragged K tail in reach; nothing conditional, every address advanced
+  // by adding a constant to a scalar base, the waits are the literal steady-state counts (see wait_vm_at_most) ----
+  const bool ragged_tail = (uint64_t)(k0 + T) * kBK > a.inner;   // the last k-step of this unit reaches past the end of the rows of A
+  const uint32_t T_safe = ragged_tail ? T - 1 : T;
+  const uint32_t Ts = T_safe > 3 ? ((T_safe - 3) & ~1u) : 0;      // steady steps (an even number: two per loop trip)
+  if (Ts) {
+    const uint32_t* a_run = uniform_ptr(u.a_base + (uint64_t)(k0 + 3) * kBK);      // A(t + 3), advanced by one k-step per step
+    const uint4* b_run = uniform_ptr(u.b_base + (uint64_t)(k0 + 2) * 128);         // D(t + 2)
+    uint32_t aoffq[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) aoffq[j] = u.a_off[j] + pl.kq[j] * 4u;
+    const uint32_t dma_voff = lane * 16u;
+    const uint32_t dma_dst0 = lds_b0 + wave * 2048u;  // this wave's two pieces inside a stage
+    uint32_t st_read = 0, st_dma = 2;                // stage of k-step t, stage that receives D(t + 2)
+    auto steady = [&](uint32_t t, v4i(&set)[4], const uint32_t a_par /* (t + 1) & 1 */, const uint32_t r_par /* t & 1 */) {
+      // the first fragments are requested from LDS before anything else, so that their latency runs while the DMA is being issued
+      const uint4* A_ = lds + r_par * kPiecesA * 64;
+      const uint4* B_ = lds + (2 * kPiecesA + st_read * kPiecesB) * 64;
+      v4i bf[2][2], af0[4];
+#pragma unroll
+      for (int n = 0; n < 2; n++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const uint4 q = B_[((wn * 2 + n) * 2 + j) * 64 + lane];
+          bf[n][j] = v4i{(int)q.x, (int)q.y, (int)q.z, (int)q.w};
+        }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const uint4 q = A_[((wm * 4 + 0) * 4 + i) * 64 + lane];
+        af0[i] = v4i{(int)q.x, (int)q.y, (int)q.z, (int)q.w};
+      }
+      {
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(dma_dst0 + st_dma * (kPiecesB * 1024u));
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %1, %3 offset:1024\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(dma_voff), "s"(dst), "s"(b_run)
+                     : "memory");
+        b_run += 128;
+      }
+      asm volatile("s_waitcnt vmcnt(8)" : "+v"(set[0]), "+v"(set[1]), "+v"(set[2]), "+v"(set[3])::"memory");
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        v4i af[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          if (m == 0) {
+            af[i] = af0[i];
+          } else {
+            const uint4 q = A_[((wm * 4 + m) * 4 + i) * 64 + lane];
+            af[i] = v4i{(int)q.x, (int)q.y, (int)q.z, (int)q.w};
+          }
+        }
+        uint32_t* const wbase = reinterpret_cast<uint32_t*>(lds + a_par * kPiecesA * 64) + pl.wdw[m];
+        mfma_group_with_conversion<SUM>(acc[m], af, bf, (uint32_t)set[m][0], (uint32_t)set[m][1], (uint32_t)set[m][2], (uint32_t)set[m][3],
+                                        wbase, true, u.rvalid[m], u.rs[m]);
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(set[m]) : "v"(aoffq[m]), "s"(a_run) : "memory");
+      }
+      a_run += kBK;
+      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      lds_barrier();
+      st_read = st_read == 2 ? 0 : st_read + 1;
+      st_dma = st_dma == 2 ? 0 : st_dma + 1;
+      (void)t;
+    };
+    for (uint32_t t = 0; t < Ts; t += 2) {
+      steady(t, S1, 1, 0);
+      steady(t + 1, S0, 0, 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain once; the remaining steps run on the generic path with exact bookkeeping
+    u.issued = 0, mark0 = 0, mark1 = 0, bm_next = 0;
+  }
+  for (uint32_t t = Ts; t < T; t += 2) {  // (unrolled by two so that the register set of each step is a compile-time choice; Ts is even)
+    step(t, S1, mark1);
+    if (t + 1 < T) step(t + 1, S0, mark0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__global__ void __launch_bounds__(kMT) __attribute__((amdgpu_waves_per_eu(2, 2))) mat_x_mat_mfma_pipe_kernel(const MfmaArgs a) {
+  __shared__ uint4 lds[kPipePieces * 64];
+
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t wm = wave >> 2, wn = wave & 3;
+  const uint32_t xcd = blockIdx.x % a.nx, slot = blockIdx.x / a.nx, slots = gridDim.x / a.nx;  // host: gridDim.x % nx == 0
+  const uint32_t ksx0 = (uint32_t)(((uint64_t)a.KS * xcd) / a.nx), ksx1 = (uint32_t)(((uint64_t)a.KS * (xcd + 1)) / a.nx);
+  const uint32_t pairs = a.RT * a.CT;
+  const uint64_t units = (uint64_t)pairs * a.S;
+  const uint32_t lds_b0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(&lds[2 * kPiecesA * 64]);
+
+  PipeLane pl;
+  const uint32_t r8 = lane >> 3;
+  pl.q8 = lane & 7;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t x = 8 * j + wave, h = x & 1, rb = x >> 1;
+    pl.row_l[j] = 8 * rb + r8;
+    const uint32_t q = 8 * h + pl.q8;
+    pl.kq[j] = 4 * q;
+    pl.wdw[j] = (((pl.row_l[j] >> 4) * 4) * 64 + 16 * (q >> 2) + (pl.row_l[j] & 15)) * 4 + (q & 3);
+  }
+
+  for (uint64_t un = slot; un < units; un += slots) {
+    const uint32_t sub = (uint32_t)(un / pairs), pair = (uint32_t)(un % pairs), rt = pair / a.CT, ct = pair % a.CT;
+    const uint32_t k0 = ksx0 + (uint32_t)(((uint64_t)(ksx1 - ksx0) * sub) / a.S);
+    const uint32_t k1 = ksx0 + (uint32_t)(((uint64_t)(ksx1 - ksx0) * (sub + 1)) / a.S);
+    if (k0 >= k1) continue;  // block-uniform
+
+    PipeUnit u;
+    u.a_base = uniform_ptr(a.A + (uint64_t)rt * kBM * a.lda);
+    u.b_base = uniform_ptr(a.planes + (uint64_t)(ct * 8 + wave) * a.KS * 128);  // 2 pieces of 64 uint4 per k-step
+    u.sum_rows = (ct == 0);
+    u.issued = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint64_t r = (uint64_t)rt * kBM + pl.row_l[j];
+      u.rvalid[j] = r < a.rows;
+      const uint64_t rr = u.rvalid[j] ? pl.row_l[j] : (a.rows - 1 - (uint64_t)rt * kBM);  // rows past the end re-read the last row
+      u.a_off[j] = (uint32_t)(rr * a.lda * 4);                                            // host: (kBM - 1) * lda * 4 + inner * 4 < 2^32
+      u.rs[j] = 0;
+    }
+
+    v4i acc[4][2][4];
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+      for (int n = 0; n < 2; n++)
+#pragma unroll
+        for (int s2 = 0; s2 < 4; s2++) acc[m][n][s2] = v4i{0, 0, 0, 0};
+
+    if (u.sum_rows) mfma_pipe_unit<true>(a, pl, u, lds, lds_b0, lane, wave, k0, k1 - k0, acc);
+    else mfma_pipe_unit<false>(a, pl, u, lds, lds_b0, lane, wave, k0, k1 - k0, acc);
+
+    // ---- this unit's part of the output tile: sum_s acc_s << 8s, one u32 atomic per element ----
+    const uint32_t fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+      for (int n = 0; n < 2; n++) {
+        const uint64_t c = (uint64_t)ct * kBN + wn * 32 + n * 16 + fr;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const uint64_t r = (uint64_t)rt * kBM + wm * 64 + m * 16 + fq * 4 + i;
+          const uint32_t v = (uint32_t)acc[m][n][0][i] + ((uint32_t)acc[m][n][1][i] << 8) + ((uint32_t)acc[m][n][2][i] << 16) +
+                             ((uint32_t)acc[m][n][3][i] << 24);
+          if (r < a.rows && c < a.cols) atomicAdd(a.M + r * a.ldm + c, v);
+        }
+      }
+    if (u.sum_rows) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        uint32_t s2 = u.rs[j];
+        s2 += __shfl_xor(s2, 1, 64);
+        s2 += __shfl_xor(s2, 2, 64);
+        s2 += __shfl_xor(s2, 4, 64);
+        if (pl.q8 == 0 && u.rvalid[j] && s2) atomicAdd(a.rowsum + (uint64_t)rt * kBM + pl.row_l[j], s2);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // 3. correction terms
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kThreads) hint_fixup_kernel(uint32_t* __restrict__ M, uint64_t ldm, uint64_t rows, uint64_t cols,
@@ -389,7 +782,10 @@ int launch_mat_x_mat_mfma(const Device* dev, const uint32_t* A, uint64_t lda, co
 
   CPIR_HIP_TRY(hipMemsetAsync(a.rowsum, 0, 4 * round_up((uint32_t)rows, kBM), stream));
   if (!accumulate) CPIR_HIP_TRY(hipMemset2DAsync(M, ldm * sizeof(uint32_t), 0, cols * sizeof(uint32_t), rows, stream));
-  hipLaunchKernelGGL(mat_x_mat_mfma_kernel, dim3(grid), dim3(kMT), 0, stream, a);
+  // the hand-pipelined kernel addresses a row tile of A with 32-bit byte offsets
+  const bool pipe = mfma_pipeline() != 0 && ((uint64_t)(kBM - 1) * lda + inner) * 4 < (1ull << 32) && (uint64_t)a.KS * 2048 + 2048 < (1ull << 32);
+  if (pipe) hipLaunchKernelGGL(mat_x_mat_mfma_pipe_kernel, dim3(grid), dim3(kMT), 0, stream, a);
+  else hipLaunchKernelGGL(mat_x_mat_mfma_kernel, dim3(grid), dim3(kMT), 0, stream, a);
   const uint32_t k_term = (uint32_t)inner * (0x80808080u * 0x8080u);
   uint64_t fb = (rows * cols + kThreads - 1) / kThreads;
   if (fb > (uint64_t)dev->num_cus * 8) fb = (uint64_t)dev->num_cus * 8;

@@ -372,6 +372,8 @@ extern "C" int cpir_tuning_set(const char* key, int value) {
     set_default_planar(value != 0);
   } else if (!strcmp(key, "matmul.mfma")) {
     set_mfma_matmul(value != 0);
+  } else if (!strcmp(key, "matmul.pipeline")) {
+    set_mfma_pipeline(value != 0);
   } else if (!strcmp(key, "matmul.ablate")) {
     set_mfma_ablate(value);
   } else {
