@@ -369,7 +369,9 @@ def main() -> int:
         cp.tuning_set("respond.interleave_passes", -1)
     # the C-ABI host path a Rust caller uses: query bytes on the host -> pinned copy -> H2D -> kernel -> D2H -> bytes
     if world == 1 and not args.no_host_path:
+        cp.tuning_set("respond.batch_fusion", 1)  # the library's own default: coalesced callers share one stream of the database
         result["respond_host_path"] = host_path_timing(sharded.local, q_pool, N, torch)
+        cp.tuning_set("respond.batch_fusion", 0)
     if world == 1 and not args.no_host_path:
         n_vis = torch.cuda.device_count()
         k = args.group_shards or (n_vis if n_vis >= 2 else 0)

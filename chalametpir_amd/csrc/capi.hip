@@ -281,8 +281,13 @@ static int arena_create(Server* srv, RespondArena& a) {
   };
   hipError_t e = hipSuccess;
   if (!srv->streams_ready) {
+    // The two streams must not share a hardware queue (uploads would then serialise with kernels): HIP multiplexes the streams of one
+    // priority level over a handful of queues in creation order, and a host process (torch, say) has usually created several already.
+    // The run stream is created at the highest priority, which has queues of its own.
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // (least, greatest): numerically greatest <= least
     e = hipStreamCreateWithFlags(&srv->up_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&srv->run_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&srv->run_stream, hipStreamNonBlocking, prio_hi);
     if (e != hipSuccess) {
       if (srv->up_stream) (void)hipStreamDestroy(srv->up_stream);
       srv->up_stream = srv->run_stream = nullptr;

@@ -38,7 +38,7 @@ def is_respond(name):
     return "respond_kernel" in name or "respond_planar_kernel" in name
 
 
-def traffic_record(root, summary, tag):
+def traffic_record(root, summary, tag, git_head=""):
     """profiles/respond_traffic.json: HBM bytes per pass from the two counter passes, with the guide's gfx950 correction
     (FETCH_SIZE counts 64 B per 128 B request of a 16 B/lane coalesced stream -> x2; WRITE_SIZE as is), next to the byte
     counts the bench run under the profiler reports for the same launch"""
@@ -55,7 +55,13 @@ def traffic_record(root, summary, tag):
     traffic = (2 * r["FETCH_SIZE_mean_raw"] + r.get("WRITE_SIZE_mean_raw", 0.0)) * 1024 / passes
     algo = roof["bytes_per_launch"] / passes
     layout = roof["moved_bytes_per_launch"] / passes
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_sha256  # fingerprint of the respond kernels' sources as they were when this was measured
+
     return {
+        "config": bench["config"]["workload"].split(":")[0],
+        "git_head": git_head,
+        "kernel_source_sha256": kernel_source_sha256(),
         "kernel": r.get("name", ""),
         "workload": bench["config"]["workload"],
         "packing": roof["packing"].split(" ")[0],
@@ -78,6 +84,7 @@ def traffic_record(root, summary, tag):
 
 def main():
     root, tag = sys.argv[1], sys.argv[2]
+    git_head = sys.argv[3] if len(sys.argv) > 3 else ""
     summary = {"tag": tag, "kernels": [], "respond": {}}
     print(f"== rocprofv3 summary [{tag}] ==")
     stats = kernel_stats(os.path.join(root, "trace"))
@@ -114,7 +121,7 @@ def main():
             avg, tot = float(r.get("AverageNs", 0) or 0), float(r.get("TotalDurationNs", 0) or 0)
             print(f"{calls:7d} calls  avg {avg / 1e3:10.2f} us  total {tot / 1e6:10.3f} ms  {name[:110]}")
             summary["setup_kernels"].append({"name": name, "calls": calls, "avg_us": avg / 1e3, "total_ms": tot / 1e6})
-    tr = traffic_record(root, summary, tag)
+    tr = traffic_record(root, summary, tag, git_head)
     if tr:
         print(f"-- HBM traffic per pass: {tr['traffic_bytes_per_pass'] / 1e9:.4f} GB = {tr['traffic_over_algorithmic']:.3f} x algorithmic, "
               f"{tr['traffic_over_layout_bytes']:.3f} x the bytes of the resident layout")
