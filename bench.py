@@ -41,6 +41,8 @@ CONFIGS = {
     "cfg5": (1 << 20, 3, 8192),
     "cfg1": (1 << 16, 3, 1024),
     "tiny": (1 << 12, 3, 64),
+    # beyond BASELINE.json: a key count at which the reference's bit-length rule (server.rs:193-218) drops to b = 8 (byte-per-field planar)
+    "b8": (1 << 23, 3, 256),
 }
 
 SEED_D, SEED_Q = 0xD, 0x1000

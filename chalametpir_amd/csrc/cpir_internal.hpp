@@ -130,6 +130,7 @@ int dtc_layout_for(uint64_t N, uint32_t C, uint32_t b, cpir_dtc_layout* out);
 int dtc_layout_for_packing(uint64_t N, uint32_t C, uint32_t b, uint32_t packing, cpir_dtc_layout* out);
 uint32_t dense_fields_per_word64(uint32_t b);
 uint32_t planar_hi_planes(uint32_t b);
+bool planar_offered(uint32_t b);
 void set_default_dense(bool on);
 void set_default_planar(bool on);
 int check_layout(const cpir_dtc_layout& L);

@@ -97,13 +97,11 @@ uint32_t dense_fields_per_word64(uint32_t b) {
   return k > 2 * cf ? k : 0;
 }
 
-// bit planes above the low byte in the planar packing, or 0 where it is not offered.  planar stores a field as its low
-// byte plus (b - 8) one-bit planes: exactly b bits per field, so it is offered where that beats both other packings
-// (b >= 9; at b <= 8 the reference packing already spends 8 bits per field)
-uint32_t planar_hi_planes(uint32_t b) {
-  if (compression_factor(b) == 0 || b < 9) return 0;
-  return b - 8;
-}
+// bit planes above the low byte in the planar packing.  planar stores a field as its low byte plus (b - 8) one-bit planes: exactly
+// b bits per field for b >= 9; for b <= 8 the byte alone (8 bits per field, what the reference packing spends there too), so that
+// every bit length the reference allows runs on the matrix cores
+uint32_t planar_hi_planes(uint32_t b) { return (compression_factor(b) != 0 && b >= 9) ? b - 8 : 0; }
+bool planar_offered(uint32_t b) { return compression_factor(b) != 0; }
 
 static std::atomic<int> g_default_dense{1};
 static std::atomic<int> g_default_planar{1};
@@ -134,7 +132,6 @@ int dtc_layout_for_packing(uint64_t N, uint32_t C, uint32_t b, uint32_t packing,
     // super-tiles of 16 columns x 512 slots: 8 KiB of low bytes + 1 KiB per high bit plane, stored tile after tile
     // (column tile major, then along the slots); after the tiles one u32 per padded column: the wrap-around sum of its fields
     const uint32_t hb = planar_hi_planes(b);
-    if (hb == 0) return CPIR_ERR_INVALID_ARGUMENT;
     const uint64_t rp = ((uint64_t)C + CPIR_DTC_ROW_ALIGN - 1) / CPIR_DTC_ROW_ALIGN * CPIR_DTC_ROW_ALIGN;
     if (rp > 0xffffffffull) return CPIR_ERR_INVALID_MATRIX_DIMENSION;
     out->fields_per_word = 0;
@@ -159,7 +156,7 @@ int dtc_layout_for_packing(uint64_t N, uint32_t C, uint32_t b, uint32_t packing,
 }
 
 int dtc_layout_for(uint64_t N, uint32_t C, uint32_t b, cpir_dtc_layout* out) {
-  if (g_default_planar.load() && planar_hi_planes(b) != 0) return dtc_layout_for_packing(N, C, b, CPIR_PACK_PLANAR, out);
+  if (g_default_planar.load() && planar_offered(b)) return dtc_layout_for_packing(N, C, b, CPIR_PACK_PLANAR, out);
   const bool dense = g_default_dense.load() && dense_fields_per_word64(b) != 0;
   return dtc_layout_for_packing(N, C, b, dense ? CPIR_PACK_DENSE64 : CPIR_PACK_REFERENCE, out);
 }

@@ -349,6 +349,7 @@ struct PackStreamArgs {
   const uint32_t* D;
   uint64_t ld, N;
   uint32_t C, col_tiles, stripe_groups, ks_total;
+  uint32_t low_mask;  // (2^b - 1) in every byte for b < 8 (the fields are masked to b bits: matrix.rs:121,149,181), all ones otherwise
   uint4* tiles;
   uint32_t* colsum;
   uint32_t* or_of_entries;
@@ -359,6 +360,7 @@ template <int HB, bool VEC, bool GUARD>
 __device__ __forceinline__ void pack_stream_unit(const PackStreamArgs& a, uint4* my_stage, uint32_t lane, uint32_t stripe, uint32_t ks) {
   constexpr uint32_t ST16 = (8 + HB) * 64;  // uint4 per super-tile
   constexpr uint32_t HMASK = ((1u << HB) - 1u) * 0x01010101u;
+  constexpr int HP = HB ? HB : 1;  // (no zero-length arrays)
   const uint32_t g = lane >> 4, lc = lane & 15;
   const uint32_t c0 = stripe * 64 + 4 * lc;  // this lane's first column
   const uint64_t n0 = (uint64_t)ks * CPIR_PLANAR_SLOTS_PER_TILE;
@@ -370,12 +372,12 @@ __device__ __forceinline__ void pack_stream_unit(const PackStreamArgs& a, uint4*
   const uint32_t csafe = cvalid[0] ? c0 : 0;
   const uint32_t piece0 = 64 * (lc >> 2) + 16 * g + 4 * (lc & 3);
 
-  uint32_t plane[4][HB][4];
+  uint32_t plane[4][HP][4];
   uint32_t lowsum[4] = {0, 0, 0, 0}, seen = 0;
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
-    for (int p = 0; p < HB; p++)
+    for (int p = 0; p < HP; p++)
 #pragma unroll
       for (int w = 0; w < 4; w++) plane[i][p][w] = 0;
 
@@ -412,14 +414,16 @@ __device__ __forceinline__ void pack_stream_unit(const PackStreamArgs& a, uint4*
     for (int i = 0; i < 4; i++)
 #pragma unroll
       for (int d = 0; d < 4; d++) {
-        const uint32_t lo = gather_byte4(v[4 * d][i], v[4 * d + 1][i], v[4 * d + 2][i], v[4 * d + 3][i], 0x0400u);
+        const uint32_t lo = gather_byte4(v[4 * d][i], v[4 * d + 1][i], v[4 * d + 2][i], v[4 * d + 3][i], 0x0400u) & a.low_mask;
         lowsum[i] = __builtin_amdgcn_sad_u8(lo, 0u, lowsum[i]);
         W[i][d] = lo ^ 0x80808080u;  // signed-byte operand
         // bits 8.. of the four fields, one per byte (fields are masked to b bits: matrix.rs:121,149,181), spread over the planes:
         // plane p, dword kb >> 1, bit 8*jj + 4*(kb & 1) + d  <-  bit 8+p of slot 64*kb + 16*g + 4*d + jj
-        const uint32_t hi = gather_byte4(v[4 * d][i], v[4 * d + 1][i], v[4 * d + 2][i], v[4 * d + 3][i], 0x0501u) & HMASK;
+        if constexpr (HB > 0) {
+          const uint32_t hi = gather_byte4(v[4 * d][i], v[4 * d + 1][i], v[4 * d + 2][i], v[4 * d + 3][i], 0x0501u) & HMASK;
 #pragma unroll
-        for (int p = 0; p < HB; p++) plane[i][p][kb >> 1] |= ((hi >> p) & 0x01010101u) << (4 * (kb & 1) + d);
+          for (int p = 0; p < HB; p++) plane[i][p][kb >> 1] |= ((hi >> p) & 0x01010101u) << (4 * (kb & 1) + d);
+        }
       }
     // materialise the accumulators now (as `seen` above): the compiler would otherwise sink this k-block's plane arithmetic to where the
     // planes are stored, after the last k-block, and keep all 64 loaded values of all 8 k-blocks alive (512 registers + scratch)
@@ -520,7 +524,7 @@ int launch_planar_pack(const uint32_t* src, uint64_t ld, bool from_ref, const cp
   const uint32_t hb = planar_hi_planes(L.mat_elem_bit_len);
   const uint64_t ks_total = (L.num_slots + CPIR_PLANAR_SLOTS_PER_TILE - 1) / CPIR_PLANAR_SLOTS_PER_TILE;
   const uint32_t col_tiles = L.rows_padded / 16;
-  if (hb == 0 || ks_total > 0x7fffffffull || col_tiles > 65535u) return CPIR_ERR_INVALID_ARGUMENT;
+  if (!planar_offered(L.mat_elem_bit_len) || ks_total > 0x7fffffffull || col_tiles > 65535u) return CPIR_ERR_INVALID_ARGUMENT;
   uint32_t* colsum = dtc + (uint64_t)L.rows_padded * L.words_per_row_padded;
   CPIR_HIP_TRY(hipMemsetAsync(colsum, 0, (size_t)L.rows_padded * sizeof(uint32_t), stream));
   if (from_ref) {
@@ -537,6 +541,7 @@ int launch_planar_pack(const uint32_t* src, uint64_t ld, bool from_ref, const cp
   PackStreamArgs pa;
   pa.D = src, pa.ld = ld, pa.N = L.num_slots, pa.C = L.num_cols, pa.col_tiles = col_tiles, pa.stripe_groups = stripe_groups;
   pa.ks_total = (uint32_t)ks_total, pa.tiles = reinterpret_cast<uint4*>(dtc), pa.colsum = colsum, pa.or_of_entries = or_of_entries;
+  pa.low_mask = L.mat_elem_bit_len < 8 ? ((1u << L.mat_elem_bit_len) - 1u) * 0x01010101u : 0xFFFFFFFFu;
 #define LAUNCH_PP2(HB_, VEC_)                                                                                                       \
   do {                                                                                                                              \
     if (full_steps)                                                                                                                 \
@@ -552,6 +557,7 @@ int launch_planar_pack(const uint32_t* src, uint64_t ld, bool from_ref, const cp
     else LAUNCH_PP2(HB_, false);     \
   } while (0)
   switch (hb) {
+    case 0: LAUNCH_PP(0); break;
     case 1: LAUNCH_PP(1); break;
     case 2: LAUNCH_PP(2); break;
     case 3: LAUNCH_PP(3); break;

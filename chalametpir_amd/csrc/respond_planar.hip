@@ -263,7 +263,7 @@ respond_planar_kernel(const PlanarArgs a) {
           const uint4 au = abuf[par][s][kb][lane];
           const v4i af = as_v4i(au);
           acc_lo[s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, as_v4i(cur[kb]), acc_lo[s], 0, 0, 0);
-          acc_hi[s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, hb, acc_hi[s], 0, 0, 0);
+          if constexpr (HB > 0) acc_hi[s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, hb, acc_hi[s], 0, 0, 0);
         }
       }
     }
@@ -324,6 +324,7 @@ using KernelFn = void (*)(const PlanarArgs);
 template <int NS>
 KernelFn pick_hb(uint32_t hb, bool nt) {
   switch (hb) {
+    case 0: return nt ? respond_planar_kernel<0, NS, true> : respond_planar_kernel<0, NS, false>;  // b <= 8: the byte alone
     case 1: return nt ? respond_planar_kernel<1, NS, true> : respond_planar_kernel<1, NS, false>;
     case 2: return nt ? respond_planar_kernel<2, NS, true> : respond_planar_kernel<2, NS, false>;
     case 3: return nt ? respond_planar_kernel<3, NS, true> : respond_planar_kernel<3, NS, false>;

@@ -144,8 +144,9 @@ const char* cpir_mat_x_mat_kernel_name(uint32_t rhs_max_bits);
  *                       m = L*512 + 2t + e  <->  p = 4t + 2L + e  (t < 256, L,e in {0,1}): lane t of a workgroup then reads
  *                       two fully coalesced 16-byte pieces per row and, per field plane j, ONE aligned 16-byte piece of q.
  *
- *  CPIR_PACK_PLANAR     exactly b bits per field, laid out as operands of the i8 matrix cores (v_mfma_i32_16x16x64_i8), offered
- *                       for b >= 9: a field is split into its low byte and (b - 8) one-bit planes.  The unit is a super-tile of
+ *  CPIR_PACK_PLANAR     laid out as operands of the i8 matrix cores (v_mfma_i32_16x16x64_i8): a field is split into its low byte and, for
+ *                       b >= 9, (b - 8) one-bit planes -- exactly b bits per field; for b <= 8 the byte alone (8 bits per field, what
+ *                       the reference packing spends there too).  The unit is a super-tile of
  *                       16 columns x 512 slots = 8 k-blocks of 64 slots: 8 x 1 KiB of low bytes (k-block kb, lane l = 16*g + c holds,
  *                       in byte j of its 16 bytes, (f XOR 0x80) & 0xFF of column c, slot 64*kb + 16*g + j -- the B operand of one
  *                       MFMA as it stands) followed by 1 KiB per bit plane p (lane l holds 4 dwords; dword w, bit 8*jj + 4*s + d is
@@ -174,15 +175,15 @@ typedef struct cpir_dtc_layout {
   uint32_t packing;              /* CPIR_PACK_REFERENCE, CPIR_PACK_DENSE64 or CPIR_PACK_PLANAR */
   uint32_t fields_per_word;      /* cf (per u32) for the reference packing, K (per u64) for dense64, 0 for planar */
   uint32_t chunk_words;          /* u32 words of one row per chunk: 1024 (reference) or 2048 (dense64); planar: u32 words of one
-                                    super-tile = (8 + b - 8) * 256 */
+                                    super-tile = max(b, 8) * 256 */
   uint64_t slots_per_chunk;      /* cf*1024 (reference), K*1024 (dense64), 512 (planar); see cpir_shard_unit */
 } cpir_dtc_layout;
 #define CPIR_DTC_WORD_ALIGN 1024u
 #define CPIR_DTC_ROW_ALIGN 16u
 
-/* Default layout for a database shape: planar where it is offered (b >= 9: every BASELINE config; the matrix-core respond), else
- * dense64 where it is offered (b = 7), else the reference packing (b in {4, 5, 6, 8}).  cpir_tuning_set("layout.planar", 0) /
- * ("layout.dense", 0) switch the first two off process-wide (then b in {9, 11, 12} fall to dense64, the rest to the reference packing). */
+/* Default layout for a database shape: planar (the matrix-core respond) for every bit length.  cpir_tuning_set("layout.planar", 0)
+ * switches it off process-wide: then dense64 where it is offered (b in {7, 9, 11, 12}), else the reference packing;
+ * ("layout.dense", 0) switches dense64 off as well. */
 int cpir_dtc_layout_for(uint64_t num_slots, uint32_t num_cols, uint32_t mat_elem_bit_len, cpir_dtc_layout* out);
 /* Granularity of shard boundaries along the filter slots for this layout: lcm(slots_per_chunk, compression_factor).  A multi-GPU
  * partition whose boundaries are multiples of it splits no chunk / super-tile of the device packing, no packed word of the

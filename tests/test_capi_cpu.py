@@ -96,15 +96,13 @@ def test_layout_invariants(native):
         assert (L.num_slots, L.num_cols, L.mat_elem_bit_len, L.compression_factor) == (N, Cc, b, cf)
         assert L.words_per_row == -(-N // cf) <= L.words_per_row_padded < L.words_per_row + 1024
         assert Cc <= L.rows_padded < Cc + 16
-    for b in range(4, 15):  # planar is offered exactly for b >= 9 and is the default there
-        if b >= 9:
-            P = cp.dtc_layout_for(50_000, 10, b)
-            assert (P.packing, P.chunk_words, P.slots_per_chunk) == (2, b * 256, 512)
-            assert cp.dtc_layout_for(50_000, 10, b, packing=2).total_words == P.total_words
-        else:
-            assert cp.dtc_layout_for(50_000, 10, b).packing != 2
-            with pytest.raises(cp.ChalametPIRError):
-                cp.dtc_layout_for(50_000, 10, b, packing=2)
+    for b in range(4, 15):  # planar is offered, and the default, for every bit length: b bits per field for b >= 9, a byte below
+        P = cp.dtc_layout_for(50_000, 10, b)
+        assert (P.packing, P.chunk_words, P.slots_per_chunk) == (2, max(b, 8) * 256, 512)
+        assert cp.dtc_layout_for(50_000, 10, b, packing=2).total_words == P.total_words
+    for b in (0, 3, 15):
+        with pytest.raises(cp.ChalametPIRError):
+            cp.dtc_layout_for(50_000, 10, b, packing=2)
     cp.tuning_set("layout.planar", 0)
     for b in range(4, 15):  # without planar: dense64 is offered exactly for b in {7, 9, 11, 12}
         L = cp.dtc_layout_for(50_000, 10, b)

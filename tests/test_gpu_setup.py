@@ -74,7 +74,7 @@ def check_planar_image(words, L, D, b):
     """decode the planar device image (layout documented at cpir_dtc_layout in include/chalamet_hip.h) with numpy, independently of
     the library's own export kernel: every (slot, column) incl. padding, and the per-column field sums behind the tiles"""
     N, C = D.shape
-    hb = b - 8
+    hb = max(b - 8, 0)  # b <= 8: the byte alone
     ks_total = -(-N // 512)
     tile_bytes = (8 + hb) * 1024
     assert (L.chunk_words, L.slots_per_chunk, L.words_per_row_padded) == (tile_bytes // 4, 512, ks_total * (8 + hb) * 16)
