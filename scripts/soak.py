@@ -90,5 +90,28 @@ while time.time() < t_end:
             print("MISMATCH host", i, seed)
             sys.exit(1)
         checks += 1
+    # 20 concurrent callers on the ONE handle, pageable and page-locked buffers mixed, three calls each: every arena of the coalescing
+    # front end fills up (spread admission, full arenas, lone stragglers at the end)
+    pins = [cp.PinnedArray(N) for _ in range(4)]
+    for j, pa in enumerate(pins):
+        pa.array[:] = hq[j]
+    bad = []
+
+    def hammer(t):
+        for rep in range(3):
+            i = (t + rep) % k
+            buf = pins[i].array if (i < 4 and t % 2 == 0) else hq[i]
+            if not np.array_equal(srv.respond_array(buf), want[i]):
+                bad.append((t, rep, i))
+
+    ts = [threading.Thread(target=hammer, args=(t,)) for t in range(20)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for pa in pins:
+        pa.close()
+    if bad:
+        print("MISMATCH concurrent", bad[:5], seed)
+        sys.exit(1)
+    checks += 60
     rounds += 1
 print(f"soak ok: {rounds} rounds, {checks} responses checked against exact 64-bit sums")
