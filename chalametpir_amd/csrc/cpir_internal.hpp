@@ -72,7 +72,7 @@ const char* respond_kernel_name(const cpir_dtc_layout& L);
 constexpr uint32_t CPIR_PLANAR_MAX_QUERIES_PER_PASS = 8;
 int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                           uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, int blocks_per_cu,
-                          bool nontemporal, bool xcd_split, int interleave, uint64_t step_lo = 0, uint64_t step_hi = 0);
+                          bool nontemporal, bool xcd_split, int interleave, bool ks_major, uint64_t step_lo = 0, uint64_t step_hi = 0);
 bool respond_batch_fusion();
 uint64_t respond_multi_pass_limit_bytes();
 

@@ -294,6 +294,7 @@ struct Tuning {
   int interleave_passes = -1;  // order of the passes of one launch: 0 slice order, 1 interleaved, -1 by shard size
   int planar_blocks_per_cu = 0;  // the matrix-core kernel (respond_planar.hip): 0 = by pass order (2 streaming, 3 sharing)
   int multi_pass_limit_mb = 2560;  // unfused batches: databases above this size get one launch per query
+  int ks_major = 1;                // the matrix-core kernel walks its units step-major where it can (respond_planar.hip)
 };
 Tuning g_tuning;
 std::mutex g_tuning_mu;
@@ -366,6 +367,8 @@ extern "C" int cpir_tuning_set(const char* key, int value) {
   } else if (!strcmp(key, "respond.interleave_passes")) {
     if (value < -1 || value > 1) return CPIR_ERR_INVALID_ARGUMENT;
     g_tuning.interleave_passes = value;
+  } else if (!strcmp(key, "respond.ks_major")) {
+    g_tuning.ks_major = value ? 1 : 0;
   } else if (!strcmp(key, "layout.dense")) {
     set_default_dense(value != 0);
   } else if (!strcmp(key, "layout.planar")) {
@@ -417,7 +420,7 @@ int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout
   }
   if (L.packing == CPIR_PACK_PLANAR)  // the matrix-core path (respond_planar.hip)
     return launch_respond_planar(dev, dtc, L, q, q_len, q_slot_offset, batch, passes, r, stream, t.planar_blocks_per_cu, t.nontemporal != 0,
-                                 t.xcd_split != 0, t.interleave_passes);
+                                 t.xcd_split != 0, t.interleave_passes, t.ks_major != 0);
   if (L.words_per_row_padded / L.chunk_words > 0xffffffffull) return CPIR_ERR_INVALID_ARGUMENT;
   Picked k;
   if (batch == 1) k = pick_kernel<1>(L, t.rows_per_unit, t.nontemporal);

@@ -289,6 +289,200 @@ respond_planar_kernel(const PlanarArgs a) {
   if (i < total) step(b0, b1, 0, true);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same contraction walked STEP-MAJOR: a block owns a contiguous range of (step, tile group) units ordered by step first, so
+//   * the A fragments of a 512-slot step are built ONCE per block and step and serve every tile group of that step (the kernel above
+//     rebuilds them for every unit: at 2^20 keys each word of q is gathered 15 times, with 8 kB values 115 times) -- every word of q is
+//     read by (almost) exactly one block, which is what lets a lone host query be read straight from page-locked HOST memory (zero-copy:
+//     the 83 us upload of a 4.7 MB query disappears behind the 190 us stream instead of preceding it);
+//   * one barrier per STEP instead of one per unit (the waves of a block run free between the steps);
+//   * the responses accumulate in LDS (one u32 per query and padded column) and leave through one pass of u32 atomics per block.
+// Same arithmetic, same packed image, same results bit for bit.  Used for the slice pass order (every pass its own stream from HBM);
+// the interleaved order of the multi-GPU shards stays on the kernel above.
+template <int HB, int NS, bool NT>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NS == 1 ? 3 : 2, NS == 1 ? 3 : 2)))
+respond_planar_ks_kernel(const PlanarArgs a) {
+  constexpr int NL = 8 + HB;     // 16-byte loads per lane and tile step
+  constexpr int ST16 = NL * 64;  // uint4 per super-tile
+  __shared__ uint4 abuf[2][NS][8][64];     // A fragments of a step: [parity][row set][k-block][lane]
+  extern __shared__ uint32_t racc[];       // [query of the pass][padded column]: this block's part of the responses
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const uint32_t cl = lane & 15;
+  const uint32_t grp = lane >> 4;
+  const uint32_t cpad = a.col_tiles * 16;
+
+  const uint32_t nx = a.nx;
+  const uint32_t xcd = blockIdx.x % nx;
+  const uint32_t j = blockIdx.x / nx;
+  const uint32_t nb = gridDim.x / nx;  // host guarantees gridDim.x % nx == 0
+  const uint32_t ks_len = a.ks_hi - a.ks_lo;
+  const uint32_t kb0 = a.ks_lo + (uint32_t)(((uint64_t)ks_len * xcd) / nx);
+  const uint32_t ke0 = a.ks_lo + (uint32_t)(((uint64_t)ks_len * (xcd + 1)) / nx);
+  const uint32_t span = ke0 - kb0;
+  const uint32_t TG = a.tile_groups;
+  const uint64_t units = (uint64_t)TG * span;
+  const uint64_t sb = units * j / nb, se = units * (j + 1) / nb;  // unit u = (step kb0 + u / TG, tile group u % TG)
+  if (span == 0 || sb == se) return;  // block-uniform: an idle block takes part in nothing
+
+  const uint32_t nq = a.q_per_pass;
+  bool arow[NS];
+  uint32_t qi[NS];
+#pragma unroll
+  for (int s = 0; s < NS; s++) {
+    arow[s] = 4 * s + (cl >> 2) < nq;
+    qi[s] = arow[s] ? 4 * s + (cl >> 2) : 0;
+  }
+  const uint32_t limb = cl & 3;
+  const uint32_t sel01 = limb | ((4 + limb) << 8);
+  const uint4* const tiles = reinterpret_cast<const uint4*>(a.dtc);
+
+  auto guarded_step = [&](uint32_t ks_) {
+    const uint64_t slot0 = (uint64_t)ks_ * CPIR_PLANAR_SLOTS_PER_TILE;
+    return a.q_scalar || slot0 + CPIR_PLANAR_SLOTS_PER_TILE > a.num_slots || a.q_slot_offset + slot0 + CPIR_PLANAR_SLOTS_PER_TILE > a.q_len;
+  };
+  auto a_issue = [&](uint4(&raw)[NS][2][4], uint32_t ks_, uint32_t pass_) {
+    const uint64_t base = (uint64_t)ks_ * CPIR_PLANAR_SLOTS_PER_TILE + (2 * wave) * 64 + grp * 16;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+      const uint32_t* qrow = a.q + ((uint64_t)pass_ * nq + qi[s]) * a.q_len + a.q_slot_offset;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const uint4* src = reinterpret_cast<const uint4*>(qrow + base + h * 64);
+#pragma unroll
+        for (int d = 0; d < 4; d++) raw[s][h][d] = src[d];
+      }
+    }
+  };
+  auto a_finish = [&](const uint4(&raw)[NS][2][4], int par) {
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        uint32_t o[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+          const uint4& t = raw[s][h][d];
+          const uint32_t v = gather_limb(t.x, t.y, t.z, t.w, sel01) ^ 0x80808080u;
+          o[d] = arow[s] ? v : 0u;
+        }
+        abuf[par][s][2 * wave + h][lane] = make_uint4(o[0], o[1], o[2], o[3]);
+      }
+  };
+  auto a_guarded = [&](uint32_t ks_, uint32_t pass_, int par) {
+    const uint64_t slot0 = (uint64_t)ks_ * CPIR_PLANAR_SLOTS_PER_TILE;
+    for (int s = 0; s < NS; s++) {
+      const uint32_t* qrow = a.q + ((uint64_t)pass_ * nq + qi[s]) * a.q_len + a.q_slot_offset;
+      for (int h = 0; h < 2; h++) {
+        const int kb = 2 * wave + h;
+        const uint64_t base = slot0 + kb * 64 + grp * 16;
+        uint32_t o[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+          uint32_t w[4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const uint64_t n = base + d * 4 + e;
+            const bool ok = n < a.num_slots && a.q_slot_offset + n < a.q_len;
+            w[e] = ok ? (qrow[n] ^ 0x80808080u) : 0u;
+          }
+          o[d] = arow[s] ? gather_limb(w[0], w[1], w[2], w[3], sel01) : 0u;
+        }
+        abuf[par][s][kb][lane] = make_uint4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  };
+  auto load_tile = [&](uint4(&dst)[NL], uint32_t tg_, uint32_t ks_) {
+    const uint32_t T = tg_ * kM + wave;
+    const uint4* p = tiles + (T < a.col_tiles ? ((uint64_t)T * a.ks_total + ks_) * ST16 : 0) + lane;
+#pragma unroll
+    for (int i = 0; i < NL; i++) dst[i] = load16<NT>(p + i * 64);
+  };
+
+  const uint32_t ks_first = kb0 + (uint32_t)(sb / TG), tg_first = (uint32_t)(sb % TG);
+  const uint32_t ks_last = kb0 + (uint32_t)((se - 1) / TG);  // last step this block touches
+
+  for (uint32_t pass = 0; pass < a.passes; pass++) {
+    for (uint32_t i = threadIdx.x; i < nq * cpad; i += kThreads) racc[i] = 0;
+    // prologue of the pass: A fragments of the first step, the first tile
+    uint4 b0[NL], b1[NL];
+    load_tile(b0, tg_first, ks_first);
+    a_guarded(ks_first, pass, 0);
+    __syncthreads();
+
+    uint32_t tg = tg_first, ks = ks_first;
+    int par = 0;
+    bool first_of_step = true;  // the first unit this block processes of the current step: builds the NEXT step's A fragments
+    auto unit = [&](uint4(&cur)[NL], uint4(&nxt)[NL], bool last) {
+      uint32_t tg_n = tg + 1, ks_n = ks;
+      if (tg_n == TG) tg_n = 0, ks_n = ks + 1;
+      uint4 raw[NS][2][4];
+      const bool build = first_of_step && ks < ks_last;  // block-uniform
+      const bool g_n = build && guarded_step(ks + 1);
+      if (build && !g_n) a_issue(raw, ks + 1, pass);
+      if (!last) load_tile(nxt, tg_n, ks_n);
+      v4i acc_lo[NS], acc_hi[NS];
+#pragma unroll
+      for (int s = 0; s < NS; s++) acc_lo[s] = v4i{0, 0, 0, 0}, acc_hi[s] = v4i{0, 0, 0, 0};
+      const uint32_t T = tg * kM + wave;
+      if (T < a.col_tiles) {
+#pragma unroll
+        for (int kb = 0; kb < 8; kb++) {
+          v4i hb;
+#pragma unroll
+          for (int d = 0; d < 4; d++) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int p = 0; p < HB; p++) x += ((comp(cur[8 + p], kb >> 1) >> (4 * (kb & 1) + d)) & 0x01010101u) << p;
+            hb[d] = (int)x;
+          }
+#pragma unroll
+          for (int s = 0; s < NS; s++) {
+            const uint4 au = abuf[par][s][kb][lane];
+            const v4i af = as_v4i(au);
+            acc_lo[s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, as_v4i(cur[kb]), acc_lo[s], 0, 0, 0);
+            if constexpr (HB > 0) acc_hi[s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, hb, acc_hi[s], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+          uint32_t v = 0;
+#pragma unroll
+          for (int i = 0; i < 4; i++) v += ((uint32_t)acc_lo[s][i] + ((uint32_t)acc_hi[s][i] << 8)) << (8 * i);
+          const uint32_t query = 4 * s + grp;
+          if (query < nq) atomicAdd(&racc[query * cpad + T * 16 + cl], v);  // LDS; this wave owns tile T of every step
+        }
+      }
+      if (build) {
+        if (!g_n) a_finish(raw, par ^ 1);
+        else a_guarded(ks + 1, pass, par ^ 1);
+      }
+      first_of_step = false;
+      if (ks_n != ks) {
+        __syncthreads();  // everybody is done with this step's fragments; the next step's are complete
+        par ^= 1;
+        first_of_step = true;
+      }
+      tg = tg_n, ks = ks_n;
+    };
+    uint64_t i = sb;
+    for (; i + 2 <= se; i += 2) {
+      unit(b0, b1, false);
+      unit(b1, b0, i + 2 == se);
+    }
+    if (i < se) unit(b0, b1, true);
+
+    // ---- this block's part of the pass's responses ----
+    __syncthreads();
+    for (uint32_t i2 = threadIdx.x; i2 < nq * cpad; i2 += kThreads) {
+      const uint32_t query = i2 / cpad, col = i2 % cpad, v = racc[i2];
+      if (col < a.num_cols && v) atomicAdd(a.r + ((uint64_t)pass * nq + query) * a.num_cols + col, v);
+    }
+    __syncthreads();
+  }
+}
+
 // r[q][c] += 128 * sum_n (q[n] - 0x80808080) over this block's slice of the valid slots, and (slice 0 only) += 0x80808080 * colsum[c]:
 // the two correction terms of the signed-byte split (top of the file).  r was zeroed on the stream before; all updates are u32
 // atomic adds, so their order against the main kernel's does not matter.
@@ -337,11 +531,27 @@ KernelFn pick_hb(uint32_t hb, bool nt) {
 
 KernelFn pick(uint32_t hb, uint32_t batch, bool nt) { return batch <= 4 ? pick_hb<1>(hb, nt) : pick_hb<2>(hb, nt); }
 
+template <int NS>
+KernelFn pick_ks_hb(uint32_t hb, bool nt) {
+  switch (hb) {
+    case 0: return nt ? respond_planar_ks_kernel<0, NS, true> : respond_planar_ks_kernel<0, NS, false>;
+    case 1: return nt ? respond_planar_ks_kernel<1, NS, true> : respond_planar_ks_kernel<1, NS, false>;
+    case 2: return nt ? respond_planar_ks_kernel<2, NS, true> : respond_planar_ks_kernel<2, NS, false>;
+    case 3: return nt ? respond_planar_ks_kernel<3, NS, true> : respond_planar_ks_kernel<3, NS, false>;
+    case 4: return nt ? respond_planar_ks_kernel<4, NS, true> : respond_planar_ks_kernel<4, NS, false>;
+    case 5: return nt ? respond_planar_ks_kernel<5, NS, true> : respond_planar_ks_kernel<5, NS, false>;
+    case 6: return nt ? respond_planar_ks_kernel<6, NS, true> : respond_planar_ks_kernel<6, NS, false>;
+    default: return nullptr;
+  }
+}
+
+KernelFn pick_ks(uint32_t hb, uint32_t batch, bool nt) { return batch <= 4 ? pick_ks_hb<1>(hb, nt) : pick_ks_hb<2>(hb, nt); }
+
 }  // namespace
 
 int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                           uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, int blocks_per_cu,
-                          bool nontemporal, bool xcd_split, int interleave, uint64_t step_lo, uint64_t step_hi) {
+                          bool nontemporal, bool xcd_split, int interleave, bool ks_major, uint64_t step_lo, uint64_t step_hi) {
   // shape invariants the kernel relies on (layout already checked by the caller)
   if (L.packing != CPIR_PACK_PLANAR || batch == 0 || batch > CPIR_PLANAR_MAX_QUERIES_PER_PASS || passes == 0) return CPIR_ERR_INVALID_ARGUMENT;
   const uint32_t hb = planar_hi_planes(L.mat_elem_bit_len);
@@ -403,7 +613,11 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
   split = split < 4 ? 4 : (split > 256 ? 256 : split);
   hipLaunchKernelGGL(planar_init_kernel, dim3(nq * split), dim3(kThreads), 0, stream, q, q_len, q_slot_offset, L.num_slots, colsum,
                      L.num_cols, r, split, range_lo, range_hi);
-  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(kThreads), 0, stream, a);
+  // the step-major kernel where it applies: slice order (every pass its own stream), LDS room for the pass's responses
+  const size_t racc_bytes = (size_t)batch * a.col_tiles * 16 * sizeof(uint32_t);
+  KernelFn fn_ks = (ks_major && !inter && racc_bytes <= (48u << 10)) ? pick_ks(hb, batch, nt) : nullptr;
+  if (fn_ks) hipLaunchKernelGGL(fn_ks, dim3((unsigned)grid), dim3(kThreads), racc_bytes, stream, a);
+  else hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(kThreads), 0, stream, a);
   CPIR_HIP_TRY(hipGetLastError());
   return CPIR_OK;
 }
