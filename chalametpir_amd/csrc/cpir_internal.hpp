@@ -67,12 +67,20 @@ uint64_t respond_scratch_words(const cpir_dtc_layout& L, uint32_t batch);
 // stream of that pass: q holds passes*batch queries of q_len entries, r passes*batch responses of num_cols entries.
 int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                    uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, uint32_t* scratch, hipStream_t stream);
+// one query whose words are read exactly once (q may therefore live in page-locked host memory: device-visible pointer), r already zero;
+// planar packing only, CPIR_ERR_INVALID_ARGUMENT where the step-major kernel does not apply
+int launch_respond_read_once(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
+                             uint64_t q_slot_offset, uint32_t* r_prezeroed, hipStream_t stream);
 const char* respond_kernel_name(const cpir_dtc_layout& L);
 // respond_planar.hip (CPIR_PACK_PLANAR: the MFMA path); same contract as launch_respond, batch up to CPIR_PLANAR_MAX_QUERIES_PER_PASS
 constexpr uint32_t CPIR_PLANAR_MAX_QUERIES_PER_PASS = 8;
 int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                           uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, int blocks_per_cu,
-                          bool nontemporal, bool xcd_split, int interleave, bool ks_major, uint64_t step_lo = 0, uint64_t step_hi = 0);
+                          bool nontemporal, bool xcd_split, int interleave, int ks_mode, bool r_prezeroed = false, uint64_t step_lo = 0,
+                          uint64_t step_hi = 0);
+// ks_mode: 0 = the tile-major kernel only; 1 = the step-major kernel for fused batches (2+ queries per pass), where building the A
+// fragments once per step pays (26 against 30 us per query at 8 per pass); 2 = the step-major kernel or fail: the caller needs every
+// query word read exactly once (a query read in place from page-locked host memory).  r_prezeroed: the caller has zeroed r already.
 bool respond_batch_fusion();
 uint64_t respond_multi_pass_limit_bytes();
 

@@ -294,7 +294,7 @@ struct Tuning {
   int interleave_passes = -1;  // order of the passes of one launch: 0 slice order, 1 interleaved, -1 by shard size
   int planar_blocks_per_cu = 0;  // the matrix-core kernel (respond_planar.hip): 0 = by pass order (2 streaming, 3 sharing)
   int multi_pass_limit_mb = 2560;  // unfused batches: databases above this size get one launch per query
-  int ks_major = 1;                // the matrix-core kernel walks its units step-major where it can (respond_planar.hip)
+  int ks_major = 1;                // the step-major matrix-core kernel: 0 never, 1 for fused batches, 2 wherever it applies
 };
 Tuning g_tuning;
 std::mutex g_tuning_mu;
@@ -368,7 +368,8 @@ extern "C" int cpir_tuning_set(const char* key, int value) {
     if (value < -1 || value > 1) return CPIR_ERR_INVALID_ARGUMENT;
     g_tuning.interleave_passes = value;
   } else if (!strcmp(key, "respond.ks_major")) {
-    g_tuning.ks_major = value ? 1 : 0;
+    if (value < 0 || value > 2) return CPIR_ERR_INVALID_ARGUMENT;
+    g_tuning.ks_major = value;
   } else if (!strcmp(key, "layout.dense")) {
     set_default_dense(value != 0);
   } else if (!strcmp(key, "layout.planar")) {
@@ -405,6 +406,21 @@ const char* respond_kernel_name(const cpir_dtc_layout& L) {
   return L.packing == CPIR_PACK_PLANAR ? "respond_planar_kernel" : "respond_kernel";
 }
 
+int launch_respond_read_once(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
+                             uint64_t q_slot_offset, uint32_t* r_prezeroed, hipStream_t stream) {
+  if (!dtc || !q || !r_prezeroed || L.packing != CPIR_PACK_PLANAR) return CPIR_ERR_INVALID_ARGUMENT;
+  CPIR_TRY(check_layout(L));
+  if (q_slot_offset + L.num_slots > q_len) return CPIR_ERR_SHARD_RANGE;
+  if (reinterpret_cast<uintptr_t>(dtc) % 16 != 0) return CPIR_ERR_INVALID_ARGUMENT;
+  Tuning t;
+  {
+    std::lock_guard<std::mutex> lk(g_tuning_mu);
+    t = g_tuning;
+  }
+  return launch_respond_planar(dev, dtc, L, q, q_len, q_slot_offset, 1, 1, r_prezeroed, stream, t.planar_blocks_per_cu, t.nontemporal != 0,
+                               t.xcd_split != 0, 0, 2, true);
+}
+
 int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                    uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, uint32_t* /*scratch*/, hipStream_t stream) {
   if (!dtc || !q || !r || batch == 0 || passes == 0) return CPIR_ERR_INVALID_ARGUMENT;
@@ -420,7 +436,7 @@ int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout
   }
   if (L.packing == CPIR_PACK_PLANAR)  // the matrix-core path (respond_planar.hip)
     return launch_respond_planar(dev, dtc, L, q, q_len, q_slot_offset, batch, passes, r, stream, t.planar_blocks_per_cu, t.nontemporal != 0,
-                                 t.xcd_split != 0, t.interleave_passes, t.ks_major != 0);
+                                 t.xcd_split != 0, t.interleave_passes, t.ks_major);
   if (L.words_per_row_padded / L.chunk_words > 0xffffffffull) return CPIR_ERR_INVALID_ARGUMENT;
   Picked k;
   if (batch == 1) k = pick_kernel<1>(L, t.rows_per_unit, t.nontemporal);

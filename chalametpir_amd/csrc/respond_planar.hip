@@ -56,6 +56,7 @@ struct PlanarArgs {
   uint32_t passes;         // independent passes over the database in this launch
   uint32_t q_scalar;       // q not 16-byte loadable -> guarded scalar loads everywhere
   uint32_t interleave;     // order of the passes of one launch (see the kernel)
+  const uint32_t* colsum;  // step-major kernel: per-column field sums behind the tiles (NULL: this launch does not cover step 0)
 };
 
 template <bool NT>
@@ -296,7 +297,11 @@ respond_planar_kernel(const PlanarArgs a) {
 //     read by (almost) exactly one block, which is what lets a lone host query be read straight from page-locked HOST memory (zero-copy:
 //     the 83 us upload of a 4.7 MB query disappears behind the 190 us stream instead of preceding it);
 //   * one barrier per STEP instead of one per unit (the waves of a block run free between the steps);
-//   * the responses accumulate in LDS (one u32 per query and padded column) and leave through one pass of u32 atomics per block.
+//   * the responses accumulate in LDS (one u32 per query and padded column) and leave through one pass of u32 atomics per block;
+//   * the two correction terms of the signed-byte split are added here, not by planar_init_kernel (which would read q a second time):
+//     while a wave gathers its share of a step's query words it also sums them, and every (step, tile group) unit adds
+//     128 * (sum of the step's valid query words) - 0x40404000 * (valid slots of the step) to each of its 64 columns -- every unit
+//     is visited exactly once, so every column receives the whole per-query term; the units of step 0 add 0x80808080 * colsum[column].
 // Same arithmetic, same packed image, same results bit for bit.  Used for the slice pass order (every pass its own stream from HBM);
 // the interleaved order of the multi-GPU shards stays on the kernel above.
 template <int HB, int NS, bool NT>
@@ -305,6 +310,7 @@ respond_planar_ks_kernel(const PlanarArgs a) {
   constexpr int NL = 8 + HB;     // 16-byte loads per lane and tile step
   constexpr int ST16 = NL * 64;  // uint4 per super-tile
   __shared__ uint4 abuf[2][NS][8][64];     // A fragments of a step: [parity][row set][k-block][lane]
+  __shared__ uint32_t ksum[2][kThreads / 64][4 * NS];  // per step parity, wave and query: the sum of the query words that wave gathered
   extern __shared__ uint32_t racc[];       // [query of the pass][padded column]: this block's part of the responses
 
   const int lane = threadIdx.x & 63;
@@ -355,24 +361,42 @@ respond_planar_ks_kernel(const PlanarArgs a) {
       }
     }
   };
-  auto a_finish = [&](const uint4(&raw)[NS][2][4], int par) {
+  // this wave's sum of the query words of a step, per query: the four lanes that share a query word (one per byte limb) count it once
+  // (limb 0), the four 16-slot groups are added up with two shuffles, lane (group 0, limb 0) of every query writes
+  auto store_ksum = [&](const uint32_t(&part)[NS], int par) {
 #pragma unroll
-    for (int s = 0; s < NS; s++)
+    for (int s = 0; s < NS; s++) {
+      uint32_t v = part[s];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (grp == 0 && limb == 0) ksum[par][wave][4 * s + (cl >> 2)] = arow[s] ? v : 0u;
+    }
+  };
+  auto a_finish = [&](const uint4(&raw)[NS][2][4], int par) {
+    uint32_t part[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+      part[s] = 0;
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         uint32_t o[4];
 #pragma unroll
         for (int d = 0; d < 4; d++) {
           const uint4& t = raw[s][h][d];
+          part[s] += (t.x + t.y) + (t.z + t.w);
           const uint32_t v = gather_limb(t.x, t.y, t.z, t.w, sel01) ^ 0x80808080u;
           o[d] = arow[s] ? v : 0u;
         }
         abuf[par][s][2 * wave + h][lane] = make_uint4(o[0], o[1], o[2], o[3]);
       }
+    }
+    store_ksum(part, par);
   };
   auto a_guarded = [&](uint32_t ks_, uint32_t pass_, int par) {
     const uint64_t slot0 = (uint64_t)ks_ * CPIR_PLANAR_SLOTS_PER_TILE;
+    uint32_t part[NS];
     for (int s = 0; s < NS; s++) {
+      part[s] = 0;
       const uint32_t* qrow = a.q + ((uint64_t)pass_ * nq + qi[s]) * a.q_len + a.q_slot_offset;
       for (int h = 0; h < 2; h++) {
         const int kb = 2 * wave + h;
@@ -385,19 +409,31 @@ respond_planar_ks_kernel(const PlanarArgs a) {
           for (int e = 0; e < 4; e++) {
             const uint64_t n = base + d * 4 + e;
             const bool ok = n < a.num_slots && a.q_slot_offset + n < a.q_len;
-            w[e] = ok ? (qrow[n] ^ 0x80808080u) : 0u;
+            const uint32_t x = ok ? qrow[n] : 0u;
+            part[s] += x;
+            w[e] = ok ? (x ^ 0x80808080u) : 0u;
           }
           o[d] = arow[s] ? gather_limb(w[0], w[1], w[2], w[3], sel01) : 0u;
         }
         abuf[par][s][kb][lane] = make_uint4(o[0], o[1], o[2], o[3]);
       }
     }
+    store_ksum(part, par);
   };
   auto load_tile = [&](uint4(&dst)[NL], uint32_t tg_, uint32_t ks_) {
     const uint32_t T = tg_ * kM + wave;
     const uint4* p = tiles + (T < a.col_tiles ? ((uint64_t)T * a.ks_total + ks_) * ST16 : 0) + lane;
 #pragma unroll
     for (int i = 0; i < NL; i++) dst[i] = load16<NT>(p + i * 64);
+  };
+  // valid slots of a step: inside the shard and inside the query
+  const uint64_t room = a.q_len > a.q_slot_offset ? a.q_len - a.q_slot_offset : 0;
+  const uint64_t nvalid_total = a.num_slots < room ? a.num_slots : room;
+  auto valid_slots = [&](uint32_t ks_) -> uint32_t {
+    const uint64_t lo = (uint64_t)ks_ * CPIR_PLANAR_SLOTS_PER_TILE;
+    if (lo >= nvalid_total) return 0u;
+    const uint64_t left = nvalid_total - lo;
+    return left < CPIR_PLANAR_SLOTS_PER_TILE ? (uint32_t)left : CPIR_PLANAR_SLOTS_PER_TILE;
   };
 
   const uint32_t ks_first = kb0 + (uint32_t)(sb / TG), tg_first = (uint32_t)(sb % TG);
@@ -445,13 +481,19 @@ respond_planar_ks_kernel(const PlanarArgs a) {
             if constexpr (HB > 0) acc_hi[s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, hb, acc_hi[s], 0, 0, 0);
           }
         }
+        const uint32_t nv = valid_slots(ks);
+        const uint32_t col_term = (ks == 0 && a.colsum) ? 0x80808080u * a.colsum[T * 16 + cl] : 0u;
 #pragma unroll
         for (int s = 0; s < NS; s++) {
           uint32_t v = 0;
 #pragma unroll
           for (int i = 0; i < 4; i++) v += ((uint32_t)acc_lo[s][i] + ((uint32_t)acc_hi[s][i] << 8)) << (8 * i);
           const uint32_t query = 4 * s + grp;
-          if (query < nq) atomicAdd(&racc[query * cpad + T * 16 + cl], v);  // LDS; this wave owns tile T of every step
+          if (query < nq) {
+            const uint32_t qsum = (ksum[par][0][query] + ksum[par][1][query]) + (ksum[par][2][query] + ksum[par][3][query]);
+            v += 128u * qsum - 0x40404000u * nv + col_term;  // 128 * 0x80808080 = 0x40404000 mod 2^32
+            atomicAdd(&racc[query * cpad + T * 16 + cl], v);  // LDS; this wave owns tile T of every step
+          }
         }
       }
       if (build) {
@@ -551,7 +593,7 @@ KernelFn pick_ks(uint32_t hb, uint32_t batch, bool nt) { return batch <= 4 ? pic
 
 int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                           uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, int blocks_per_cu,
-                          bool nontemporal, bool xcd_split, int interleave, bool ks_major, uint64_t step_lo, uint64_t step_hi) {
+                          bool nontemporal, bool xcd_split, int interleave, int ks_mode, bool r_prezeroed, uint64_t step_lo, uint64_t step_hi) {
   // shape invariants the kernel relies on (layout already checked by the caller)
   if (L.packing != CPIR_PACK_PLANAR || batch == 0 || batch > CPIR_PLANAR_MAX_QUERIES_PER_PASS || passes == 0) return CPIR_ERR_INVALID_ARGUMENT;
   const uint32_t hb = planar_hi_planes(L.mat_elem_bit_len);
@@ -604,8 +646,21 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
 
   const uint32_t nq = batch * passes;
   const bool first = (step_lo == 0);
-  if (first) CPIR_HIP_TRY(hipMemsetAsync(r, 0, (size_t)nq * L.num_cols * sizeof(uint32_t), stream));
   const uint32_t* colsum = first ? dtc + (uint64_t)L.rows_padded * L.words_per_row_padded : nullptr;
+  // the step-major kernel where it applies: slice order (every pass its own stream), LDS room for the pass's responses.  It adds the
+  // correction terms itself (and reads every query word once), so no init kernel in front of it.
+  const size_t racc_bytes = (size_t)batch * a.col_tiles * 16 * sizeof(uint32_t);
+  const bool want_ks = ks_mode == 2 || (ks_mode == 1 && batch >= 2);
+  KernelFn fn_ks = (want_ks && !inter && racc_bytes <= (48u << 10)) ? pick_ks(hb, batch, nt) : nullptr;
+  if (ks_mode == 2 && !fn_ks) return CPIR_ERR_INVALID_ARGUMENT;  // the caller relies on q being read once
+  if (first && !r_prezeroed) CPIR_HIP_TRY(hipMemsetAsync(r, 0, (size_t)nq * L.num_cols * sizeof(uint32_t), stream));
+  if (fn_ks) {
+    a.colsum = colsum;
+    hipLaunchKernelGGL(fn_ks, dim3((unsigned)grid), dim3(kThreads), racc_bytes, stream, a);
+    CPIR_HIP_TRY(hipGetLastError());
+    return CPIR_OK;
+  }
+  a.colsum = nullptr;
   const uint64_t range_lo = step_lo * CPIR_PLANAR_SLOTS_PER_TILE, range_hi = step_hi * CPIR_PLANAR_SLOTS_PER_TILE;
   // slices of the query per init block: at most 16 Ki slots each (a lone query must not leave a handful of blocks reading hundreds of
   // KB each in front of the main kernel: 12.6 us with 64 Ki-slot slices at 2^20 keys)
@@ -613,11 +668,7 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
   split = split < 4 ? 4 : (split > 256 ? 256 : split);
   hipLaunchKernelGGL(planar_init_kernel, dim3(nq * split), dim3(kThreads), 0, stream, q, q_len, q_slot_offset, L.num_slots, colsum,
                      L.num_cols, r, split, range_lo, range_hi);
-  // the step-major kernel where it applies: slice order (every pass its own stream), LDS room for the pass's responses
-  const size_t racc_bytes = (size_t)batch * a.col_tiles * 16 * sizeof(uint32_t);
-  KernelFn fn_ks = (ks_major && !inter && racc_bytes <= (48u << 10)) ? pick_ks(hb, batch, nt) : nullptr;
-  if (fn_ks) hipLaunchKernelGGL(fn_ks, dim3((unsigned)grid), dim3(kThreads), racc_bytes, stream, a);
-  else hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(kThreads), 0, stream, a);
+  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(kThreads), 0, stream, a);
   CPIR_HIP_TRY(hipGetLastError());
   return CPIR_OK;
 }

@@ -255,6 +255,33 @@ def test_batches_equal_single_responds(cfg, device):
         cp.tuning_set("respond.batch_fusion", 1)
 
 
+def test_step_major_kernel_everywhere_equals_the_default(cfg, device):
+    """respond.ks_major=2: the step-major kernel (correction terms folded in, every query word read once) answers the single queries
+    too; 0: the tile-major kernel answers everything.  Same responses as the default split between the two."""
+    import torch
+
+    import chalametpir_amd as cp
+
+    f = cfg
+    batch = 5
+    Q = torch.empty((batch, f.N), dtype=torch.int32, device="cuda")
+    for i in range(batch):
+        device.synth_fill(Q, f.N, 0x7100 + i, offset_words=i * f.N, stream=f.stream)
+    want = np.stack([respond(f, f.srv, Q[i]) for i in range(batch)])
+    assert np.array_equal(want[1], exact_sums(f, Q[1]))
+    try:
+        for mode in (2, 0):
+            cp.tuning_set("respond.ks_major", mode)
+            got = np.stack([respond(f, f.srv, Q[i]) for i in range(batch)])
+            assert np.array_equal(got, want), mode
+            R = torch.full((batch, f.C), -1, dtype=torch.int32, device="cuda")
+            f.srv.respond_batch_device(Q, batch, R, stream=f.stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(R.cpu().numpy().view(np.uint32), want), mode
+    finally:
+        cp.tuning_set("respond.ks_major", 1)
+
+
 def test_hint_matmul_at_this_shape(cfg, device):
     """impl Mul for &Matrix (matrix.rs:1040-1059) == gpu_utils::mat_x_mat (gpu_utils.rs:156-220) at the config's shape: hint = A * D with
     a synthetic A (the XOF expansion of the real A is a host phase, covered at configs[1] in test_gpu_fullsize.py).  Checked two ways:

@@ -269,36 +269,42 @@ def test_unaligned_queries_odd_shard_offsets_and_every_batch_size(orc, device):
         nq = 17
         Q = np.stack([random_query(rng, N) for _ in range(nq)])
         want = np.stack([orc.row_vector_x_compressed_transposed_matrix(Q[i], dtc, N, b)[0] for i in range(nq)])
-        # one query, buffer shifted by one element: 4-byte but not 16-byte aligned
-        buf = torch.zeros(N + 8, dtype=torch.int32, device="cuda")
-        for shift in (1, 2, 3):
-            buf[shift:shift + N] = torch.from_numpy(Q[0].view(np.int32)).cuda()
-            r = torch.full((C,), -1, dtype=torch.int32, device="cuda")
-            srv.respond_device(buf[shift:shift + N], r, stream=stream)
-            torch.cuda.synchronize()
-            assert np.array_equal(r.cpu().numpy().view(np.uint32), want[0]), (b, shift)
-        # every batch size; rows of Q_dev are N apart and N % 4 != 0, so all but the first are unaligned
         Q_dev = torch.from_numpy(Q.view(np.int32)).cuda()
-        try:
-            for fusion in (1, 0):
-                cp.tuning_set("respond.batch_fusion", fusion)
-                for k in range(1, nq + 1):
-                    R = torch.full((k, C), -1, dtype=torch.int32, device="cuda")
-                    srv.respond_batch_device(Q_dev, k, R, stream=stream)
-                    torch.cuda.synchronize()
-                    assert np.array_equal(R.cpu().numpy().view(np.uint32), want[:k]), (b, fusion, k)
-        finally:
-            cp.tuning_set("respond.batch_fusion", 1)
-        # a shard that starts at an odd slot and ends in the middle of a packing unit
         lo, hi = 1027, N - 5
         D_dev = torch.from_numpy(np.ascontiguousarray(D[lo:hi]).view(np.int32)).cuda()
         shard = cp.Server.from_device_matrix(D_dev, hi - lo, C, b, device=device, slot_offset=lo, total_slots=N)
-        part = torch.empty(C, dtype=torch.int32, device="cuda")
-        shard.respond_device(Q_dev[0], part, stream=stream)
-        torch.cuda.synchronize()
         dtc_shard = orc.row_wise_compress(orc.transpose(D[lo:hi]), b)
         want_part = orc.row_vector_x_compressed_transposed_matrix(Q[0][lo:hi], dtc_shard, hi - lo, b)[0]
-        assert np.array_equal(part.cpu().numpy().view(np.uint32), want_part), b
+        try:
+            # respond.ks_major: 0 = tile-major kernel + init kernel, 1 = step-major kernel for the fused passes, 2 = step-major kernel
+            # (which adds the correction terms itself) for every pass
+            for ks_major in (1, 2, 0):
+                cp.tuning_set("respond.ks_major", ks_major)
+                # one query, buffer shifted by one element: 4-byte but not 16-byte aligned
+                buf = torch.zeros(N + 8, dtype=torch.int32, device="cuda")
+                for shift in (1, 2, 3):
+                    buf[shift:shift + N] = torch.from_numpy(Q[0].view(np.int32)).cuda()
+                    r = torch.full((C,), -1, dtype=torch.int32, device="cuda")
+                    srv.respond_device(buf[shift:shift + N], r, stream=stream)
+                    torch.cuda.synchronize()
+                    assert np.array_equal(r.cpu().numpy().view(np.uint32), want[0]), (b, ks_major, shift)
+                # every batch size; rows of Q_dev are N apart and N % 4 != 0, so all but the first are unaligned
+                for fusion in (1, 0):
+                    cp.tuning_set("respond.batch_fusion", fusion)
+                    for k in range(1, nq + 1):
+                        R = torch.full((k, C), -1, dtype=torch.int32, device="cuda")
+                        srv.respond_batch_device(Q_dev, k, R, stream=stream)
+                        torch.cuda.synchronize()
+                        assert np.array_equal(R.cpu().numpy().view(np.uint32), want[:k]), (b, ks_major, fusion, k)
+                cp.tuning_set("respond.batch_fusion", 1)
+                # a shard that starts at an odd slot and ends in the middle of a packing unit
+                part = torch.empty(C, dtype=torch.int32, device="cuda")
+                shard.respond_device(Q_dev[0], part, stream=stream)
+                torch.cuda.synchronize()
+                assert np.array_equal(part.cpu().numpy().view(np.uint32), want_part), (b, ks_major)
+        finally:
+            cp.tuning_set("respond.batch_fusion", 1)
+            cp.tuning_set("respond.ks_major", 1)
 
 
 def test_query_in_page_locked_memory_takes_the_direct_upload(orc, device):
