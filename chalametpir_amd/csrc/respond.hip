@@ -418,7 +418,7 @@ int launch_respond_read_once(const Device* dev, const uint32_t* dtc, const cpir_
     t = g_tuning;
   }
   return launch_respond_planar(dev, dtc, L, q, q_len, q_slot_offset, 1, 1, r_prezeroed, stream, t.planar_blocks_per_cu, t.nontemporal != 0,
-                               t.xcd_split != 0, 0, 2, true);
+                               t.xcd_split != 0, 0, 3, true);
 }
 
 int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,

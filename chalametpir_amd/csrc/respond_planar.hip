@@ -650,9 +650,9 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
   // the step-major kernel where it applies: slice order (every pass its own stream), LDS room for the pass's responses.  It adds the
   // correction terms itself (and reads every query word once), so no init kernel in front of it.
   const size_t racc_bytes = (size_t)batch * a.col_tiles * 16 * sizeof(uint32_t);
-  const bool want_ks = ks_mode == 2 || (ks_mode == 1 && batch >= 2);
+  const bool want_ks = ks_mode >= 2 || (ks_mode == 1 && batch >= 2);
   KernelFn fn_ks = (want_ks && !inter && racc_bytes <= (48u << 10)) ? pick_ks(hb, batch, nt) : nullptr;
-  if (ks_mode == 2 && !fn_ks) return CPIR_ERR_INVALID_ARGUMENT;  // the caller relies on q being read once
+  if (ks_mode == 3 && !fn_ks) return CPIR_ERR_INVALID_ARGUMENT;  // the caller relies on q being read once
   if (first && !r_prezeroed) CPIR_HIP_TRY(hipMemsetAsync(r, 0, (size_t)nq * L.num_cols * sizeof(uint32_t), stream));
   if (fn_ks) {
     a.colsum = colsum;
