@@ -36,7 +36,10 @@ void set_last_hip_error(hipError_t e, const char* what, const char* file, int li
 //   * the leader keeps its arena open until the device is free of the previous arena's launch (or the arena is full) and every seat
 //     taken so far is staged, then closes it and enqueues ONE batched respond for those seats on the run stream, behind the seats' upload
 //     events; callers that arrive later open the next arena and upload while this kernel runs;
-//   * a lone caller finds everything idle: upload (in pieces, so the DMA of one piece overlaps the pinned copy of the next), one launch.
+//   * a lone caller finds everything idle and is served without an upload at all: the step-major kernel reads every query word exactly
+//     once, so it reads them IN PLACE over the host link -- from the caller's buffer when that is page-locked, else from the arena's
+//     pinned block, which the caller's thread and the staging helpers fill in two halves, each half's steps launched as soon as it is
+//     in place.  (respond.host_zero_copy=0: upload first, as concurrent callers do.)
 struct RespondArena {
   uint32_t* q_dev = nullptr;     // kSeats x total_slots u32
   uint32_t* r_dev = nullptr;     // kSeats x C u32
@@ -44,6 +47,8 @@ struct RespondArena {
   uint32_t* r_pinned = nullptr;  // kSeats x C u32
   std::vector<hipEvent_t> seat_ev;  // upload of seat i has crossed the link
   hipEvent_t done_ev = nullptr;     // the arena's responses are in r_pinned
+  const uint32_t* q_pinned_dev = nullptr;  // q_pinned as the device addresses it (a lone query is read in place)
+  bool r0_zero = false;                    // seat 0 of r_dev holds zeros (guarded by the arena's own leader: one at a time)
   // guarded by Server::mu
   enum State { FREE, OPEN, LAUNCHED, DONE } state = FREE;
   uint32_t joined = 0;  // seats taken
@@ -70,7 +75,7 @@ struct Server {
   static constexpr uint32_t kSpread = 4;
   // CPIR_RESPOND_TRACE=1: per-phase wall time of the host path, printed when the server is destroyed (diagnosis)
   struct Trace {
-    std::atomic<uint64_t> calls{0}, batches{0}, ns_seat{0}, ns_stage{0}, ns_gate{0}, ns_enqueue{0}, ns_gpu{0}, ns_follow{0}, ns_out{0};
+    std::atomic<uint64_t> calls{0}, solo{0}, ns_solo{0}, batches{0}, ns_seat{0}, ns_stage{0}, ns_gate{0}, ns_enqueue{0}, ns_gpu{0}, ns_follow{0}, ns_out{0};
     std::atomic<uint64_t> batch_hist[9] = {};
   } trace;
   bool trace_on = false;
@@ -298,6 +303,12 @@ static int arena_create(Server* srv, RespondArena& a) {
   if ((e = hipMalloc(&a.q_dev, (qw + rw) * 4)) != hipSuccess) return fail(e, "hipMalloc(respond arena)");
   if ((e = hipHostMalloc(&a.q_pinned, (qw + rw) * 4, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc(respond arena)");
   a.r_dev = a.q_dev + qw, a.r_pinned = a.q_pinned + qw;
+  {
+    void* dp = nullptr;
+    if ((e = hipHostGetDevicePointer(&dp, a.q_pinned, 0)) != hipSuccess) return fail(e, "hipHostGetDevicePointer");
+    a.q_pinned_dev = static_cast<const uint32_t*>(dp);
+  }
+  a.r0_zero = false;
   a.seat_ev.assign(Server::kSeats, nullptr);
   for (hipEvent_t& ev : a.seat_ev)
     if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreateWithFlags");
@@ -340,7 +351,8 @@ static void server_destroy(Server* srv) {
             n, nb, t.ns_seat.load() / n / 1e3, t.ns_stage.load() / n / 1e3, t.ns_out.load() / n / 1e3,
             t.ns_follow.load() / (n - nb > 0 ? n - nb : 1) / 1e3, t.ns_gate.load() / nb / 1e3, t.ns_enqueue.load() / nb / 1e3, t.ns_gpu.load() / nb / 1e3);
     for (int i = 1; i <= 8; i++) fprintf(stderr, " %d:%llu", i, (unsigned long long)t.batch_hist[i].load());
-    fprintf(stderr, "\n");
+    fprintf(stderr, "; served alone (query read in place) %llu, %.1f us each\n", (unsigned long long)t.solo.load(),
+            t.solo.load() ? t.ns_solo.load() / (double)t.solo.load() / 1e3 : 0.0);
   }
   if (!srv->shards.empty()) {
     group_ctx_destroy(srv);
@@ -1466,6 +1478,88 @@ int cpir_server_group_shard(const cpir_server* srv, uint32_t index, int* device_
 // ---------------------------------------------------------------------------------------------------------------
 // server: respond
 // ---------------------------------------------------------------------------------------------------------------
+// A caller that found the server idle (it holds arena `a` alone, closed to others): no upload.  The step-major kernel reads each query
+// word once, so it reads them where they are: in the caller's buffer if that is page-locked and 16-byte aligned, else in the arena's
+// pinned block, filled in two halves by this thread and the staging helpers with each half's steps launched as soon as it is in place
+// (the second half is copied while the kernel works on the first).  The launches add up in r_dev, which is kept zeroed between uses.
+static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32_t* r_out) {
+  const size_t C = srv->layout.num_cols;
+  const size_t q_lo = (size_t)srv->slot_offset, words = (size_t)srv->layout.num_slots;
+  hipStream_t st = srv->run_stream;
+  std::lock_guard<std::mutex> ll(srv->launch_mu);
+  hipError_t e = hipSuccess;
+  int rc = CPIR_OK;
+  if (!a->r0_zero) e = hipMemsetAsync(a->r_dev, 0, C * 4, st);
+  a->r0_zero = false;
+  const uint32_t* in_place = nullptr;
+  if (e == hipSuccess && reinterpret_cast<uintptr_t>(q) % 16 == 0 && host_pointer_is_pinned_cached(q + q_lo, words * 4)) {
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, const_cast<uint32_t*>(q), 0) == hipSuccess) in_place = static_cast<const uint32_t*>(dp);
+    else (void)hipGetLastError();
+  }
+  if (e == hipSuccess && in_place) {
+    rc = launch_respond_read_once(srv->dev, srv->dtc, srv->layout, in_place, srv->total_slots, srv->slot_offset, a->r_dev, st);
+  } else if (e == hipSuccess) {
+    uint32_t* const qp = a->q_pinned;  // seat 0; same offsets as the caller's buffer
+    constexpr size_t kJob = (size_t)1 << 16;  // 256 KiB of u32, a multiple of the kernel's 512-slot step
+    constexpr size_t kMaxJobs = 512;
+    const size_t n_jobs = (words + kJob - 1) / kJob;
+    if (words >= ((size_t)1 << 19) && n_jobs <= kMaxJobs && g_staging.try_acquire()) {
+      std::atomic<int> done[kMaxJobs];
+      for (size_t i = 0; i < n_jobs; i++) {
+        done[i].store(0, std::memory_order_relaxed);
+        const size_t o = q_lo + i * kJob, n = (words - i * kJob < kJob) ? words - i * kJob : kJob;
+        g_staging.submit(StagingHelpers::Job{qp + o, q + o, n * 4, &done[i]});
+      }
+      const size_t j_half = (n_jobs + 1) / 2;
+      size_t next = 0;
+      for (int h = 0; h < 2 && rc == CPIR_OK; h++) {
+        const size_t j_hi = h ? n_jobs : j_half;
+        for (; next < j_hi; next++)
+          while (!done[next].load(std::memory_order_acquire))
+            if (!g_staging.help()) {
+#if defined(__x86_64__)
+              __builtin_ia32_pause();
+#endif
+            }
+        const uint64_t s_lo = h ? j_half * (kJob / CPIR_PLANAR_SLOTS_PER_TILE) : 0;
+        const uint64_t s_hi = h ? (words + CPIR_PLANAR_SLOTS_PER_TILE - 1) / CPIR_PLANAR_SLOTS_PER_TILE : j_half * (kJob / CPIR_PLANAR_SLOTS_PER_TILE);
+        if (s_hi > s_lo)
+          rc = launch_respond_read_once(srv->dev, srv->dtc, srv->layout, a->q_pinned_dev, srv->total_slots, srv->slot_offset, a->r_dev, st,
+                                        s_lo, s_hi);
+      }
+      // every job must have run before the stack array goes away, whatever happened
+      for (; next < n_jobs; next++)
+        while (!done[next].load(std::memory_order_acquire))
+          if (!g_staging.help()) {
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+          }
+      g_staging.release();
+    } else {
+      memcpy(qp + q_lo, q + q_lo, words * 4);
+      rc = launch_respond_read_once(srv->dev, srv->dtc, srv->layout, a->q_pinned_dev, srv->total_slots, srv->slot_offset, a->r_dev, st);
+    }
+  }
+  if (e == hipSuccess && rc == CPIR_OK) e = hipMemcpyAsync(a->r_pinned, a->r_dev, C * 4, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && rc == CPIR_OK) e = hipEventRecord(a->done_ev, st);
+  if (e == hipSuccess && rc == CPIR_OK) {
+    // zeros for the next lone caller, off this one's critical path
+    if (hipMemsetAsync(a->r_dev, 0, C * 4, st) == hipSuccess) a->r0_zero = true;
+    else (void)hipGetLastError();
+    e = wait_for_event(a->done_ev);
+  } else {
+    (void)hipStreamSynchronize(st);  // whatever was enqueued reads the caller's buffer / the pinned block: drain before returning
+  }
+  if (rc == CPIR_OK && e != hipSuccess) {
+    set_last_hip_error(e, "respond (query read in place)", __FILE__, __LINE__);
+    rc = CPIR_ERR_HIP;
+  }
+  if (rc == CPIR_OK) memcpy(r_out, a->r_pinned, C * 4);
+  return rc;
+}
+
 int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_rows, uint64_t q_cols, uint32_t* r_out) {
   if (!csrv || !q || !r_out) return CPIR_ERR_INVALID_ARGUMENT;
   Server* srv = const_cast<cpir_server*>(csrv);  // the pool is the only mutable state; it is internally locked
@@ -1478,8 +1572,10 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
   // ---- take a seat ----------------------------------------------------------------------------------------------
   const bool tr = srv->trace_on;
   const double t_enter = tr ? now_seconds() : 0;
+  const bool read_once_ok = respond_read_once_applicable(srv->layout);
   std::unique_lock<std::mutex> lk(srv->mu);
   RespondArena* a = nullptr;
+  bool solo = false;
   for (;;) {
     for (RespondArena& x : srv->arena)  // 1. an open arena that is still spreading
       if (!a && x.state == RespondArena::OPEN && x.joined < Server::kSpread) a = &x;
@@ -1488,6 +1584,11 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
         if (!a && x.state == RespondArena::FREE) {
           if (!x.q_dev) CPIR_TRY(arena_create(srv, x));
           a = &x, x.state = RespondArena::OPEN, x.status = CPIR_OK;
+          // nobody else is filling an arena or on the device: this caller is served alone, its query read in place
+          solo = read_once_ok;
+          for (const RespondArena& y : srv->arena)
+            if (&y != a && (y.state == RespondArena::OPEN || y.state == RespondArena::LAUNCHED)) solo = false;
+          if (solo) x.state = RespondArena::LAUNCHED;  // closed at once: later callers open the next arena and upload meanwhile
         }
     if (!a)
       for (RespondArena& x : srv->arena)  // 3. no arena free: fill the open one up
@@ -1499,6 +1600,18 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
   const bool leader = (seat == 0);
   lk.unlock();
   const double t_seated = tr ? now_seconds() : 0;
+  if (solo) {
+    const int st = respond_alone(srv, a, q, r_out);
+    if (tr) {
+      srv->trace.calls++, srv->trace.solo++;
+      srv->trace.ns_seat += (uint64_t)((t_seated - t_enter) * 1e9), srv->trace.ns_solo += (uint64_t)((now_seconds() - t_seated) * 1e9);
+    }
+    lk.lock();
+    a->state = RespondArena::FREE;
+    a->joined = a->staged = a->left = 0;
+    srv->cv.notify_all();
+    return st;
+  }
 
   // ---- stage the query (the reference copies too: from_bytes .to_vec(), matrix.rs:1001-1007) and enqueue its upload -----------------
   // (a shard reads only its own slots of the query: only those are staged and uploaded)
@@ -1592,6 +1705,7 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
     if (st == CPIR_OK) {
       std::lock_guard<std::mutex> ll(srv->launch_mu);  // the launch sequences of two arenas must not interleave on the run stream
       for (uint32_t i = 0; i < k && e == hipSuccess; i++) e = hipStreamWaitEvent(srv->run_stream, a->seat_ev[i], 0);
+      a->r0_zero = false;
       if (e == hipSuccess)
         st = respond_batched(srv->dev, srv->dtc, srv->layout, a->q_dev, srv->total_slots, srv->slot_offset, k, a->r_dev, nullptr, srv->run_stream);
       if (e == hipSuccess && st == CPIR_OK) e = hipMemcpyAsync(a->r_pinned, a->r_dev, (size_t)k * C * 4, hipMemcpyDeviceToHost, srv->run_stream);

@@ -70,7 +70,10 @@ int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout
 // one query whose words are read exactly once (q may therefore live in page-locked host memory: device-visible pointer), r already zero;
 // planar packing only, CPIR_ERR_INVALID_ARGUMENT where the step-major kernel does not apply
 int launch_respond_read_once(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
-                             uint64_t q_slot_offset, uint32_t* r_prezeroed, hipStream_t stream);
+                             uint64_t q_slot_offset, uint32_t* r_prezeroed, hipStream_t stream, uint64_t step_lo = 0, uint64_t step_hi = 0);
+// steps [step_lo, step_hi) of 512 slots only (0, 0 = all): a query may be answered by several launches, each over the steps whose
+// query words are in place by then; they add up in r
+bool respond_read_once_applicable(const cpir_dtc_layout& L);  // planar packing, LDS room for one response, respond.host_zero_copy on
 const char* respond_kernel_name(const cpir_dtc_layout& L);
 // respond_planar.hip (CPIR_PACK_PLANAR: the MFMA path); same contract as launch_respond, batch up to CPIR_PLANAR_MAX_QUERIES_PER_PASS
 constexpr uint32_t CPIR_PLANAR_MAX_QUERIES_PER_PASS = 8;

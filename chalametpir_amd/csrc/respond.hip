@@ -294,6 +294,7 @@ struct Tuning {
   int interleave_passes = -1;  // order of the passes of one launch: 0 slice order, 1 interleaved, -1 by shard size
   int planar_blocks_per_cu = 0;  // the matrix-core kernel (respond_planar.hip): 0 = by pass order (2 streaming, 3 sharing)
   int multi_pass_limit_mb = 2560;  // unfused batches: databases above this size get one launch per query
+  int host_zero_copy = 1;          // a lone host query is read by the kernel in place (page-locked memory), not uploaded first
   int ks_major = 1;                // the step-major matrix-core kernel: 0 never, 1 for fused batches, 2 wherever it applies
 };
 Tuning g_tuning;
@@ -367,6 +368,8 @@ extern "C" int cpir_tuning_set(const char* key, int value) {
   } else if (!strcmp(key, "respond.interleave_passes")) {
     if (value < -1 || value > 1) return CPIR_ERR_INVALID_ARGUMENT;
     g_tuning.interleave_passes = value;
+  } else if (!strcmp(key, "respond.host_zero_copy")) {
+    g_tuning.host_zero_copy = value ? 1 : 0;
   } else if (!strcmp(key, "respond.ks_major")) {
     if (value < 0 || value > 2) return CPIR_ERR_INVALID_ARGUMENT;
     g_tuning.ks_major = value;
@@ -406,8 +409,14 @@ const char* respond_kernel_name(const cpir_dtc_layout& L) {
   return L.packing == CPIR_PACK_PLANAR ? "respond_planar_kernel" : "respond_kernel";
 }
 
+bool respond_read_once_applicable(const cpir_dtc_layout& L) {
+  std::lock_guard<std::mutex> lk(g_tuning_mu);
+  // one query's responses must fit the step-major kernel's LDS accumulators (48 KiB: 12288 padded columns)
+  return g_tuning.host_zero_copy != 0 && L.packing == CPIR_PACK_PLANAR && (uint64_t)(L.num_cols + 15) / 16 * 64 <= (48u << 10);
+}
+
 int launch_respond_read_once(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
-                             uint64_t q_slot_offset, uint32_t* r_prezeroed, hipStream_t stream) {
+                             uint64_t q_slot_offset, uint32_t* r_prezeroed, hipStream_t stream, uint64_t step_lo, uint64_t step_hi) {
   if (!dtc || !q || !r_prezeroed || L.packing != CPIR_PACK_PLANAR) return CPIR_ERR_INVALID_ARGUMENT;
   CPIR_TRY(check_layout(L));
   if (q_slot_offset + L.num_slots > q_len) return CPIR_ERR_SHARD_RANGE;
@@ -418,7 +427,7 @@ int launch_respond_read_once(const Device* dev, const uint32_t* dtc, const cpir_
     t = g_tuning;
   }
   return launch_respond_planar(dev, dtc, L, q, q_len, q_slot_offset, 1, 1, r_prezeroed, stream, t.planar_blocks_per_cu, t.nontemporal != 0,
-                               t.xcd_split != 0, 0, 3, true);
+                               t.xcd_split != 0, 0, 3, true, step_lo, step_hi);
 }
 
 int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,

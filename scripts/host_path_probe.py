@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Closed-loop callers on ONE server handle through the host-pointer C ABI (cpir_server_respond), at a BASELINE config.
-usage: host_path_probe.py <cfg> <threads> <per-thread calls> <pinned 0|1>     (CPIR_RESPOND_TRACE=1 prints the phase split at exit)"""
+usage: host_path_probe.py <cfg> <threads> <per-thread calls> <pinned 0|1> [zero-copy 0|1]   (CPIR_RESPOND_TRACE=1 prints the phase split at exit)
+The expected responses are always computed with respond.host_zero_copy=0 (upload + tile-major kernel)."""
 import os
 import sys
 import threading
@@ -15,6 +16,7 @@ import chalametpir_amd as cp  # noqa: E402
 from bench import CONFIGS  # noqa: E402
 
 cfg, threads, per, pinned = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+zero_copy = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 n_keys, arity, value_bytes = CONFIGS[cfg]
 b = cp.find_encoded_db_matrix_element_bit_length(n_keys)
 _, _, N = cp.filter_shape(arity, n_keys)
@@ -35,7 +37,9 @@ if pinned:
         p.array[:] = q
         pins.append(p)
 bufs = [p.array for p in pins] if pinned else qs
+cp.tuning_set("respond.host_zero_copy", 0)
 want = [srv.respond_array(q) for q in qs]
+cp.tuning_set("respond.host_zero_copy", zero_copy)
 bad = [0]
 
 
@@ -51,5 +55,5 @@ t0 = time.perf_counter()
 [t.start() for t in ts]
 [t.join() for t in ts]
 dt = time.perf_counter() - t0
-print(f"{cfg} threads={threads} pinned={pinned}: {threads * per / dt:.0f} queries/s, {dt / per * 1e6:.0f} us per call per thread, mismatches {bad[0]}", flush=True)
+print(f"{cfg} threads={threads} pinned={pinned} zero_copy={zero_copy}: {threads * per / dt:.0f} queries/s, {dt / per * 1e6:.0f} us per call per thread, mismatches {bad[0]}", flush=True)
 srv.close()
