@@ -81,8 +81,9 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
                           uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, int blocks_per_cu,
                           bool nontemporal, bool xcd_split, int interleave, int ks_mode, bool r_prezeroed = false, uint64_t step_lo = 0,
                           uint64_t step_hi = 0);
-// ks_mode: 0 = the tile-major kernel only; 1 = the step-major kernel for fused batches (2+ queries per pass), where building the A
-// fragments once per step pays (26 against 30 us per query at 8 per pass); 2 = the step-major kernel wherever it applies; 3 = the
+// ks_mode: 0 = the tile-major kernel only; 1 = the step-major kernel for fused batches (2+ queries per pass: 26 against
+// 32 us per query at 8 per pass) and for single-pass launches (a lone query: 192 against 201 us), the tile-major kernel for one query per
+// pass over many passes; 2 = the step-major kernel wherever it applies; 3 = the
 // step-major kernel or fail: the caller needs every query word read exactly once (a query read in place from page-locked host memory).  r_prezeroed: the caller has zeroed r already.
 bool respond_batch_fusion();
 uint64_t respond_multi_pass_limit_bytes();

@@ -295,7 +295,7 @@ struct Tuning {
   int planar_blocks_per_cu = 0;  // the matrix-core kernel (respond_planar.hip): 0 = by pass order (2 streaming, 3 sharing)
   int multi_pass_limit_mb = 2560;  // unfused batches: databases above this size get one launch per query
   int host_zero_copy = 1;          // a lone host query is read by the kernel in place (page-locked memory), not uploaded first
-  int ks_major = 1;                // the step-major matrix-core kernel: 0 never, 1 for fused batches, 2 wherever it applies
+  int ks_major = 1;                // the step-major matrix-core kernel: 0 never, 1 fused batches + lone launches, 2 wherever it applies
 };
 Tuning g_tuning;
 std::mutex g_tuning_mu;
@@ -371,7 +371,7 @@ extern "C" int cpir_tuning_set(const char* key, int value) {
   } else if (!strcmp(key, "respond.host_zero_copy")) {
     g_tuning.host_zero_copy = value ? 1 : 0;
   } else if (!strcmp(key, "respond.ks_major")) {
-    if (value < 0 || value > 2) return CPIR_ERR_INVALID_ARGUMENT;
+    if (value < 0 || value > 3) return CPIR_ERR_INVALID_ARGUMENT;  // 3: as the in-place host path launches it (diagnosis)
     g_tuning.ks_major = value;
   } else if (!strcmp(key, "layout.dense")) {
     set_default_dense(value != 0);

@@ -56,6 +56,7 @@ struct PlanarArgs {
   uint32_t passes;         // independent passes over the database in this launch
   uint32_t q_scalar;       // q not 16-byte loadable -> guarded scalar loads everywhere
   uint32_t interleave;     // order of the passes of one launch (see the kernel)
+  uint32_t q_far;          // step-major kernel: q sits behind the host link -> a whole step of units between requesting and using it
   const uint32_t* colsum;  // step-major kernel: per-column field sums behind the tiles (NULL: this launch does not cover step 0)
 };
 
@@ -305,7 +306,7 @@ respond_planar_kernel(const PlanarArgs a) {
 // Same arithmetic, same packed image, same results bit for bit.  Used for the slice pass order (every pass its own stream from HBM);
 // the interleaved order of the multi-GPU shards stays on the kernel above.
 template <int HB, int NS, bool NT>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NS == 1 ? 3 : 2, NS == 1 ? 3 : 2)))
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))  // two blocks a CU is the grid; at 3 it spills
 respond_planar_ks_kernel(const PlanarArgs a) {
   constexpr int NL = 8 + HB;     // 16-byte loads per lane and tile step
   constexpr int ST16 = NL * 64;  // uint4 per super-tile
@@ -348,17 +349,14 @@ respond_planar_ks_kernel(const PlanarArgs a) {
     const uint64_t slot0 = (uint64_t)ks_ * CPIR_PLANAR_SLOTS_PER_TILE;
     return a.q_scalar || slot0 + CPIR_PLANAR_SLOTS_PER_TILE > a.num_slots || a.q_slot_offset + slot0 + CPIR_PLANAR_SLOTS_PER_TILE > a.q_len;
   };
-  auto a_issue = [&](uint4(&raw)[NS][2][4], uint32_t ks_, uint32_t pass_) {
-    const uint64_t base = (uint64_t)ks_ * CPIR_PLANAR_SLOTS_PER_TILE + (2 * wave) * 64 + grp * 16;
+  const uint32_t half = lane >> 5, l32 = lane & 31;
+  auto a_issue = [&](uint4(&raw)[2 * NS], uint32_t ks_, uint32_t pass_) {
+    const uint64_t base = (uint64_t)ks_ * CPIR_PLANAR_SLOTS_PER_TILE + wave * 128 + l32 * 4;
 #pragma unroll
-    for (int s = 0; s < NS; s++) {
-      const uint32_t* qrow = a.q + ((uint64_t)pass_ * nq + qi[s]) * a.q_len + a.q_slot_offset;
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const uint4* src = reinterpret_cast<const uint4*>(qrow + base + h * 64);
-#pragma unroll
-        for (int d = 0; d < 4; d++) raw[s][h][d] = src[d];
-      }
+    for (int i = 0; i < 2 * NS; i++) {
+      const uint32_t row = 2 * i + half;
+      raw[i] = make_uint4(0, 0, 0, 0);
+      if (row < nq) raw[i] = *reinterpret_cast<const uint4*>(a.q + ((uint64_t)pass_ * nq + row) * a.q_len + a.q_slot_offset + base);
     }
   };
   // this wave's sum of the query words of a step, per query: the four lanes that share a query word (one per byte limb) count it once
@@ -372,17 +370,37 @@ respond_planar_ks_kernel(const PlanarArgs a) {
       if (grp == 0 && limb == 0) ksum[par][wave][4 * s + (cl >> 2)] = arow[s] ? v : 0u;
     }
   };
-  auto a_finish = [&](const uint4(&raw)[NS][2][4], int par) {
+  // A wave loads its 128 slots of every query row of a step with ONE fully coalesced 16-byte load per two rows (512 contiguous bytes a
+  // row: whole lines, each requested once -- which matters when q sits in host memory behind the link).  To reach the fragment order it
+  // parks the four rows of a row set in the 2 KiB of abuf it is about to fill (its own two k-blocks of that row set), reads them back
+  // lane by lane, and then overwrites them with the fragments: LDS operations of one wave complete in order, nobody else touches the
+  // slice before the step's barrier, and the fences keep the compiler from reordering the three phases.
+  auto wave_lds_fence = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  auto a_finish = [&](const uint4(&raw)[2 * NS], int par) {
     uint32_t part[NS];
 #pragma unroll
     for (int s = 0; s < NS; s++) {
+      uint32_t* const stage = reinterpret_cast<uint32_t*>(&abuf[par][s][2 * wave][0]);  // 4 rows x 128 words
+      *reinterpret_cast<uint4*>(stage + (0 + half) * 128 + l32 * 4) = raw[2 * s];
+      *reinterpret_cast<uint4*>(stage + (2 + half) * 128 + l32 * 4) = raw[2 * s + 1];
+      wave_lds_fence();
+      uint4 back[2][4];
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int d = 0; d < 4; d++) back[h][d] = *reinterpret_cast<const uint4*>(stage + (cl >> 2) * 128 + h * 64 + grp * 16 + d * 4);
+      wave_lds_fence();
       part[s] = 0;
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         uint32_t o[4];
 #pragma unroll
         for (int d = 0; d < 4; d++) {
-          const uint4& t = raw[s][h][d];
+          const uint4 t = back[h][d];
           part[s] += (t.x + t.y) + (t.z + t.w);
           const uint32_t v = gather_limb(t.x, t.y, t.z, t.w, sel01) ^ 0x80808080u;
           o[d] = arow[s] ? v : 0u;
@@ -444,19 +462,27 @@ respond_planar_ks_kernel(const PlanarArgs a) {
     // prologue of the pass: A fragments of the first step, the first tile
     uint4 b0[NL], b1[NL];
     load_tile(b0, tg_first, ks_first);
-    a_guarded(ks_first, pass, 0);
+    if (guarded_step(ks_first)) {
+      a_guarded(ks_first, pass, 0);
+    } else {
+      uint4 raw0[2 * NS];
+      a_issue(raw0, ks_first, pass);
+      a_finish(raw0, 0);
+    }
     __syncthreads();
 
     uint32_t tg = tg_first, ks = ks_first;
     int par = 0;
-    bool first_of_step = true;  // the first unit this block processes of the current step: builds the NEXT step's A fragments
+    // The NEXT step's query words are requested in the first unit this block processes of the current step and turned into fragments
+    // in its last one: a whole step's worth of units (tens of microseconds) covers the latency of the host link when q is read in place.
+    bool first_of_step = true;
+    uint4 raw[2 * NS];
     auto unit = [&](uint4(&cur)[NL], uint4(&nxt)[NL], bool last) {
       uint32_t tg_n = tg + 1, ks_n = ks;
       if (tg_n == TG) tg_n = 0, ks_n = ks + 1;
-      uint4 raw[NS][2][4];
-      const bool build = first_of_step && ks < ks_last;  // block-uniform
-      const bool g_n = build && guarded_step(ks + 1);
-      if (build && !g_n) a_issue(raw, ks + 1, pass);
+      const bool build = (a.q_far ? ks_n != ks : first_of_step) && ks < ks_last;  // block-uniform
+      const bool g_n = ks < ks_last && guarded_step(ks + 1);
+      if (first_of_step && ks < ks_last && !g_n) a_issue(raw, ks + 1, pass);
       if (!last) load_tile(nxt, tg_n, ks_n);
       v4i acc_lo[NS], acc_hi[NS];
 #pragma unroll
@@ -628,11 +654,22 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
   a.q_per_pass = batch;
   a.passes = passes;
   a.interleave = inter ? 1u : 0u;
+  a.q_far = ks_mode == 3 ? 1u : 0u;
   a.q_scalar = (reinterpret_cast<uintptr_t>(q) % 16 != 0 || q_slot_offset % 4 != 0 || (batch * passes > 1 && q_len % 4 != 0)) ? 1u : 0u;
 
   // resident blocks per CU, measured on MI355X at 2^20 keys: streaming (slice order) 2 blocks 188.7 us per query, 3 blocks 192.9,
   // 1 block 273; sharing passes (interleaved) 3 blocks 107 vs 2 blocks 118.  The two-row-set kernel fits 2 blocks per CU.
-  int bpc = blocks_per_cu > 0 ? blocks_per_cu : (inter ? 3 : 2);
+  // The step-major kernel where it applies: slice order (every pass its own stream), LDS room for the pass's responses.  It adds the
+  // correction terms itself (and reads every query word once), so no init kernel in front of it.  Measured at 2^20 keys, us per query,
+  // tile-major / step-major: one query, one launch 200.6 / 191.9 (2^22 keys 757 / 723, 8 kB values 1453 / 1394); passes of 8 queries
+  // 32.0 / 25.6, of 4 51.6 / 48.3; one query per pass, 32 passes a launch 185.3 / 185.0 (within half a per cent either way at every
+  // config) -- so mode 1 keeps the tile-major kernel for that streaming case only.  One-row-set step-major blocks run ONE per CU
+  // (191.9 against 202.3 with two: half as many prologues and flushes, and 4 waves x 2 tiles in flight already cover the latency).
+  const size_t racc_bytes = (size_t)batch * a.col_tiles * 16 * sizeof(uint32_t);
+  const bool want_ks = ks_mode >= 2 || (ks_mode == 1 && (batch >= 2 || passes == 1));
+  KernelFn fn_ks = (want_ks && !inter && racc_bytes <= (48u << 10)) ? pick_ks(hb, batch, nt) : nullptr;
+  if (ks_mode == 3 && !fn_ks) return CPIR_ERR_INVALID_ARGUMENT;  // the caller relies on q being read once
+  int bpc = blocks_per_cu > 0 ? blocks_per_cu : (fn_ks ? (batch <= 4 ? 1 : 2) : (inter ? 3 : 2));
   if (batch > 4 && bpc > 2) bpc = 2;
   const uint64_t units = (uint64_t)a.tile_groups * (a.ks_hi - a.ks_lo);
   uint64_t grid = (uint64_t)dev->num_cus * (uint64_t)bpc;
@@ -647,12 +684,6 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
   const uint32_t nq = batch * passes;
   const bool first = (step_lo == 0);
   const uint32_t* colsum = first ? dtc + (uint64_t)L.rows_padded * L.words_per_row_padded : nullptr;
-  // the step-major kernel where it applies: slice order (every pass its own stream), LDS room for the pass's responses.  It adds the
-  // correction terms itself (and reads every query word once), so no init kernel in front of it.
-  const size_t racc_bytes = (size_t)batch * a.col_tiles * 16 * sizeof(uint32_t);
-  const bool want_ks = ks_mode >= 2 || (ks_mode == 1 && batch >= 2);
-  KernelFn fn_ks = (want_ks && !inter && racc_bytes <= (48u << 10)) ? pick_ks(hb, batch, nt) : nullptr;
-  if (ks_mode == 3 && !fn_ks) return CPIR_ERR_INVALID_ARGUMENT;  // the caller relies on q being read once
   if (first && !r_prezeroed) CPIR_HIP_TRY(hipMemsetAsync(r, 0, (size_t)nq * L.num_cols * sizeof(uint32_t), stream));
   if (fn_ks) {
     a.colsum = colsum;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B timing of respond kernel variants in ONE process, interleaved rounds (the only comparison that means anything: boxes and runs
-differ by a few per cent).   usage: respond_ab.py <cfg> "<key=value,...>" "<key=value,...>" ... [--batch N] [--rounds R]
+differ by a few per cent).   usage: respond_ab.py <cfg> "<key=value,...>" "<key=value,...>" ... [--batch=N] [--rounds=R] [--fusion=F] [--hostq=1]
 Each variant is a comma list of cpir_tuning_set settings applied on top of the defaults; prints min / median us per query."""
 import os
 import statistics
@@ -32,6 +32,11 @@ del D
 Q = torch.empty((batch, N), dtype=torch.int32, device="cuda")
 for i in range(batch):
     dev.synth_fill(Q, N, 0x1000 + i, offset_words=i * N, stream=stream)
+if int(opts.get("hostq", 0)):  # the queries stay in page-locked HOST memory: the kernels read them over the link (respond.ks_major=2 reads each word once)
+    Qh = torch.empty((batch, N), dtype=torch.int32, pin_memory=True)
+    Qh.copy_(Q)
+    torch.cuda.synchronize()
+    Q = Qh
 R = torch.empty((batch, C), dtype=torch.int32, device="cuda")
 cp.tuning_set("respond.batch_fusion", fusion)
 defaults = {"respond.ks_major": 1, "respond.nontemporal": 1, "respond.planar_blocks_per_cu": 0, "respond.xcd_split": 1, "respond.interleave_passes": -1}
