@@ -322,3 +322,41 @@ def test_query_in_page_locked_memory_takes_the_direct_upload(orc, device):
         assert np.array_equal(srv.respond_array(pin.array), want)
         assert np.array_equal(srv.respond_array(q), want)
     pin.close()
+
+
+def test_lone_host_query_is_read_in_place(orc, device):
+    """a caller that finds the server idle is served without an upload: the step-major kernel reads its query in place -- from the
+    caller's buffer when that is page-locked and 16-byte aligned, else from the server's pinned block, filled and launched in two
+    halves once the query has 2^19 words.  Same answers as with respond.host_zero_copy=0 (upload first), for a whole server and for a
+    shard that starts in the middle of the query."""
+    import torch
+
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(4242)
+    for b, N, C in ((9, 3 * (1 << 18) + 77, 7), (6, (1 << 19) + 2048 + 5, 5), (10, 5 * 1536 + 3, 19)):
+        D = random_db_matrix(rng, N, C, b)
+        dtc = orc.row_wise_compress(orc.transpose(D), b)
+        whole = cp.Server.from_compressed(dtc, N, b, device=device)
+        lo, hi = 1024 * 3, N - 1000  # a shard: reads only q[lo:hi], from where it lies
+        D_dev = torch.from_numpy(np.ascontiguousarray(D[lo:hi]).view(np.int32)).cuda()
+        shard = cp.Server.from_device_matrix(D_dev, hi - lo, C, b, device=device, slot_offset=lo, total_slots=N)
+        dtc_shard = orc.row_wise_compress(orc.transpose(D[lo:hi]), b)
+        pin = cp.PinnedArray(N + 4)
+        try:
+            for trial in range(2):
+                q = random_query(rng, N)
+                want = orc.row_vector_x_compressed_transposed_matrix(q, dtc, N, b)[0]
+                want_shard = orc.row_vector_x_compressed_transposed_matrix(q[lo:hi], dtc_shard, hi - lo, b)[0]
+                for zero_copy in (1, 0):
+                    cp.tuning_set("respond.host_zero_copy", zero_copy)
+                    for shift in (0, 1):  # page-locked and aligned: read in place; shifted by one word: staged like pageable memory
+                        view = pin.array[shift:shift + N]
+                        view[:] = q
+                        assert np.array_equal(whole.respond_array(view), want), (b, zero_copy, shift)
+                        assert np.array_equal(shard.respond_array(view), want_shard), (b, zero_copy, shift)
+                    assert np.array_equal(whole.respond_array(q), want), (b, zero_copy)  # pageable
+                    assert np.array_equal(shard.respond_array(q), want_shard), (b, zero_copy)
+        finally:
+            cp.tuning_set("respond.host_zero_copy", 1)
+            pin.close()
