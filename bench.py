@@ -541,6 +541,17 @@ def host_path_timing(server, q_pool, N, torch):
     for i in range(n1):
         server.respond_array(pins[0].array)
     lat_pinned = (time.perf_counter() - t0) / n1
+    # the same with the in-place read switched off (upload first, as concurrent callers do): what the zero-copy path saves
+    cp.tuning_set("respond.host_zero_copy", 0)
+    try:
+        for _ in range(3):
+            server.respond_array(pins[0].array)
+        t0 = time.perf_counter()
+        for i in range(n1):
+            server.respond_array(pins[0].array)
+        lat_pinned_upload = (time.perf_counter() - t0) / n1
+    finally:
+        cp.tuning_set("respond.host_zero_copy", 1)
 
     def throughput(threads, per, pinned):
         def work(k):
@@ -558,6 +569,7 @@ def host_path_timing(server, q_pool, N, torch):
         "one_caller_us_per_query": round(lat * 1e6, 1),
         "one_caller_queries_per_sec": round(1.0 / lat, 1),
         "one_caller_pinned_query_us_per_query": round(lat_pinned * 1e6, 1),
+        "one_caller_pinned_query_upload_first_us_per_query": round(lat_pinned_upload * 1e6, 1),
         "eight_callers_queries_per_sec": round(throughput(8, 48, False), 1),
         "eight_callers_pinned_queries_per_sec": round(throughput(8, 48, True), 1),
         "sixteen_callers_queries_per_sec": round(throughput(16, 24, False), 1),
@@ -566,9 +578,10 @@ def host_path_timing(server, q_pool, N, torch):
         "h2d_GBps": round(rates["h2d"], 1),
         "d2h_GBps": round(rates["d2h"], 1),
         "link_bound_queries_per_sec": round(rates["h2d"] * 1e9 / (4 * N), 1),
-        "note": "cpir_server_respond on host buffers: pinned staging (skipped for page-locked queries) + H2D + respond kernel + D2H; concurrent "
-                "callers are coalesced into batched launches: arenas of up to 8 seats, uploads in single file on one stream, kernels back to back on "
-                "another; link_bound = h2d_GBps / query_bytes",
+        "note": "cpir_server_respond on host buffers.  A lone caller is served without an upload: the step-major kernel reads the query in "
+                "place over the host link (from the caller's page-locked buffer, or from the server's pinned block filled in two halves) + D2H. "
+                "Concurrent callers: pinned staging (skipped for page-locked queries) + H2D + batched respond + D2H, coalesced into arenas of up "
+                "to 8 seats, uploads in single file on one stream, kernels back to back on another; link_bound = h2d_GBps / query_bytes",
     }
     for p in pins:
         p.close()
