@@ -343,6 +343,26 @@ def main() -> int:
             "note": "cpir_server_respond_batch_device with batch fusion: the queries of a pass share one stream of the packed DB; same results bit for bit",
         }
         cp.tuning_set("respond.batch_fusion", 0)
+    # one query per LAUNCH (what a caller of cpir_server_respond_device pays when it has a single query): launches back to back
+    if world == 1:
+        r1 = torch.empty(C, dtype=torch.int32, device="cuda")
+        for i in range(4):
+            sharded.local.respond_device(q_pool[i % pool], r1, stream=stream)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        n_lone = 64
+        for i in range(n_lone):
+            sharded.local.respond_device(q_pool[i % pool], r1, stream=stream)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        lone_us = e0.elapsed_time(e1) * 1e3 / n_lone
+        result["lone_query_launch"] = {
+            "us_per_query": round(lone_us, 2),
+            "queries_per_sec": round(1e6 / lone_us, 1),
+            "note": "one query per launch, launches back to back on one stream (memset of r + one kernel each; on the planar packing the "
+                    "step-major kernel, which adds the correction terms itself)",
+        }
     # also row f3: the same independent passes (one query each, no fusion), but walked in the interleaved order so that concurrent
     # passes share database bytes in L2 / Infinity Cache -- above the HBM roof by construction, hence never the headline
     if world == 1 and full_layout.packing == 2 and passes_per_launch > 1:

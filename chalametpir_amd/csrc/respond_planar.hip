@@ -663,10 +663,13 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
   // correction terms itself (and reads every query word once), so no init kernel in front of it.  Measured at 2^20 keys, us per query,
   // tile-major / step-major: one query, one launch 200.6 / 191.9 (2^22 keys 757 / 723, 8 kB values 1453 / 1394); passes of 8 queries
   // 32.0 / 25.6, of 4 51.6 / 48.3; one query per pass, 32 passes a launch 185.3 / 185.0 (within half a per cent either way at every
-  // config) -- so mode 1 keeps the tile-major kernel for that streaming case only.  One-row-set step-major blocks run ONE per CU
+  // config but 2^22 keys) -- so mode 1 keeps the tile-major kernel for that streaming case.  One-row-set step-major blocks run ONE per CU
   // (191.9 against 202.3 with two: half as many prologues and flushes, and 4 waves x 2 tiles in flight already cover the latency).
   const size_t racc_bytes = (size_t)batch * a.col_tiles * 16 * sizeof(uint32_t);
-  const bool want_ks = ks_mode >= 2 || (ks_mode == 1 && (batch >= 2 || passes == 1));
+  // (a query beyond 8 MiB no longer stays in the XCDs' L2 next to the stream, and the tile-major kernel gathers every word of it once
+  // per tile group: at 2^22 keys, 18.9 MB, the step-major kernel streams 727 against 743 us per query, so it takes that case too)
+  const bool long_query = (uint64_t)(a.ks_hi - a.ks_lo) * CPIR_PLANAR_SLOTS_PER_TILE * 4 > (8ull << 20);
+  const bool want_ks = ks_mode >= 2 || (ks_mode == 1 && (batch >= 2 || passes == 1 || long_query));
   KernelFn fn_ks = (want_ks && !inter && racc_bytes <= (48u << 10)) ? pick_ks(hb, batch, nt) : nullptr;
   if (ks_mode == 3 && !fn_ks) return CPIR_ERR_INVALID_ARGUMENT;  // the caller relies on q being read once
   int bpc = blocks_per_cu > 0 ? blocks_per_cu : (fn_ks ? (batch <= 4 ? 1 : 2) : (inter ? 3 : 2));
