@@ -233,7 +233,11 @@ int cpir_op_synth_fill(cpir_device* dev, uint32_t* out, uint64_t count, uint64_t
  *   "respond.xcd_split" {0,1}, "respond.batch_fusion" {0,1} (0: every query of a batch call streams the database on its
  *   own, i.e. a batch call is only a cheaper way to enqueue independent responds), "respond.interleave_passes" {-1,0,1}
  *   (order in which one launch walks its passes; -1 = by shard size), "respond.planar_blocks_per_cu" 0..8, "respond.multi_pass_limit_mb"
- *   (unfused batches on databases above this size get one launch per query), "matmul.mfma" {0,1} (1, the default:
+ *   (unfused batches on databases above this size get one launch per query), "respond.ks_major" 0..3 (which launches of the
+ *   matrix-core respond take the step-major kernel: 0 none, 1 -- the default -- single-pass launches, fused batches and queries
+ *   beyond 8 MiB, 2 every launch it applies to, 3 as 2 but failing where it does not apply), "respond.host_zero_copy" {0,1}
+ *   (1, the default: cpir_server_respond serves a caller that finds the server idle without an upload, the kernel reading the
+ *   query in place from page-locked host memory; 0: always stage + upload first), "matmul.mfma" {0,1} (1, the default:
  *   cpir_op_mat_x_mat and the setup paths run right-hand sides below 2^16 on the i8 matrix cores; 0: on the integer VALU),
  *   "matmul.ablate" (diagnosis only, results are WRONG while it is non-zero: bit mask of parts of the matrix-core matmul to skip),
  *   "layout.dense" {0,1} and "layout.planar" {0,1}
