@@ -131,16 +131,6 @@ static double now_seconds() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// is this host address page-locked memory the HIP runtime knows (so that a copy from it is a true asynchronous DMA)?
-static bool host_pointer_is_pinned(const void* p) {
-  hipPointerAttribute_t attr;
-  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
-    (void)hipGetLastError();  // ordinary pageable memory: not an error worth keeping
-    return false;
-  }
-  return attr.type == hipMemoryTypeHost;
-}
-
 // A lone caller's query is copied into the pinned block by several threads: one core copies ~20 GB/s, the host link takes ~57, and the
 // reference's own benchmark is exactly a single caller handing over a pageable buffer (integrations/benches/online_phase.rs:81-97).
 // Three helper threads per process, created on first use; a caller that finds them busy (many concurrent callers: their own threads
@@ -241,20 +231,29 @@ static void device_release(Device* d) {
   }
 }
 
-// is this host address page-locked memory the HIP runtime knows (so that a copy from it is a true asynchronous DMA)?  The answer for
-// the last buffer asked about is remembered per thread: a server loop hands over the same query buffer again and again.  (A stale
-// answer is harmless: hipMemcpyAsync accepts pageable memory, and a pinned buffer taken for pageable is merely staged.)
-static bool host_pointer_is_pinned_cached(const void* p, size_t bytes) {
+// Where the device may read [p, p + bytes) of host memory in place (a DMA straight from the caller's buffer, or a kernel reading a lone
+// query where it lies): the device address of p if BOTH ends of the range are page-locked memory the runtime has mapped, at the same distance from each other as on the host (one mapping, or mappings laid end to end); NULL
+// otherwise (pageable memory, a registration that covers only part of the buffer).  Remembered per thread for the last buffer asked about.
+static const void* pinned_range_device_pointer(const void* p, size_t bytes) {
   struct Last {
     const char* lo = nullptr;
-    const char* hi = nullptr;
-    bool pinned = false;
+    size_t bytes = 0;
+    const void* dev = nullptr;
   };
   static thread_local Last last;
   const char* c = static_cast<const char*>(p);
-  if (last.lo && c >= last.lo && c + bytes <= last.hi) return last.pinned;
-  last.lo = c, last.hi = c + bytes, last.pinned = host_pointer_is_pinned(p);
-  return last.pinned;
+  if (last.lo == c && last.bytes == bytes) return last.dev;
+  const void* dev = nullptr;
+  hipPointerAttribute_t lo_attr, hi_attr;
+  if (bytes > 0 && hipPointerGetAttributes(&lo_attr, c) == hipSuccess && hipPointerGetAttributes(&hi_attr, c + bytes - 1) == hipSuccess) {
+    if (lo_attr.type == hipMemoryTypeHost && hi_attr.type == hipMemoryTypeHost && lo_attr.devicePointer && hi_attr.devicePointer &&
+        static_cast<const char*>(hi_attr.devicePointer) - static_cast<const char*>(lo_attr.devicePointer) == (ptrdiff_t)(bytes - 1))
+      dev = lo_attr.devicePointer;
+  } else {
+    (void)hipGetLastError();  // ordinary pageable memory: not an error worth keeping
+  }
+  last.lo = c, last.bytes = bytes, last.dev = dev;
+  return dev;
 }
 
 // an arena's query and response seats live in ONE device block and ONE pinned block (pinning is the slow call)
@@ -372,7 +371,7 @@ static void server_destroy(Server* srv) {
 static int group_shard_respond(const Server* child, Server::GroupLane& l, const uint32_t* q, uint32_t C) {
   const size_t n = (size_t)child->layout.num_slots;
   hipError_t e;
-  if (host_pointer_is_pinned(q)) {
+  if (pinned_range_device_pointer(q + child->slot_offset, n * 4) != nullptr) {  // this shard's slots lie in page-locked memory: DMA from there
     e = hipMemcpyAsync(l.q_dev, q + child->slot_offset, n * 4, hipMemcpyHostToDevice, l.stream);
   } else {
     memcpy(l.q_pinned, q + child->slot_offset, n * 4);
@@ -1491,11 +1490,12 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
   int rc = CPIR_OK;
   if (!a->r0_zero) e = hipMemsetAsync(a->r_dev, 0, C * 4, st);
   a->r0_zero = false;
+  // the slots this server reads, q[q_lo, q_lo + words), as the device addresses them -- if the whole range is page-locked; the kernel
+  // is handed the (possibly virtual) address of q[0] and adds the offset itself
   const uint32_t* in_place = nullptr;
-  if (e == hipSuccess && reinterpret_cast<uintptr_t>(q) % 16 == 0 && host_pointer_is_pinned_cached(q + q_lo, words * 4)) {
-    void* dp = nullptr;
-    if (hipHostGetDevicePointer(&dp, const_cast<uint32_t*>(q), 0) == hipSuccess) in_place = static_cast<const uint32_t*>(dp);
-    else (void)hipGetLastError();
+  if (e == hipSuccess && reinterpret_cast<uintptr_t>(q) % 16 == 0) {
+    const void* dp = pinned_range_device_pointer(q + q_lo, words * 4);
+    if (dp && reinterpret_cast<uintptr_t>(dp) % 16 == (q_lo * 4) % 16) in_place = static_cast<const uint32_t*>(dp) - q_lo;
   }
   if (e == hipSuccess && in_place) {
     rc = launch_respond_read_once(srv->dev, srv->dtc, srv->layout, in_place, srv->total_slots, srv->slot_offset, a->r_dev, st);
@@ -1618,7 +1618,7 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
   hipError_t up = hipSuccess;
   const size_t q_lo = (size_t)srv->slot_offset, q_hi = q_lo + (size_t)srv->layout.num_slots;
   uint32_t* const qd = a->q_dev + seat * N;
-  if (host_pointer_is_pinned_cached(q + q_lo, (q_hi - q_lo) * 4)) {
+  if (pinned_range_device_pointer(q + q_lo, (q_hi - q_lo) * 4) != nullptr) {
     // the caller's buffer is page-locked already (cpir_host_alloc, hipHostMalloc, hipHostRegister): DMA straight from it
     std::lock_guard<std::mutex> ul(srv->upload_mu);
     up = hipMemcpyAsync(qd + q_lo, q + q_lo, (q_hi - q_lo) * 4, hipMemcpyHostToDevice, srv->up_stream);

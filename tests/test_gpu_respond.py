@@ -360,3 +360,36 @@ def test_lone_host_query_is_read_in_place(orc, device):
         finally:
             cp.tuning_set("respond.host_zero_copy", 1)
             pin.close()
+
+
+def test_partly_registered_query_buffer_is_not_read_in_place(orc, device):
+    """hipHostRegister over only the first half of a query buffer: the in-place path must see that the END of the range is not
+    page-locked and stage the query instead (a kernel reading unmapped host pages would fault); registered as a whole it is read in place.
+    Same answers either way."""
+    import torch
+
+    import chalametpir_amd as cp
+
+    rt = torch.cuda.cudart()
+    if not hasattr(rt, "cudaHostRegister") or not hasattr(rt, "cudaHostUnregister"):
+        pytest.skip("no hipHostRegister binding in this torch")
+    rng = np.random.default_rng(99)
+    N, C, b = 6 * 4096 + 512, 11, 9
+    srv, dtc = make_server(cp, orc, device, rng, N, C, b)
+    raw = np.zeros(N + 2048, dtype=np.uint32)
+    off = (-raw.ctypes.data % 4096) // 4  # page-aligned start, so that the registered half ends on a page boundary
+    q = raw[off:off + N]
+    q[:] = random_query(rng, N)
+    want = orc.row_vector_x_compressed_transposed_matrix(q, dtc, N, b)[0]
+    half_bytes = (N // 2 * 4) // 4096 * 4096
+    for nbytes in (half_bytes, (N * 4 + 4095) // 4096 * 4096):
+        err = rt.cudaHostRegister(q.ctypes.data, nbytes, 0)
+        assert int(err) == 0, err
+        try:
+            for _ in range(2):
+                assert np.array_equal(srv.respond_array(q), want), nbytes
+        finally:
+            rt.cudaHostUnregister(q.ctypes.data)
+        # unregistered again, and a probe of another buffer in between so that the per-thread answer of the last probe is not reused
+        assert np.array_equal(srv.respond_array(q.copy()), want)
+        assert np.array_equal(srv.respond_array(q), want)
