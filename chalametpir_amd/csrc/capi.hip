@@ -233,7 +233,10 @@ static void device_release(Device* d) {
 
 // Where the device may read [p, p + bytes) of host memory in place (a DMA straight from the caller's buffer, or a kernel reading a lone
 // query where it lies): the device address of p if BOTH ends of the range are page-locked memory the runtime has mapped, at the same distance from each other as on the host (one mapping, or mappings laid end to end); NULL
-// otherwise (pageable memory, a registration that covers only part of the buffer).  Remembered per thread for the last buffer asked about.
+// otherwise (pageable memory, a registration that covers only part of the buffer).  Only a NO is remembered (per thread, for the last
+// buffer asked about: a server loop hands over the same pageable buffer again and again, and a stale no merely stages a buffer that has
+// been registered since); a yes is asked again every call, because a stale yes -- the buffer unregistered in between -- would let the
+// device read unmapped host pages.
 static const void* pinned_range_device_pointer(const void* p, size_t bytes) {
   struct Last {
     const char* lo = nullptr;
@@ -242,7 +245,7 @@ static const void* pinned_range_device_pointer(const void* p, size_t bytes) {
   };
   static thread_local Last last;
   const char* c = static_cast<const char*>(p);
-  if (last.lo == c && last.bytes == bytes) return last.dev;
+  if (last.lo == c && last.bytes == bytes && last.dev == nullptr) return nullptr;
   const void* dev = nullptr;
   hipPointerAttribute_t lo_attr, hi_attr;
   if (bytes > 0 && hipPointerGetAttributes(&lo_attr, c) == hipSuccess && hipPointerGetAttributes(&hi_attr, c + bytes - 1) == hipSuccess) {
