@@ -48,6 +48,8 @@ struct RespondArena {
   std::vector<hipEvent_t> seat_ev;  // upload of seat i has crossed the link
   hipEvent_t done_ev = nullptr;     // the arena's responses are in r_pinned
   const uint32_t* q_pinned_dev = nullptr;  // q_pinned as the device addresses it (a lone query is read in place)
+  uint32_t* fill_progress = nullptr;       // in the pinned block: steps of a lone query copied so far (the kernel polls it)
+  const uint32_t* fill_progress_dev = nullptr;
   bool r0_zero = false;                    // seat 0 of r_dev holds zeros (guarded by the arena's own leader: one at a time)
   // guarded by Server::mu
   enum State { FREE, OPEN, LAUNCHED, DONE } state = FREE;
@@ -85,6 +87,8 @@ struct Server {
   bool streams_ready = false;
   hipStream_t up_stream = nullptr;   // every query upload, FIFO
   hipStream_t run_stream = nullptr;  // every batched respond + response download, FIFO
+  std::atomic<uint32_t> fill_aborts{0};  // lone queries whose polled launch gave up waiting for the copy (3: stop polling)
+  std::atomic<uint64_t> fill_polled{0};  // lone pageable queries answered by one launch polling the copy's progress
   std::mutex upload_mu;              // one query's upload is enqueued at a time (whole queries, not interleaved pieces)
   std::mutex launch_mu;              // one arena's launch sequence is enqueued at a time
 
@@ -277,10 +281,19 @@ static void arenas_destroy(Server* srv) {
   srv->streams_ready = false;
 }
 
+// spare words behind the response seats of an arena's two blocks: the fill progress of a lone query in CPIR_FILL_LINES copies (pinned
+// block; + 16 words so that the copies can start on a 64-byte line), the abort flag (device block, behind seat 0's response)
+static constexpr size_t kArenaSpareWords = (size_t)CPIR_FILL_LINES * 16 + 16;
+static void publish_fill_progress(uint32_t* lines, uint32_t steps) {
+  for (uint32_t i = 0; i < CPIR_FILL_LINES; i++) __atomic_store_n(lines + i * 16, steps, __ATOMIC_RELEASE);
+}
+
 // on first use of this arena (caller holds Server::mu).  A shard stages only its own slots of a query, but seats keep the full stride.
 static int arena_create(Server* srv, RespondArena& a) {
   // kSeats queries, then kSeats responses (query block first: it stays 16-byte aligned)
-  const size_t qw = (size_t)srv->total_slots * Server::kSeats, rw = ((size_t)srv->layout.num_cols * Server::kSeats + 3) / 4 * 4;
+  // (+ 16 words behind the responses: the device block's spare words follow seat 0's response when a lone caller has only one seat
+  // to fill -- the abort flag of a polled launch; the pinned block's hold the fill progress the kernel polls)
+  const size_t qw = (size_t)srv->total_slots * Server::kSeats, rw = ((size_t)srv->layout.num_cols * Server::kSeats + 3) / 4 * 4 + kArenaSpareWords;
   auto fail = [&](hipError_t e, const char* what) {
     set_last_hip_error(e, what, __FILE__, __LINE__);
     arena_free(a);
@@ -309,6 +322,9 @@ static int arena_create(Server* srv, RespondArena& a) {
     void* dp = nullptr;
     if ((e = hipHostGetDevicePointer(&dp, a.q_pinned, 0)) != hipSuccess) return fail(e, "hipHostGetDevicePointer");
     a.q_pinned_dev = static_cast<const uint32_t*>(dp);
+    const size_t off = (qw + rw - kArenaSpareWords + 15) / 16 * 16;  // the copies start on a 64-byte line (the block itself is page-aligned)
+    a.fill_progress = a.q_pinned + off;
+    a.fill_progress_dev = a.q_pinned_dev + off;
   }
   a.r0_zero = false;
   a.seat_ev.assign(Server::kSeats, nullptr);
@@ -353,8 +369,9 @@ static void server_destroy(Server* srv) {
             n, nb, t.ns_seat.load() / n / 1e3, t.ns_stage.load() / n / 1e3, t.ns_out.load() / n / 1e3,
             t.ns_follow.load() / (n - nb > 0 ? n - nb : 1) / 1e3, t.ns_gate.load() / nb / 1e3, t.ns_enqueue.load() / nb / 1e3, t.ns_gpu.load() / nb / 1e3);
     for (int i = 1; i <= 8; i++) fprintf(stderr, " %d:%llu", i, (unsigned long long)t.batch_hist[i].load());
-    fprintf(stderr, "; served alone (query read in place) %llu, %.1f us each\n", (unsigned long long)t.solo.load(),
-            t.solo.load() ? t.ns_solo.load() / (double)t.solo.load() / 1e3 : 0.0);
+    fprintf(stderr, "; served alone (query read in place) %llu, %.1f us each; of those %llu by one launch polling the copy, %u such launches gave up\n",
+            (unsigned long long)t.solo.load(), t.solo.load() ? t.ns_solo.load() / (double)t.solo.load() / 1e3 : 0.0,
+            (unsigned long long)srv->fill_polled.load(), srv->fill_aborts.load());
   }
   if (!srv->shards.empty()) {
     group_ctx_destroy(srv);
@@ -1491,8 +1508,10 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
   std::lock_guard<std::mutex> ll(srv->launch_mu);
   hipError_t e = hipSuccess;
   int rc = CPIR_OK;
-  if (!a->r0_zero) e = hipMemsetAsync(a->r_dev, 0, C * 4, st);
+  // seat 0's response and the word behind it (the abort flag of a polled launch) are kept zeroed between uses
+  if (!a->r0_zero) e = hipMemsetAsync(a->r_dev, 0, (C + 1) * 4, st);
   a->r0_zero = false;
+  bool polled = false;
   // the slots this server reads, q[q_lo, q_lo + words), as the device addresses them -- if the whole range is page-locked; the kernel
   // is handed the (possibly virtual) address of q[0] and adds the offset itself
   const uint32_t* in_place = nullptr;
@@ -1505,56 +1524,84 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
   } else if (e == hipSuccess) {
     uint32_t* const qp = a->q_pinned;  // seat 0; same offsets as the caller's buffer
     constexpr size_t kJob = (size_t)1 << 16;  // 256 KiB of u32, a multiple of the kernel's 512-slot step
+    constexpr size_t kStepsPerJob = kJob / CPIR_PLANAR_SLOTS_PER_TILE;
     constexpr size_t kMaxJobs = 512;
     const size_t n_jobs = (words + kJob - 1) / kJob;
+    const uint32_t fill_timeout_us = respond_host_fill_timeout_us();
     if (words >= ((size_t)1 << 19) && n_jobs <= kMaxJobs && g_staging.try_acquire()) {
       std::atomic<int> done[kMaxJobs];
+      // ONE launch, in front of the copy: the kernel takes the steps of q round-robin (front to back over the whole grid) and waits
+      // for each step's words to be in place, which this thread announces job by job in *fill_progress; the copy (~55 us for 4.7 MB)
+      // runs underneath the stream (~200 us).  A wave that has waited fill_timeout_us gives up and flags the launch as void: the query
+      // is then answered again from the (by then complete) pinned block -- a launch that cannot start before this thread moves on
+      // (synchronous launches under a debugger or a serialising profiler) costs that timeout once, and after three such launches the
+      // server stops polling and launches each half of the query when it is in place.
+      polled = fill_timeout_us > 0 && srv->fill_aborts.load(std::memory_order_relaxed) < 3;
+      if (polled) {
+        publish_fill_progress(a->fill_progress, 0u);
+        const PlanarHostFill fill{a->fill_progress_dev, a->r_dev + C, fill_timeout_us};
+        rc = launch_respond_read_once(srv->dev, srv->dtc, srv->layout, a->q_pinned_dev, srv->total_slots, srv->slot_offset, a->r_dev, st, 0, 0,
+                                      &fill);
+        if (rc != CPIR_OK) polled = false;  // nothing was launched
+      }
       for (size_t i = 0; i < n_jobs; i++) {
         done[i].store(0, std::memory_order_relaxed);
         const size_t o = q_lo + i * kJob, n = (words - i * kJob < kJob) ? words - i * kJob : kJob;
         g_staging.submit(StagingHelpers::Job{qp + o, q + o, n * 4, &done[i]});
       }
-      const size_t j_half = (n_jobs + 1) / 2;
-      size_t next = 0;
-      for (int h = 0; h < 2 && rc == CPIR_OK; h++) {
-        const size_t j_hi = h ? n_jobs : j_half;
-        for (; next < j_hi; next++)
-          while (!done[next].load(std::memory_order_acquire))
-            if (!g_staging.help()) {
-#if defined(__x86_64__)
-              __builtin_ia32_pause();
-#endif
-            }
-        const uint64_t s_lo = h ? j_half * (kJob / CPIR_PLANAR_SLOTS_PER_TILE) : 0;
-        const uint64_t s_hi = h ? (words + CPIR_PLANAR_SLOTS_PER_TILE - 1) / CPIR_PLANAR_SLOTS_PER_TILE : j_half * (kJob / CPIR_PLANAR_SLOTS_PER_TILE);
-        if (s_hi > s_lo)
-          rc = launch_respond_read_once(srv->dev, srv->dtc, srv->layout, a->q_pinned_dev, srv->total_slots, srv->slot_offset, a->r_dev, st,
-                                        s_lo, s_hi);
-      }
-      // every job must have run before the stack array goes away, whatever happened
-      for (; next < n_jobs; next++)
-        while (!done[next].load(std::memory_order_acquire))
+      auto wait_for_job = [&](size_t i) {
+        while (!done[i].load(std::memory_order_acquire))
           if (!g_staging.help()) {
 #if defined(__x86_64__)
             __builtin_ia32_pause();
 #endif
           }
+      };
+      if (polled) {
+        for (size_t i = 0; i < n_jobs; i++) {
+          wait_for_job(i);
+          publish_fill_progress(a->fill_progress, i + 1 == n_jobs ? 0xffffffffu : (uint32_t)((i + 1) * kStepsPerJob));
+        }
+      } else if (rc == CPIR_OK) {
+        const size_t j_half = (n_jobs + 1) / 2;
+        size_t next = 0;
+        for (int h = 0; h < 2 && rc == CPIR_OK; h++) {
+          for (; next < (h ? n_jobs : j_half); next++) wait_for_job(next);
+          const uint64_t s_lo = h ? j_half * kStepsPerJob : 0;
+          const uint64_t s_hi = h ? (words + CPIR_PLANAR_SLOTS_PER_TILE - 1) / CPIR_PLANAR_SLOTS_PER_TILE : j_half * kStepsPerJob;
+          if (s_hi > s_lo)
+            rc = launch_respond_read_once(srv->dev, srv->dtc, srv->layout, a->q_pinned_dev, srv->total_slots, srv->slot_offset, a->r_dev, st,
+                                          s_lo, s_hi);
+        }
+      }
+      for (size_t i = 0; i < n_jobs; i++) wait_for_job(i);  // every job must have run before the stack array goes away, whatever happened
       g_staging.release();
     } else {
       memcpy(qp + q_lo, q + q_lo, words * 4);
       rc = launch_respond_read_once(srv->dev, srv->dtc, srv->layout, a->q_pinned_dev, srv->total_slots, srv->slot_offset, a->r_dev, st);
     }
   }
-  if (e == hipSuccess && rc == CPIR_OK) e = hipMemcpyAsync(a->r_pinned, a->r_dev, C * 4, hipMemcpyDeviceToHost, st);
-  if (e == hipSuccess && rc == CPIR_OK) e = hipEventRecord(a->done_ev, st);
-  if (e == hipSuccess && rc == CPIR_OK) {
-    // zeros for the next lone caller, off this one's critical path
-    if (hipMemsetAsync(a->r_dev, 0, C * 4, st) == hipSuccess) a->r0_zero = true;
-    else (void)hipGetLastError();
-    e = wait_for_event(a->done_ev);
-  } else {
-    (void)hipStreamSynchronize(st);  // whatever was enqueued reads the caller's buffer / the pinned block: drain before returning
+  for (int attempt = 0; attempt < 2; attempt++) {
+    if (e == hipSuccess && rc == CPIR_OK) e = hipMemcpyAsync(a->r_pinned, a->r_dev, (C + 1) * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && rc == CPIR_OK) e = hipEventRecord(a->done_ev, st);
+    if (e == hipSuccess && rc == CPIR_OK) {
+      // zeros for the next lone caller, off this one's critical path
+      if (hipMemsetAsync(a->r_dev, 0, (C + 1) * 4, st) == hipSuccess) a->r0_zero = true;
+      else (void)hipGetLastError();
+      e = wait_for_event(a->done_ev);
+    } else {
+      (void)hipStreamSynchronize(st);  // whatever was enqueued reads the caller's buffer / the pinned block: drain before returning
+    }
+    if (!(polled && e == hipSuccess && rc == CPIR_OK && a->r_pinned[C] != 0)) break;
+    // the polled launch gave up waiting: its results are void.  The pinned block is complete by now: answer from it, without polling.
+    polled = false;
+    srv->fill_aborts.fetch_add(1, std::memory_order_relaxed);
+    if (!a->r0_zero) e = hipMemsetAsync(a->r_dev, 0, (C + 1) * 4, st);
+    a->r0_zero = false;
+    if (e == hipSuccess)
+      rc = launch_respond_read_once(srv->dev, srv->dtc, srv->layout, a->q_pinned_dev, srv->total_slots, srv->slot_offset, a->r_dev, st);
   }
+  if (polled) srv->fill_polled.fetch_add(1, std::memory_order_relaxed);
   if (rc == CPIR_OK && e != hipSuccess) {
     set_last_hip_error(e, "respond (query read in place)", __FILE__, __LINE__);
     rc = CPIR_ERR_HIP;

@@ -67,12 +67,23 @@ uint64_t respond_scratch_words(const cpir_dtc_layout& L, uint32_t batch);
 // stream of that pass: q holds passes*batch queries of q_len entries, r passes*batch responses of num_cols entries.
 int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                    uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, uint32_t* scratch, hipStream_t stream);
+// A launch whose query is still being copied into page-locked host memory while the kernel runs (respond_planar.hip): the host counts
+// the 512-slot steps of q in place so far in *progress (host memory, device-visible address), front to back; the kernel waits for each
+// step it needs, at most timeout_us per wave, and sets *abort_flag (device memory, zeroed by the caller) if a wave gave up.
+constexpr uint32_t CPIR_FILL_LINES = 64;  // the count is kept in this many copies, one per 64-byte line (16 words apart): block b polls copy b % 64
+struct PlanarHostFill {
+  const uint32_t* progress;
+  uint32_t* abort_flag;
+  uint32_t timeout_us;
+};
 // one query whose words are read exactly once (q may therefore live in page-locked host memory: device-visible pointer), r already zero;
 // planar packing only, CPIR_ERR_INVALID_ARGUMENT where the step-major kernel does not apply
 int launch_respond_read_once(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
-                             uint64_t q_slot_offset, uint32_t* r_prezeroed, hipStream_t stream, uint64_t step_lo = 0, uint64_t step_hi = 0);
+                             uint64_t q_slot_offset, uint32_t* r_prezeroed, hipStream_t stream, uint64_t step_lo = 0, uint64_t step_hi = 0,
+                             const PlanarHostFill* fill = nullptr);
 // steps [step_lo, step_hi) of 512 slots only (0, 0 = all): a query may be answered by several launches, each over the steps whose
 // query words are in place by then; they add up in r
+uint32_t respond_host_fill_timeout_us();  // tuning "respond.host_fill_timeout_us"; 0 = never launch in front of the copy
 bool respond_read_once_applicable(const cpir_dtc_layout& L);  // planar packing, LDS room for one response, respond.host_zero_copy on
 const char* respond_kernel_name(const cpir_dtc_layout& L);
 // respond_planar.hip (CPIR_PACK_PLANAR: the MFMA path); same contract as launch_respond, batch up to CPIR_PLANAR_MAX_QUERIES_PER_PASS
@@ -80,7 +91,7 @@ constexpr uint32_t CPIR_PLANAR_MAX_QUERIES_PER_PASS = 8;
 int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                           uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, int blocks_per_cu,
                           bool nontemporal, bool xcd_split, int interleave, int ks_mode, bool r_prezeroed = false, uint64_t step_lo = 0,
-                          uint64_t step_hi = 0);
+                          uint64_t step_hi = 0, const PlanarHostFill* fill = nullptr);
 // ks_mode: 0 = the tile-major kernel only; 1 = the step-major kernel for fused batches (2+ queries per pass: 26 against
 // 32 us per query at 8 per pass) and for single-pass launches (a lone query: 192 against 201 us), the tile-major kernel for one query per
 // pass over many passes; 2 = the step-major kernel wherever it applies; 3 = the

@@ -294,6 +294,7 @@ struct Tuning {
   int interleave_passes = -1;  // order of the passes of one launch: 0 slice order, 1 interleaved, -1 by shard size
   int planar_blocks_per_cu = 0;  // the matrix-core kernel (respond_planar.hip): 0 = by pass order (2 streaming, 3 sharing)
   int multi_pass_limit_mb = 2560;  // unfused batches: databases above this size get one launch per query
+  int host_fill_timeout_us = 20000;  // a lone pageable host query: ONE launch polling the copy's progress, each wave for at most this long (0: off)
   int host_zero_copy = 1;          // a lone host query is read by the kernel in place (page-locked memory), not uploaded first
   int ks_major = 1;                // the step-major matrix-core kernel: 0 never, 1 fused batches + lone launches, 2 wherever it applies
 };
@@ -368,6 +369,9 @@ extern "C" int cpir_tuning_set(const char* key, int value) {
   } else if (!strcmp(key, "respond.interleave_passes")) {
     if (value < -1 || value > 1) return CPIR_ERR_INVALID_ARGUMENT;
     g_tuning.interleave_passes = value;
+  } else if (!strcmp(key, "respond.host_fill_timeout_us")) {
+    if (value < 0 || value > 1000000) return CPIR_ERR_INVALID_ARGUMENT;
+    g_tuning.host_fill_timeout_us = value;
   } else if (!strcmp(key, "respond.host_zero_copy")) {
     g_tuning.host_zero_copy = value ? 1 : 0;
   } else if (!strcmp(key, "respond.ks_major")) {
@@ -409,6 +413,11 @@ const char* respond_kernel_name(const cpir_dtc_layout& L) {
   return L.packing == CPIR_PACK_PLANAR ? "respond_planar_kernel" : "respond_kernel";
 }
 
+uint32_t respond_host_fill_timeout_us() {
+  std::lock_guard<std::mutex> lk(g_tuning_mu);
+  return (uint32_t)g_tuning.host_fill_timeout_us;
+}
+
 bool respond_read_once_applicable(const cpir_dtc_layout& L) {
   std::lock_guard<std::mutex> lk(g_tuning_mu);
   // one query's responses must fit the step-major kernel's LDS accumulators (48 KiB: 12288 padded columns)
@@ -416,7 +425,8 @@ bool respond_read_once_applicable(const cpir_dtc_layout& L) {
 }
 
 int launch_respond_read_once(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
-                             uint64_t q_slot_offset, uint32_t* r_prezeroed, hipStream_t stream, uint64_t step_lo, uint64_t step_hi) {
+                             uint64_t q_slot_offset, uint32_t* r_prezeroed, hipStream_t stream, uint64_t step_lo, uint64_t step_hi,
+                             const PlanarHostFill* fill) {
   if (!dtc || !q || !r_prezeroed || L.packing != CPIR_PACK_PLANAR) return CPIR_ERR_INVALID_ARGUMENT;
   CPIR_TRY(check_layout(L));
   if (q_slot_offset + L.num_slots > q_len) return CPIR_ERR_SHARD_RANGE;
@@ -427,7 +437,7 @@ int launch_respond_read_once(const Device* dev, const uint32_t* dtc, const cpir_
     t = g_tuning;
   }
   return launch_respond_planar(dev, dtc, L, q, q_len, q_slot_offset, 1, 1, r_prezeroed, stream, t.planar_blocks_per_cu, t.nontemporal != 0,
-                               t.xcd_split != 0, 0, 3, true, step_lo, step_hi);
+                               t.xcd_split != 0, 0, 3, true, step_lo, step_hi, fill);
 }
 
 int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,

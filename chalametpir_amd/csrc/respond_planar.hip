@@ -58,6 +58,11 @@ struct PlanarArgs {
   uint32_t interleave;     // order of the passes of one launch (see the kernel)
   uint32_t q_far;          // step-major kernel: q sits behind the host link -> a whole step of units between requesting and using it
   const uint32_t* colsum;  // step-major kernel: per-column field sums behind the tiles (NULL: this launch does not cover step 0)
+  // step-major kernel, q read in place from host memory that is still being FILLED while the kernel runs (a lone pageable host query):
+  uint32_t strided;          // blocks take whole steps round-robin (step s -> block s % blocks), so the grid consumes q front to back
+  const uint32_t* progress;  // host memory: number of 512-slot steps of q in place so far, CPIR_FILL_LINES copies 64 bytes apart (NULL: all of q is in place)
+  uint32_t* abort_flag;      // device memory: set when a wave has given up waiting (the launch's results are then void)
+  uint64_t poll_ticks;       // ... after this many ticks of the 100 MHz wall clock
 };
 
 template <bool NT>
@@ -329,9 +334,24 @@ respond_planar_ks_kernel(const PlanarArgs a) {
   const uint32_t ke0 = a.ks_lo + (uint32_t)(((uint64_t)ks_len * (xcd + 1)) / nx);
   const uint32_t span = ke0 - kb0;
   const uint32_t TG = a.tile_groups;
-  const uint64_t units = (uint64_t)TG * span;
-  const uint64_t sb = units * j / nb, se = units * (j + 1) / nb;  // unit u = (step kb0 + u / TG, tile group u % TG)
-  if (span == 0 || sb == se) return;  // block-uniform: an idle block takes part in nothing
+  // A block's work is a sequence of VISITS: (step, first tile group, one past the last tile group).
+  //   contiguous order: units u = (step kb0 + u / TG, tile group u % TG) of [0, TG * span) split evenly over the blocks;
+  //   strided order (nx == 1): `rounds` whole steps per block, step kb0 + r * nb + j in round r -- at any moment the grid works on nb
+  //   neighbouring steps, so q is consumed front to back -- and the units of the span % nb steps left over split evenly as above.
+  const uint32_t rounds = a.strided ? span / nb : 0;
+  const uint32_t tail0 = kb0 + rounds * nb;  // first step of the evenly split part
+  const uint64_t units = (uint64_t)TG * (ke0 - tail0);
+  const uint64_t sb = units * j / nb, se = units * (j + 1) / nb;
+  const uint32_t tail_visits = se > sb ? (uint32_t)((se - 1) / TG - sb / TG + 1) : 0;
+  const uint32_t n_visits = rounds + tail_visits;
+  if (n_visits == 0) return;  // block-uniform: an idle block takes part in nothing
+  // (the 64-bit divisions once, not per unit; plain scalars, no structs: selecting between structs captured by reference sends them
+  // through scratch memory)
+  const uint32_t tail_ks = tail0 + (uint32_t)(sb / TG), tail_tg0 = (uint32_t)(sb % TG);
+  const uint32_t tail_tg1 = se > sb ? (uint32_t)((se - 1) % TG) + 1 : TG;
+  auto visit_ks = [=](uint32_t v) { return v < rounds ? kb0 + v * nb + j : tail_ks + (v - rounds); };
+  auto visit_tg0 = [=](uint32_t v) { return v == rounds ? tail_tg0 : 0u; };
+  auto visit_tg1 = [=](uint32_t v) { return v + 1 == n_visits && tail_visits ? tail_tg1 : TG; };
 
   const uint32_t nq = a.q_per_pass;
   bool arow[NS];
@@ -348,6 +368,31 @@ respond_planar_ks_kernel(const PlanarArgs a) {
   auto guarded_step = [&](uint32_t ks_) {
     const uint64_t slot0 = (uint64_t)ks_ * CPIR_PLANAR_SLOTS_PER_TILE;
     return a.q_scalar || slot0 + CPIR_PLANAR_SLOTS_PER_TILE > a.num_slots || a.q_slot_offset + slot0 + CPIR_PLANAR_SLOTS_PER_TILE > a.q_len;
+  };
+  // q still being filled by the host (a.progress): wait until step ks_ is in place.  Every wave polls for itself (one request per wave and
+  // poll, a couple of microseconds each over the link); a wave that has waited poll_ticks gives up FOR GOOD, raises the abort flag and
+  // carries on with whatever it reads -- no wave ever leaves the common control flow, so the grid always drains; the host discards the
+  // results of an aborted launch.
+  // The count is published in CPIR_FILL_LINES copies, one per 64-byte line, and a block polls line (block % lines): uncached reads of ONE
+  // host line are served one after the other (measured: ~170 ns each, i.e. 1024 polling waves get an answer every 174 us and the kernel
+  // took 1.6 ms with everything in place); 16 waves per line are answered within 3 us.  The last count seen is kept: it only grows.
+  bool gave_up = false;
+  uint32_t seen = 0;
+  const uint32_t* const my_progress = a.progress ? a.progress + (blockIdx.x % CPIR_FILL_LINES) * 16 : nullptr;
+  auto wait_for_step = [&](uint32_t ks_) {
+    if (!my_progress || gave_up || seen > ks_) return;
+    const uint64_t t0 = wall_clock64();
+    // RELAXED system-scope loads (they bypass the caches by themselves): an acquire would invalidate the L2 under the whole grid's feet
+    // at every poll.  Nothing needs it: the words waited for are fetched only after the loop has seen the count (control dependency),
+    // from host memory that this kernel has not touched before, and the host publishes the count with a release store after the copy.
+    while ((seen = __hip_atomic_load(my_progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) <= ks_) {
+      if (wall_clock64() - t0 > a.poll_ticks) {
+        gave_up = true;
+        if (lane == 0) atomicOr(a.abort_flag, 1u);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(64);  // ~2 us between polls of a wave: a poll is a 64-byte read over the host link
+    }
   };
   const uint32_t half = lane >> 5, l32 = lane & 31;
   auto a_issue = [&](uint4(&raw)[2 * NS], uint32_t ks_, uint32_t pass_) {
@@ -454,36 +499,47 @@ respond_planar_ks_kernel(const PlanarArgs a) {
     return left < CPIR_PLANAR_SLOTS_PER_TILE ? (uint32_t)left : CPIR_PLANAR_SLOTS_PER_TILE;
   };
 
-  const uint32_t ks_first = kb0 + (uint32_t)(sb / TG), tg_first = (uint32_t)(sb % TG);
-  const uint32_t ks_last = kb0 + (uint32_t)((se - 1) / TG);  // last step this block touches
-
   for (uint32_t pass = 0; pass < a.passes; pass++) {
     for (uint32_t i = threadIdx.x; i < nq * cpad; i += kThreads) racc[i] = 0;
-    // prologue of the pass: A fragments of the first step, the first tile
+    // prologue of the pass: A fragments of the first visit's step, the first tile
+    uint32_t v = 0;
+    uint32_t cks = visit_ks(0), ctg1 = visit_tg1(0);  // the current visit
+    uint32_t tg = visit_tg0(0);
     uint4 b0[NL], b1[NL];
-    load_tile(b0, tg_first, ks_first);
-    if (guarded_step(ks_first)) {
-      a_guarded(ks_first, pass, 0);
+    load_tile(b0, tg, cks);
+    wait_for_step(cks);
+    if (guarded_step(cks)) {
+      a_guarded(cks, pass, 0);
     } else {
       uint4 raw0[2 * NS];
-      a_issue(raw0, ks_first, pass);
+      a_issue(raw0, cks, pass);
       a_finish(raw0, 0);
     }
     __syncthreads();
 
-    uint32_t tg = tg_first, ks = ks_first;
     int par = 0;
-    // The NEXT step's query words are requested in the first unit this block processes of the current step and turned into fragments
-    // in its last one: a whole step's worth of units (tens of microseconds) covers the latency of the host link when q is read in place.
-    bool first_of_step = true;
+    // The NEXT visit's query words are requested in the first unit of the current visit; they are turned into fragments in the same
+    // unit when q is near (L2), in the visit's last unit when q is far (host memory: a whole visit's worth of units, tens of
+    // microseconds, covers the latency of the link).
+    bool first_of_visit = true;
+    bool done = false;
     uint4 raw[2 * NS];
-    auto unit = [&](uint4(&cur)[NL], uint4(&nxt)[NL], bool last) {
-      uint32_t tg_n = tg + 1, ks_n = ks;
-      if (tg_n == TG) tg_n = 0, ks_n = ks + 1;
-      const bool build = (a.q_far ? ks_n != ks : first_of_step) && ks < ks_last;  // block-uniform
-      const bool g_n = ks < ks_last && guarded_step(ks + 1);
-      if (first_of_step && ks < ks_last && !g_n) a_issue(raw, ks + 1, pass);
-      if (!last) load_tile(nxt, tg_n, ks_n);
+    auto unit = [&](uint4(&cur)[NL], uint4(&nxt)[NL]) __attribute__((always_inline)) {
+      const uint32_t ks = cks;
+      const bool last_of_visit = tg + 1 == ctg1;
+      const bool more_visits = v + 1 < n_visits;
+      const uint32_t nks = visit_ks(v + 1);  // the next visit (unused values when there is none)
+      const bool last = last_of_visit && !more_visits;
+      const uint32_t tg_n = last_of_visit ? visit_tg0(v + 1) : tg + 1, ks_n = last_of_visit ? nks : ks;
+      const bool build = (a.q_far ? last_of_visit : first_of_visit) && more_visits;  // block-uniform
+      const bool g_n = more_visits && guarded_step(nks);
+      if (first_of_visit && more_visits) {
+        wait_for_step(nks);
+        if (!g_n) a_issue(raw, nks, pass);
+      }
+      // ALWAYS issued (the very last unit asks for its own tile again: 9 KiB per block and pass): with a conditional prefetch the compiler
+      // cannot count the loads in flight and waits for all of them, this tile's successor included, before the first MFMA
+      load_tile(nxt, last ? tg : tg_n, last ? ks : ks_n);
       v4i acc_lo[NS], acc_hi[NS];
 #pragma unroll
       for (int s = 0; s < NS; s++) acc_lo[s] = v4i{0, 0, 0, 0}, acc_hi[s] = v4i{0, 0, 0, 0};
@@ -507,39 +563,43 @@ respond_planar_ks_kernel(const PlanarArgs a) {
             if constexpr (HB > 0) acc_hi[s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, hb, acc_hi[s], 0, 0, 0);
           }
         }
-        const uint32_t nv = valid_slots(ks);
+        const uint32_t nvs = valid_slots(ks);
         const uint32_t col_term = (ks == 0 && a.colsum) ? 0x80808080u * a.colsum[T * 16 + cl] : 0u;
 #pragma unroll
         for (int s = 0; s < NS; s++) {
-          uint32_t v = 0;
+          uint32_t val = 0;
 #pragma unroll
-          for (int i = 0; i < 4; i++) v += ((uint32_t)acc_lo[s][i] + ((uint32_t)acc_hi[s][i] << 8)) << (8 * i);
+          for (int i = 0; i < 4; i++) val += ((uint32_t)acc_lo[s][i] + ((uint32_t)acc_hi[s][i] << 8)) << (8 * i);
           const uint32_t query = 4 * s + grp;
           if (query < nq) {
             const uint32_t qsum = (ksum[par][0][query] + ksum[par][1][query]) + (ksum[par][2][query] + ksum[par][3][query]);
-            v += 128u * qsum - 0x40404000u * nv + col_term;  // 128 * 0x80808080 = 0x40404000 mod 2^32
-            atomicAdd(&racc[query * cpad + T * 16 + cl], v);  // LDS; this wave owns tile T of every step
+            val += 128u * qsum - 0x40404000u * nvs + col_term;  // 128 * 0x80808080 = 0x40404000 mod 2^32
+            atomicAdd(&racc[query * cpad + T * 16 + cl], val);  // LDS; this wave owns tile T of every step
           }
         }
       }
       if (build) {
         if (!g_n) a_finish(raw, par ^ 1);
-        else a_guarded(ks + 1, pass, par ^ 1);
+        else a_guarded(nks, pass, par ^ 1);
       }
-      first_of_step = false;
-      if (ks_n != ks) {
-        __syncthreads();  // everybody is done with this step's fragments; the next step's are complete
-        par ^= 1;
-        first_of_step = true;
+      first_of_visit = false;
+      if (last_of_visit) {
+        if (more_visits) {
+          __syncthreads();  // everybody is done with this step's fragments; the next step's are complete
+          par ^= 1;
+          first_of_visit = true;
+          v++, cks = nks, ctg1 = visit_tg1(v);
+        } else {
+          done = true;
+        }
       }
-      tg = tg_n, ks = ks_n;
+      tg = tg_n;
     };
-    uint64_t i = sb;
-    for (; i + 2 <= se; i += 2) {
-      unit(b0, b1, false);
-      unit(b1, b0, i + 2 == se);
+    while (!done) {
+      unit(b0, b1);
+      if (done) break;
+      unit(b1, b0);
     }
-    if (i < se) unit(b0, b1, true);
 
     // ---- this block's part of the pass's responses ----
     __syncthreads();
@@ -619,7 +679,8 @@ KernelFn pick_ks(uint32_t hb, uint32_t batch, bool nt) { return batch <= 4 ? pic
 
 int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                           uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, int blocks_per_cu,
-                          bool nontemporal, bool xcd_split, int interleave, int ks_mode, bool r_prezeroed, uint64_t step_lo, uint64_t step_hi) {
+                          bool nontemporal, bool xcd_split, int interleave, int ks_mode, bool r_prezeroed, uint64_t step_lo, uint64_t step_hi,
+                          const PlanarHostFill* fill) {
   // shape invariants the kernel relies on (layout already checked by the caller)
   if (L.packing != CPIR_PACK_PLANAR || batch == 0 || batch > CPIR_PLANAR_MAX_QUERIES_PER_PASS || passes == 0) return CPIR_ERR_INVALID_ARGUMENT;
   const uint32_t hb = planar_hi_planes(L.mat_elem_bit_len);
@@ -655,6 +716,13 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
   a.passes = passes;
   a.interleave = inter ? 1u : 0u;
   a.q_far = ks_mode == 3 ? 1u : 0u;
+  // q in host memory: whole steps round-robin over the blocks, so that q is consumed front to back (it may still be arriving) and
+  // every word crosses the link exactly once
+  a.strided = ks_mode == 3 ? 1u : 0u;
+  a.progress = fill ? fill->progress : nullptr;
+  a.abort_flag = fill ? fill->abort_flag : nullptr;
+  a.poll_ticks = fill ? (uint64_t)fill->timeout_us * 100 : 0;
+  if (fill && (ks_mode != 3 || !fill->progress || !fill->abort_flag)) return CPIR_ERR_INVALID_ARGUMENT;
   a.q_scalar = (reinterpret_cast<uintptr_t>(q) % 16 != 0 || q_slot_offset % 4 != 0 || (batch * passes > 1 && q_len % 4 != 0)) ? 1u : 0u;
 
   // resident blocks per CU, measured on MI355X at 2^20 keys: streaming (slice order) 2 blocks 188.7 us per query, 3 blocks 192.9,
@@ -676,7 +744,7 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
   if (batch > 4 && bpc > 2) bpc = 2;
   const uint64_t units = (uint64_t)a.tile_groups * (a.ks_hi - a.ks_lo);
   uint64_t grid = (uint64_t)dev->num_cus * (uint64_t)bpc;
-  a.nx = (xcd_split && (a.ks_hi - a.ks_lo) >= 8 && grid % 8 == 0) ? 8u : 1u;
+  a.nx = (xcd_split && !a.strided && (a.ks_hi - a.ks_lo) >= 8 && grid % 8 == 0) ? 8u : 1u;
   const uint64_t blocks_needed = (units + kThreads / 64 - 1) / (kThreads / 64);
   if (grid > blocks_needed) {
     grid = blocks_needed;

@@ -392,3 +392,28 @@ def test_partly_registered_query_buffer_is_not_read_in_place(orc, device):
             rt.cudaHostUnregister(q.ctypes.data)
         # unregistered again: the same address must not be taken for page-locked any more
         assert np.array_equal(srv.respond_array(q), want)
+
+
+def test_lone_pageable_query_polled_launch_and_its_fallbacks(orc, device):
+    """a lone pageable query of 2^19+ words: ONE launch in front of the copy, the kernel waiting for each step's words
+    (respond.host_fill_timeout_us, default 20 ms per wave).  With a 1 us limit every wave gives up at once: the launch is flagged void and
+    the query answered again from the complete pinned block; after three such launches the server stops polling (two launches, each
+    when its half is in place); 0 switches polling off from the start.  Same answers throughout."""
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(777)
+    b, N, C = 9, (1 << 19) + 3 * 4096 + 17, 6
+    D = random_db_matrix(rng, N, C, b)
+    dtc = orc.row_wise_compress(orc.transpose(D), b)
+    qs = [random_query(rng, N) for _ in range(3)]
+    want = [orc.row_vector_x_compressed_transposed_matrix(q, dtc, N, b)[0] for q in qs]
+    try:
+        for timeout_us in (20000, 1, 0):
+            cp.tuning_set("respond.host_fill_timeout_us", timeout_us)
+            srv = cp.Server.from_compressed(dtc, N, b, device=device)  # a fresh server: its give-up count starts at zero
+            for rep in range(3):  # with the 1 us limit: three void launches, then the two-launch path
+                for q, w in zip(qs, want):
+                    assert np.array_equal(srv.respond_array(q), w), (timeout_us, rep)
+            srv.close()
+    finally:
+        cp.tuning_set("respond.host_fill_timeout_us", 20000)
