@@ -599,7 +599,8 @@ def host_path_timing(server, q_pool, N, torch):
         "d2h_GBps": round(rates["d2h"], 1),
         "link_bound_queries_per_sec": round(rates["h2d"] * 1e9 / (4 * N), 1),
         "note": "cpir_server_respond on host buffers.  A lone caller is served without an upload: the step-major kernel reads the query in "
-                "place over the host link (from the caller's page-locked buffer, or from the server's pinned block filled in two halves) + D2H. "
+                "place over the host link (from the caller's page-locked buffer, or from the server's pinned block WHILE the caller's pageable query is "
+                "being copied into it: one launch in front of the copy, the kernel polling the copy's progress) + D2H. "
                 "Concurrent callers: pinned staging (skipped for page-locked queries) + H2D + batched respond + D2H, coalesced into arenas of up "
                 "to 8 seats, uploads in single file on one stream, kernels back to back on another; link_bound = h2d_GBps / query_bytes",
     }

@@ -237,7 +237,9 @@ int cpir_op_synth_fill(cpir_device* dev, uint32_t* out, uint64_t count, uint64_t
  *   matrix-core respond take the step-major kernel: 0 none, 1 -- the default -- single-pass launches, fused batches and queries
  *   beyond 8 MiB, 2 every launch it applies to, 3 as 2 but failing where it does not apply), "respond.host_zero_copy" {0,1}
  *   (1, the default: cpir_server_respond serves a caller that finds the server idle without an upload, the kernel reading the
- *   query in place from page-locked host memory; 0: always stage + upload first), "matmul.mfma" {0,1} (1, the default:
+ *   query in place from page-locked host memory; 0: always stage + upload first), "respond.host_fill_timeout_us" 0..1000000
+ *   (a lone PAGEABLE query of 2^19+ words: one launch in front of the copy into pinned memory, every wave waiting at most this long
+ *   in all for the words it needs -- default 20000; 0: two launches, each when its half of the query is in place), "matmul.mfma" {0,1} (1, the default:
  *   cpir_op_mat_x_mat and the setup paths run right-hand sides below 2^16 on the i8 matrix cores; 0: on the integer VALU),
  *   "matmul.ablate" (diagnosis only, results are WRONG while it is non-zero: bit mask of parts of the matrix-core matmul to skip),
  *   "layout.dense" {0,1} and "layout.planar" {0,1}
