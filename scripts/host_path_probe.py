@@ -37,6 +37,9 @@ if pinned:
         p.array[:] = q
         pins.append(p)
 bufs = [p.array for p in pins] if pinned else qs
+for kv in filter(None, os.environ.get("CPIR_TUNE", "").split(",")):  # e.g. CPIR_TUNE=respond.host_hand_over=0
+    k, v = kv.split("=")
+    cp.tuning_set(k, int(v))
 cp.tuning_set("respond.host_zero_copy", 0)
 want = [srv.respond_array(q) for q in qs]
 cp.tuning_set("respond.host_zero_copy", zero_copy)
