@@ -417,3 +417,52 @@ def test_lone_pageable_query_polled_launch_and_its_fallbacks(orc, device):
             srv.close()
     finally:
         cp.tuning_set("respond.host_fill_timeout_us", 20000)
+
+
+def test_random_shapes_every_kernel_order(orc, device):
+    """seeded random shapes (slots, columns, bit length, shard window, query alignment) through every dispatch of the matrix-core
+    respond: tile-major (0), the default split (1), step-major everywhere (2) and step-major in the strided step order of the in-place
+    host path (3) -- block counts above and below the number of steps, ragged last steps, shards that start at odd slots -- against
+    the oracle; the host entry point on top (lone caller: query read in place / staged)."""
+    import torch
+
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(20260)
+    stream = torch.cuda.current_stream()
+    try:
+        for trial in range(40):
+            b = int(rng.choice([4, 6, 8, 9, 9, 10, 12, 14]))
+            cf = cf_of(b)
+            steps = int(rng.choice([1, 2, 3, 7, 31, 200, 257, 300, 700]))  # around 256 blocks of the one-block-per-CU grid
+            N = max(cf, steps * 512 - int(rng.integers(0, 512)))
+            C = int(rng.choice([1, 3, 16, 17, 63, 64, 65, 130]))
+            if N * C > 12_000_000:
+                C = max(1, 12_000_000 // N)
+            D = random_db_matrix(rng, N, C, b)
+            lo = int(rng.integers(0, max(1, N // 3)))
+            hi = N - int(rng.integers(0, max(1, N // 5)))
+            if rng.integers(0, 3) == 0:
+                lo, hi = 0, N
+            dtc = orc.row_wise_compress(orc.transpose(D[lo:hi]), b)
+            D_dev = torch.from_numpy(np.ascontiguousarray(D[lo:hi]).view(np.int32)).cuda()
+            srv = cp.Server.from_device_matrix(D_dev, hi - lo, C, b, device=device, slot_offset=lo, total_slots=N)
+            q = random_query(rng, N)
+            want = orc.row_vector_x_compressed_transposed_matrix(q[lo:hi], dtc, hi - lo, b)[0]
+            shift = int(rng.integers(0, 4))
+            buf = torch.zeros(N + 8, dtype=torch.int32, device="cuda")
+            buf[shift:shift + N] = torch.from_numpy(q.view(np.int32)).cuda()
+            planar = srv.layout.packing == 2
+            for mode in (0, 1, 2, 3):
+                if mode == 3 and not planar:
+                    continue
+                cp.tuning_set("respond.ks_major", mode)
+                r = torch.full((C,), -1, dtype=torch.int32, device="cuda")
+                srv.respond_device(buf[shift:shift + N], r, stream=stream)
+                torch.cuda.synchronize()
+                assert np.array_equal(r.cpu().numpy().view(np.uint32), want), (trial, b, N, C, lo, hi, shift, mode)
+            cp.tuning_set("respond.ks_major", 1)
+            assert np.array_equal(srv.respond_array(q), want), (trial, "host")
+            srv.close()
+    finally:
+        cp.tuning_set("respond.ks_major", 1)
