@@ -198,3 +198,28 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h", "Makefile")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "chalamet_oracle" not in text and "from oracle" not in text and "import oracle" not in text, os.path.join(dirpath, f)
+
+
+def test_every_documented_tuning_key_is_accepted_and_bounded():
+    """the keys include/chalamet_hip.h documents for cpir_tuning_set exist (host-side state: no GPU needed), reject values outside their
+    range, and every key the library accepts is documented in the header"""
+    import re
+
+    import chalametpir_amd as cp
+    from chalametpir_amd.errors import ChalametPIRError
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(ROOT, "include", "chalamet_hip.h")).read()
+    doc = header[header.index("Tuning knobs of the respond kernel"):header.index("int cpir_tuning_set")]
+    documented = set(re.findall(r'"((?:respond|matmul|layout)\.[a-z_]+)"', doc))
+    source = open(os.path.join(ROOT, "chalametpir_amd", "csrc", "respond.hip")).read()
+    accepted = set(re.findall(r'!strcmp\(key, "([a-z_.]+)"\)', source))
+    assert accepted == documented, (sorted(accepted - documented), sorted(documented - accepted))
+    defaults = {"respond.ks_major": 1, "respond.host_zero_copy": 1, "respond.host_fill_timeout_us": 20000, "respond.batch_fusion": 1,
+                "respond.interleave_passes": -1, "matmul.mfma": 1}
+    for key, value in defaults.items():
+        cp.tuning_set(key, value)
+    for key, bad in (("respond.ks_major", 4), ("respond.ks_major", -1), ("respond.host_fill_timeout_us", -5),
+                     ("respond.host_fill_timeout_us", 2_000_000), ("respond.no_such_key", 1)):
+        with pytest.raises(ChalametPIRError):
+            cp.tuning_set(key, bad)
