@@ -87,6 +87,9 @@ SIGNATURES = {
     "cpir_dtc_layout_for_packing": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(DtcLayout)]),
     "cpir_shard_unit": (C.c_uint64, [C.POINTER(DtcLayout)]),
     "cpir_op_transpose_compress": (C.c_int, [vp, u32p, C.c_uint64, C.POINTER(DtcLayout), u32p, u32p, vp]),
+    "cpir_packed_rhs_plane_bytes": (C.c_uint64, [C.POINTER(DtcLayout)]),
+    "cpir_op_transpose_compress_with_plane": (C.c_int, [vp, u32p, C.c_uint64, C.POINTER(DtcLayout), u32p, u32p, vp, vp]),
+    "cpir_op_mat_x_packed": (C.c_int, [vp, u32p, C.c_uint64, u32p, C.POINTER(DtcLayout), vp, u32p, C.c_uint64, C.c_uint64, C.c_int, vp]),
     "cpir_op_dtc_import": (C.c_int, [vp, u32p, C.POINTER(DtcLayout), u32p, vp]),
     "cpir_op_dtc_export": (C.c_int, [vp, u32p, C.POINTER(DtcLayout), u32p, vp]),
     "cpir_respond_scratch_words": (C.c_uint64, [C.POINTER(DtcLayout)]),

@@ -768,7 +768,18 @@ static int setup_from_host_matrix(Device* dev, PublicMatrixUpload& upA, const ui
   srv->setup_timings[2] = now_seconds() - t0;
   t0 = now_seconds();
   TRY_(hipMemsetAsync(flag.p, 0, 4, stream));
-  int st = launch_transpose_compress(dev, (const uint32_t*)D_dev.p, C, L, srv->dtc, (uint32_t*)flag.p, stream);
+  // The hint matmul takes its right-hand side from the packed image where it can (planar packing with at least one bit plane, entries
+  // below 2^b -- checked below): the low-byte operand pieces are the image's own, the pack kernel writes the high-byte pieces next to it
+  // in the same pass over D.  (Otherwise D is split into byte planes in a pass of its own, or multiplied on the VALU.)
+  const uint32_t* A_dev = upA.device_ptr();
+  DevBuf hi_plane, rowsum_ws;
+  const uint64_t hi_bytes = planar_hi_plane_bytes(L);
+  bool planar_rhs = mfma_matmul_enabled() && hi_bytes && mfma_planar_rhs_applicable(A_dev, N, L);
+  if (planar_rhs) {
+    TRY_(hipMalloc(&hi_plane.p, (size_t)hi_bytes));
+    TRY_(hipMalloc(&rowsum_ws.p, 4 * 128));
+  }
+  int st = launch_transpose_compress(dev, (const uint32_t*)D_dev.p, C, L, srv->dtc, (uint32_t*)flag.p, stream, hi_plane.p);
   if (st != CPIR_OK) return fail(st);
   uint32_t ored = 0;
   TRY_(hipMemcpyAsync(&ored, flag.p, 4, hipMemcpyDeviceToHost, stream));
@@ -779,11 +790,16 @@ static int setup_from_host_matrix(Device* dev, PublicMatrixUpload& upA, const ui
   const uint32_t rhs_bits = (ored >> 16) ? 32u : 16u;
   // The hint in row chunks, each launched as soon as its rows of A are on their way to HBM: hint rows [r, r + 128) need only
   // those rows of A, so all but the last chunk's matmul hides behind the sponge.
-  const uint32_t* A_dev = upA.device_ptr();
   const uint64_t chunk = 128;
-  // matrix-core path: D is turned into its operand form ONCE and every chunk multiplies against that
+  // the image holds the fields masked to b bits (matrix.rs:121), the hint wants D as it is (server.rs:61): the same thing only if no entry
+  // reaches 2^b
+  if (planar_rhs && (ored >> b) != 0) {
+    planar_rhs = false;
+    hi_plane.dispose_async(dev->ordinal);
+  }
+  // matrix-core path without a usable image: D is turned into its operand form ONCE and every chunk multiplies against that
   DevBuf rhs;
-  const bool mfma = mfma_matmul_enabled() && mfma_matmul_applicable(A_dev, N, N, C, rhs_bits);
+  const bool mfma = !planar_rhs && mfma_matmul_enabled() && mfma_matmul_applicable(A_dev, N, N, C, rhs_bits);
   if (mfma) {
     TRY_(hipMalloc(&rhs.p, (size_t)mfma_rhs_workspace_bytes(N, C, chunk)));
     st = launch_rhs_split(dev, (const uint32_t*)D_dev.p, C, N, C, rhs.p, stream);
@@ -797,7 +813,10 @@ static int setup_from_host_matrix(Device* dev, PublicMatrixUpload& upA, const ui
     if (st != CPIR_OK) return fail(st);
     t_last = now_seconds();
     t_wait += t_last - t0;
-    if (mfma) st = launch_mat_x_mat_mfma(dev, A_dev + r0 * N, N, rhs.p, N, C, (uint32_t*)M_dev.p + r0 * C, C, rb, chunk, 0, stream);
+    if (planar_rhs)
+      st = launch_mat_x_mat_mfma_planar(dev, A_dev + r0 * N, N, srv->dtc, L, hi_plane.p, (uint32_t*)rowsum_ws.p, (uint32_t*)M_dev.p + r0 * C, C, rb,
+                                        0, stream);
+    else if (mfma) st = launch_mat_x_mat_mfma(dev, A_dev + r0 * N, N, rhs.p, N, C, (uint32_t*)M_dev.p + r0 * C, C, rb, chunk, 0, stream);
     else st = launch_mat_x_mat(dev, A_dev + r0 * N, N, (const uint32_t*)D_dev.p, C, (uint32_t*)M_dev.p + r0 * C, C, rb, N, C, rhs_bits, 0, stream);
     if (st != CPIR_OK) return fail(st);
   }
@@ -812,6 +831,7 @@ static int setup_from_host_matrix(Device* dev, PublicMatrixUpload& upA, const ui
 #undef TRY_
   D_dev.dispose_async(dev->ordinal);  // 4*N*C bytes
   rhs.dispose_async(dev->ordinal);
+  hi_plane.dispose_async(dev->ordinal);
   *out = srv;
   return CPIR_OK;
 }
@@ -1097,6 +1117,35 @@ int cpir_op_transpose_compress(cpir_device* dev, const uint32_t* D, uint64_t ldd
   if (!dev || !layout) return CPIR_ERR_INVALID_ARGUMENT;
   DeviceGuard g(dev->ordinal);
   return launch_transpose_compress(dev, D, ldd, *layout, dtc, or_of_entries, pick_stream(dev, stream));
+}
+
+uint64_t cpir_packed_rhs_plane_bytes(const cpir_dtc_layout* layout) {
+  if (!layout || check_layout(*layout) != CPIR_OK) return 0;
+  return planar_hi_plane_bytes(*layout);
+}
+
+int cpir_op_transpose_compress_with_plane(cpir_device* dev, const uint32_t* D, uint64_t ldd, const cpir_dtc_layout* layout, uint32_t* dtc,
+                                          uint32_t* or_of_entries, void* hi_plane, void* stream) {
+  if (!dev || !layout) return CPIR_ERR_INVALID_ARGUMENT;
+  if (hi_plane && planar_hi_plane_bytes(*layout) == 0) return CPIR_ERR_INVALID_ARGUMENT;
+  DeviceGuard g(dev->ordinal);
+  return launch_transpose_compress(dev, D, ldd, *layout, dtc, or_of_entries, pick_stream(dev, stream), hi_plane);
+}
+
+int cpir_op_mat_x_packed(cpir_device* dev, const uint32_t* A, uint64_t lda, const uint32_t* dtc, const cpir_dtc_layout* layout,
+                         const void* hi_plane, uint32_t* M, uint64_t ldm, uint64_t rows, int accumulate, void* stream) {
+  if (!dev || !layout || !A || !dtc || !hi_plane || !M || rows == 0) return CPIR_ERR_INVALID_ARGUMENT;
+  CPIR_TRY(check_layout(*layout));
+  if (!mfma_matmul_enabled() || !mfma_planar_rhs_applicable(A, lda, *layout)) return CPIR_ERR_INVALID_ARGUMENT;
+  DeviceGuard g(dev->ordinal);
+  hipStream_t s = pick_stream(dev, stream);
+  void* rowsum = nullptr;  // stream-ordered scratch: the row sums of A (a correction term of the signed-byte split)
+  CPIR_HIP_TRY(hipMallocAsync(&rowsum, 4 * ((rows + 127) / 128 * 128), s));
+  const int st = launch_mat_x_mat_mfma_planar(dev, A, lda, dtc, *layout, hi_plane, static_cast<uint32_t*>(rowsum), M, ldm, rows, accumulate, s);
+  const hipError_t e = hipFreeAsync(rowsum, s);
+  if (st != CPIR_OK) return st;
+  CPIR_HIP_TRY(e);
+  return CPIR_OK;
 }
 
 int cpir_op_dtc_import(cpir_device* dev, const uint32_t* compressed, const cpir_dtc_layout* layout, uint32_t* dtc, void* stream) {

@@ -101,7 +101,11 @@ uint64_t respond_multi_pass_limit_bytes();
 
 // pack.hip
 int launch_transpose_compress(const Device* dev, const uint32_t* D, uint64_t ldd, const cpir_dtc_layout& L, uint32_t* dtc,
-                              uint32_t* or_of_entries, hipStream_t stream);
+                              uint32_t* or_of_entries, hipStream_t stream, void* hi_plane = nullptr);
+// planar packing: hi_plane (planar_hi_plane_bytes(L) bytes, 16-byte aligned; 0 bytes for b <= 8) also receives the byte (field >> 8) XOR
+// 0x80 of every field as 1 KiB MFMA operand pieces [column tile of 16][k-block of 64 slots] -- with the low-byte pieces of the image
+// itself the right-hand side of the hint matmul, so that Server::setup reads D once (launch_mat_x_mat_mfma_planar)
+uint64_t planar_hi_plane_bytes(const cpir_dtc_layout& L);
 int launch_dtc_import(const Device* dev, const uint32_t* compressed, const cpir_dtc_layout& L, uint32_t* dtc, hipStream_t stream);
 int launch_dtc_export(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, uint32_t* compressed, hipStream_t stream);
 
@@ -115,6 +119,12 @@ const char* mat_x_mat_kernel_name(uint32_t rhs_max_bits);
 // side is prepared ONCE (launch_rhs_split: byte planes in MFMA operand order + column sums, into a caller-owned workspace of
 // mfma_rhs_workspace_bytes) and then multiplied by any number of row blocks of A of at most `max_rows` rows each.
 bool mfma_matmul_applicable(const uint32_t* A, uint64_t lda, uint64_t inner, uint64_t cols, uint32_t rhs_max_bits);
+// The same product with the right-hand side taken from a PLANAR respond image of D (entries < 2^b, b >= 9) and the high-byte plane
+// launch_transpose_compress wrote next to it: no separate pass over D.  rowsum_ws: 4 * round_up(rows, 128) bytes of device scratch.
+bool mfma_planar_rhs_applicable(const uint32_t* A, uint64_t lda, const cpir_dtc_layout& L);
+int launch_mat_x_mat_mfma_planar(const Device* dev, const uint32_t* A, uint64_t lda, const uint32_t* dtc, const cpir_dtc_layout& L,
+                                 const void* hi_plane, uint32_t* rowsum_ws, uint32_t* M, uint64_t ldm, uint64_t rows, int accumulate,
+                                 hipStream_t stream);
 uint64_t mfma_rhs_workspace_bytes(uint64_t inner, uint64_t cols, uint64_t max_rows);
 int launch_rhs_split(const Device* dev, const uint32_t* D, uint64_t ldd, uint64_t inner, uint64_t cols, void* workspace, hipStream_t stream);
 int launch_mat_x_mat_mfma(const Device* dev, const uint32_t* A, uint64_t lda, const void* workspace, uint64_t inner, uint64_t cols,

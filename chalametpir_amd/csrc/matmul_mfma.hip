@@ -147,6 +147,16 @@ struct MfmaArgs {
   uint32_t S;           // K sub-ranges per XCD range
   uint32_t nx;          // K axis split by blockIdx % nx (8, or 1 for tiny grids)
   uint32_t ablate;      // diagnosis only (results are garbage): 1 no MFMA, 2 no A conversion / LDS writes, 4 no A loads, 8 no D DMA
+  // Right-hand side straight from a planar respond image (pipelined kernel only; `planes` is NULL then): the low-byte operand pieces ARE
+  // the first 8 KiB of every super-tile of the image ([column tile][step of 512 slots][(8 + HB) KiB]), the high-byte pieces come from the
+  // plane pack.hip writes next to it ([column tile][k-block of 64][1 KiB]).  Slots and columns past the end hold field 0 there (bytes
+  // 0x80, not 0x00 as in `planes`), so the kernel feeds A = 0x80808080 (all limbs zero) for k >= inner.
+  const uint4* lo_tiles;
+  const uint4* hi_plane;
+  uint32_t lo_st16;      // uint4 per super-tile: (8 + HB) * 64
+  uint32_t lo_ks512;     // super-tile steps per column tile
+  uint32_t b_col_tiles;  // column tiles of 16 present in the image and the plane
+  uint32_t kb_total;     // k-blocks per column tile in hi_plane
 };
 
 __global__ void __launch_bounds__(kMT) __attribute__((amdgpu_waves_per_eu(2, 2))) mat_x_mat_mfma_kernel(const MfmaArgs a) {
@@ -355,7 +365,8 @@ struct PipeLane {  // per-lane constants of the A staging roles (as in the kerne
 
 struct PipeUnit {  // per-unit state of one wave
   const uint32_t* a_base;   // first row of the block's row tile (wave-uniform)
-  const uint4* b_base;      // this wave's column tile of 16 in the planes, k-step 0 (wave-uniform)
+  const uint4* b_base;      // this wave's column tile of 16 in the planes, k-step 0 (wave-uniform); planar: its low-byte pieces in the image
+  const uint4* h_base;      // planar: its pieces in the high-byte plane
   uint32_t a_off[4];        // byte offset of this lane's row inside the row tile (rows past the end re-read the last row)
   bool rvalid[4];
   uint32_t rs[4];           // row sums of A (only kept by blocks with column tile 0)
@@ -376,11 +387,14 @@ __device__ __forceinline__ void pipe_load_quad(const MfmaArgs& a, const PipeLane
 
 // request this wave's two 1 KiB pieces of D(ks) into stage `st` of the LDS ring (LDS-DMA: the destination is M0 + lane * 16); returns the
 // value of `issued` after the request
+template <bool PLANAR>
 __device__ __forceinline__ uint32_t pipe_dma_b(const MfmaArgs& a, PipeUnit& u, uint32_t lds_b0, uint32_t lane, uint32_t wave, uint32_t ks, uint32_t st) {
-  const uint4* const base = uniform_ptr(u.b_base);
+  constexpr bool planar = PLANAR;
 #pragma unroll
   for (int e = 0; e < 2; e++) {
-    const uint32_t off = (ks * 2u + (uint32_t)e) * 1024u + lane * 16u;
+    const uint4* const base = uniform_ptr(planar && e ? u.h_base : u.b_base);
+    const uint32_t piece = planar ? (e ? ks * 64u : (ks >> 3) * a.lo_st16 + (ks & 7u) * 64u) : (ks * 2u + (uint32_t)e) * 64u;  // in uint4
+    const uint32_t off = piece * 16u + lane * 16u;
     const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_b0 + ((st * kPiecesB + wave * 2 + (uint32_t)e) * 1024u));
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
@@ -408,9 +422,11 @@ __device__ __forceinline__ void byte_limbs(uint32_t x, uint32_t y, uint32_t z, u
 __device__ __forceinline__ void pipe_store_quad(const MfmaArgs& a, const PipeLane& pl, PipeUnit& u, uint4* lds, const v4i& reg, int j, uint32_t k,
                                                 uint32_t ks_abs) {
   uint32_t* base = reinterpret_cast<uint32_t*>(lds + (k & 1) * kPiecesA * 64);
-  const uint32_t x = (uint32_t)reg[0], y = (uint32_t)reg[1], z = (uint32_t)reg[2], w = (uint32_t)reg[3];
+  const bool k_in = (uint64_t)ks_abs * kBK + pl.kq[j] < a.inner;  // past the end of the rows: all limbs zero, whatever was read
+  const uint32_t x = k_in ? (uint32_t)reg[0] : 0x80808080u, y = k_in ? (uint32_t)reg[1] : 0x80808080u;
+  const uint32_t z = k_in ? (uint32_t)reg[2] : 0x80808080u, w = k_in ? (uint32_t)reg[3] : 0x80808080u;
   if (u.sum_rows) {
-    const bool in = u.rvalid[j] && (uint64_t)ks_abs * kBK + pl.kq[j] < a.inner;
+    const bool in = u.rvalid[j] && k_in;
     u.rs[j] += in ? x + y + z + w : 0u;
   }
   uint32_t limb[4];
@@ -471,7 +487,7 @@ __device__ __forceinline__ void mfma_group_with_conversion(v4i (&acc)[2][4], con
 }
 
 // One (row tile, column tile, K sub-range) unit for one wave.  Register set S0 carries the even k-steps (relative to k0), S1 the odd ones.
-template <bool SUM>
+template <bool SUM, bool PLANAR>
 __device__ __forceinline__ void mfma_pipe_unit(const MfmaArgs& a, const PipeLane& pl, PipeUnit& u, uint4* lds, uint32_t lds_b0, uint32_t lane,
                                                uint32_t wave, uint32_t k0, uint32_t T, v4i (&acc)[4][2][4]) {
   const uint32_t wm = wave >> 2, wn = wave & 3;
@@ -479,12 +495,12 @@ __device__ __forceinline__ void mfma_pipe_unit(const MfmaArgs& a, const PipeLane
   // ---- prologue: the first two k-steps are requested, A(0) is converted, A(2) requested behind it ----
 #pragma unroll
   for (int j = 0; j < 4; j++) pipe_load_quad(a, pl, u, S0[j], j, k0);
-  const uint32_t bm0 = pipe_dma_b(a, u, lds_b0, lane, wave, k0, 0);
+  const uint32_t bm0 = pipe_dma_b<PLANAR>(a, u, lds_b0, lane, wave, k0, 0);
   uint32_t bm_next = 0;  // `issued` after the request for the D stage of the NEXT k-step
   if (T > 1) {
 #pragma unroll
     for (int j = 0; j < 4; j++) pipe_load_quad(a, pl, u, S1[j], j, k0 + 1);
-    bm_next = pipe_dma_b(a, u, lds_b0, lane, wave, k0 + 1, 1);
+    bm_next = pipe_dma_b<PLANAR>(a, u, lds_b0, lane, wave, k0 + 1, 1);
   }
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(S0[0]), "+v"(S0[1]), "+v"(S0[2]), "+v"(S0[3])::"memory");
   (void)bm0;
@@ -502,11 +518,16 @@ __device__ __forceinline__ void mfma_pipe_unit(const MfmaArgs& a, const PipeLane
   // quad by quad with A(t + 3)) interleaved behind the four MFMA groups
   auto step = [&](uint32_t t, v4i(&set)[4], uint32_t& mark) {
     uint32_t bm_new = 0;
-    if (t + 2 < T) bm_new = pipe_dma_b(a, u, lds_b0, lane, wave, k0 + t + 2, (t + 2) % kStagesB);
+    if (t + 2 < T) bm_new = pipe_dma_b<PLANAR>(a, u, lds_b0, lane, wave, k0 + t + 2, (t + 2) % kStagesB);
     const bool conv = t + 1 < T;
     if (conv) {
       wait_vm_at_most<8>(u.issued - mark);
       asm volatile("" : "+v"(set[0]), "+v"(set[1]), "+v"(set[2]), "+v"(set[3])::"memory");
+      if ((uint64_t)(k0 + t + 2) * kBK > a.inner) {  // A(t + 1) reaches past the end of the rows: those quads become all-zero limbs
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+          if ((uint64_t)(k0 + t + 1) * kBK + pl.kq[m] >= a.inner) set[m] = v4i{(int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u};
+      }
     }
     const uint4* A_ = lds + (t & 1) * kPiecesA * 64;
     const uint4* B_ = lds + (2 * kPiecesA + (t % kStagesB) * kPiecesB) * 64;
@@ -544,7 +565,13 @@ __device__ __forceinline__ void mfma_pipe_unit(const MfmaArgs& a, const PipeLane
   const uint32_t Ts = T_safe > 3 ? ((T_safe - 3) & ~1u) : 0;      // steady steps (an even number: two per loop trip)
   if (Ts) {
     const uint32_t* a_run = uniform_ptr(u.a_base + (uint64_t)(k0 + 3) * kBK);      // A(t + 3), advanced by one k-step per step
-    const uint4* b_run = uniform_ptr(u.b_base + (uint64_t)(k0 + 2) * 128);         // D(t + 2)
+    // D(t + 2): the two pieces of that k-step.  Byte planes: 2 KiB per k-step, side by side.  Planar image: the low-byte piece advances
+    // 1 KiB per k-step inside a super-tile and skips the bit planes when it crosses into the next one; the high-byte piece 1 KiB per k-step.
+    // (planar: both addresses are recomputed from the k-step every time -- a handful of scalar operations -- rather than carried along:
+    // the kernel has no scalar registers to spare)
+    uint32_t ks_dma = k0 + 2;
+    const uint4* b_run = PLANAR ? nullptr : uniform_ptr(u.b_base + (uint64_t)ks_dma * 128);
+    const uint32_t lo_st16 = PLANAR ? (uint32_t)__builtin_amdgcn_readfirstlane(a.lo_st16) : 0u;
     uint32_t aoffq[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) aoffq[j] = u.a_off[j] + pl.kq[j] * 4u;
@@ -571,11 +598,23 @@ __device__ __forceinline__ void mfma_pipe_unit(const MfmaArgs& a, const PipeLane
       {
         const uint32_t dst = __builtin_amdgcn_readfirstlane(dma_dst0 + st_dma * (kPiecesB * 1024u));
         uint32_t keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %1, %3 offset:1024\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(dma_voff), "s"(dst), "s"(b_run)
-                     : "memory");
-        b_run += 128;
+        // (the second piece lands 1 KiB behind the first: M0 + 1024, and the immediate offset moves source and destination alike, so its
+        // base is passed 1 KiB early)
+        if constexpr (PLANAR) {
+          const uint4* const lo = uniform_ptr(u.b_base + ((ks_dma >> 3) * lo_st16 + (ks_dma & 7u) * 64u));
+          const uint4* const hi_early = uniform_ptr(u.h_base + ks_dma * 64u - 64);
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %1, %4 offset:1024\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep)
+                       : "v"(dma_voff), "s"(dst), "s"(lo), "s"(hi_early)
+                       : "memory");
+          ks_dma++;
+        } else {
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %1, %3 offset:1024\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep)
+                       : "v"(dma_voff), "s"(dst), "s"(b_run)
+                       : "memory");
+          b_run += 128;
+        }
       }
       asm volatile("s_waitcnt vmcnt(8)" : "+v"(set[0]), "+v"(set[1]), "+v"(set[2]), "+v"(set[3])::"memory");
 #pragma unroll
@@ -616,6 +655,7 @@ __device__ __forceinline__ void mfma_pipe_unit(const MfmaArgs& a, const PipeLane
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+template <bool PLANAR>
 __global__ void __launch_bounds__(kMT) __attribute__((amdgpu_waves_per_eu(2, 2))) mat_x_mat_mfma_pipe_kernel(const MfmaArgs a) {
   __shared__ uint4 lds[kPipePieces * 64];
 
@@ -648,7 +688,14 @@ __global__ void __launch_bounds__(kMT) __attribute__((amdgpu_waves_per_eu(2, 2))
 
     PipeUnit u;
     u.a_base = uniform_ptr(a.A + (uint64_t)rt * kBM * a.lda);
-    u.b_base = uniform_ptr(a.planes + (uint64_t)(ct * 8 + wave) * a.KS * 128);  // 2 pieces of 64 uint4 per k-step
+    if constexpr (PLANAR) {  // (column tiles past the image's last one are computed from its last tile and never stored)
+      const uint32_t T16 = ct * 8 + wave < a.b_col_tiles ? ct * 8 + wave : a.b_col_tiles - 1;
+      u.b_base = uniform_ptr(a.lo_tiles + (uint64_t)T16 * a.lo_ks512 * a.lo_st16);
+      u.h_base = uniform_ptr(a.hi_plane + (uint64_t)T16 * a.kb_total * 64);
+    } else {
+      u.b_base = uniform_ptr(a.planes + (uint64_t)(ct * 8 + wave) * a.KS * 128);  // 2 pieces of 64 uint4 per k-step
+      u.h_base = u.b_base;
+    }
     u.sum_rows = (ct == 0);
     u.issued = 0;
 #pragma unroll
@@ -668,8 +715,8 @@ __global__ void __launch_bounds__(kMT) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
         for (int s2 = 0; s2 < 4; s2++) acc[m][n][s2] = v4i{0, 0, 0, 0};
 
-    if (u.sum_rows) mfma_pipe_unit<true>(a, pl, u, lds, lds_b0, lane, wave, k0, k1 - k0, acc);
-    else mfma_pipe_unit<false>(a, pl, u, lds, lds_b0, lane, wave, k0, k1 - k0, acc);
+    if (u.sum_rows) mfma_pipe_unit<true, PLANAR>(a, pl, u, lds, lds_b0, lane, wave, k0, k1 - k0, acc);
+    else mfma_pipe_unit<false, PLANAR>(a, pl, u, lds, lds_b0, lane, wave, k0, k1 - k0, acc);
 
     // ---- this unit's part of the output tile: sum_s acc_s << 8s, one u32 atomic per element ----
     const uint32_t fr = lane & 15, fq = lane >> 4;
@@ -753,6 +800,9 @@ int launch_rhs_split(const Device* dev, const uint32_t* D, uint64_t ldd, uint64_
   return CPIR_OK;
 }
 
+// the product + the correction terms, the right-hand side described by a.planes or a.lo_tiles / a.hi_plane (already filled in)
+static int launch_product(const Device* dev, MfmaArgs& a, const uint32_t* colsum, int accumulate, hipStream_t stream);
+
 int launch_mat_x_mat_mfma(const Device* dev, const uint32_t* A, uint64_t lda, const void* workspace, uint64_t inner, uint64_t cols,
                           uint32_t* M, uint64_t ldm, uint64_t rows, uint64_t ws_max_rows, int accumulate, hipStream_t stream) {
   if (!A || !workspace || !M || rows == 0 || rows > ws_max_rows || lda < inner || ldm < cols) return CPIR_ERR_INVALID_ARGUMENT;
@@ -760,8 +810,42 @@ int launch_mat_x_mat_mfma(const Device* dev, const uint32_t* A, uint64_t lda, co
   MfmaArgs a;
   a.A = A, a.lda = lda, a.M = M, a.ldm = ldm, a.rows = rows, a.inner = inner, a.cols = cols;
   a.planes = reinterpret_cast<const uint4*>(ws);
+  a.lo_tiles = nullptr, a.hi_plane = nullptr, a.lo_st16 = 0, a.lo_ks512 = 0, a.b_col_tiles = 0, a.kb_total = 0;
   const uint32_t* colsum = reinterpret_cast<const uint32_t*>(ws + rhs_planes_bytes(inner, cols));
   a.rowsum = const_cast<uint32_t*>(colsum) + rhs_colsum_words(cols);
+  return launch_product(dev, a, colsum, accumulate, stream);
+}
+
+bool mfma_planar_rhs_applicable(const uint32_t* A, uint64_t lda, const cpir_dtc_layout& L) {
+  // the image must hold at least one bit plane (b >= 9; below that the high-byte plane does not exist), the hand-pipelined kernel must
+  // be on and able to address everything with 32-bit byte offsets
+  const uint64_t ks512 = (L.num_slots + CPIR_PLANAR_SLOTS_PER_TILE - 1) / CPIR_PLANAR_SLOTS_PER_TILE;
+  return L.packing == CPIR_PACK_PLANAR && L.mat_elem_bit_len >= 9 && mfma_pipeline() != 0 &&
+         mfma_matmul_applicable(A, lda, L.num_slots, L.num_cols, 16) && ks512 * (L.chunk_words / 4) * 16 + (1u << 20) < (1ull << 32);
+}
+
+int launch_mat_x_mat_mfma_planar(const Device* dev, const uint32_t* A, uint64_t lda, const uint32_t* dtc, const cpir_dtc_layout& L,
+                                 const void* hi_plane, uint32_t* rowsum_ws, uint32_t* M, uint64_t ldm, uint64_t rows, int accumulate,
+                                 hipStream_t stream) {
+  if (!A || !dtc || !hi_plane || !rowsum_ws || !M || rows == 0 || lda < L.num_slots || ldm < L.num_cols) return CPIR_ERR_INVALID_ARGUMENT;
+  if (!mfma_planar_rhs_applicable(A, lda, L)) return CPIR_ERR_INVALID_ARGUMENT;
+  MfmaArgs a;
+  a.A = A, a.lda = lda, a.M = M, a.ldm = ldm, a.rows = rows, a.inner = L.num_slots, a.cols = L.num_cols;
+  a.planes = nullptr;
+  a.lo_tiles = reinterpret_cast<const uint4*>(dtc);
+  a.hi_plane = reinterpret_cast<const uint4*>(hi_plane);
+  a.lo_st16 = L.chunk_words / 4;  // chunk_words = (8 + HB) * 256 u32 per super-tile
+  a.lo_ks512 = (uint32_t)((L.num_slots + CPIR_PLANAR_SLOTS_PER_TILE - 1) / CPIR_PLANAR_SLOTS_PER_TILE);
+  a.b_col_tiles = L.rows_padded / 16;
+  a.kb_total = (uint32_t)((L.num_slots + 63) / 64);
+  a.rowsum = rowsum_ws;
+  const uint32_t* colsum = dtc + (uint64_t)L.rows_padded * L.words_per_row_padded;  // per-column field sums behind the tiles
+  return launch_product(dev, a, colsum, accumulate, stream);
+}
+
+static int launch_product(const Device* dev, MfmaArgs& a, const uint32_t* colsum, int accumulate, hipStream_t stream) {
+  const uint64_t rows = a.rows, cols = a.cols, inner = a.inner, lda = a.lda, ldm = a.ldm;
+  uint32_t* const M = a.M;
   a.RT = (uint32_t)((rows + kBM - 1) / kBM), a.CT = (uint32_t)((cols + kBN - 1) / kBN), a.KS = (uint32_t)((inner + kBK - 1) / kBK);
   // persistent grid, one block per CU (96 KiB of LDS and 2 waves per SIMD each)
   uint32_t grid = (uint32_t)dev->num_cus;
@@ -784,7 +868,9 @@ int launch_mat_x_mat_mfma(const Device* dev, const uint32_t* A, uint64_t lda, co
   if (!accumulate) CPIR_HIP_TRY(hipMemset2DAsync(M, ldm * sizeof(uint32_t), 0, cols * sizeof(uint32_t), rows, stream));
   // the hand-pipelined kernel addresses a row tile of A with 32-bit byte offsets
   const bool pipe = mfma_pipeline() != 0 && ((uint64_t)(kBM - 1) * lda + inner) * 4 < (1ull << 32) && (uint64_t)a.KS * 2048 + 2048 < (1ull << 32);
-  if (pipe) hipLaunchKernelGGL(mat_x_mat_mfma_pipe_kernel, dim3(grid), dim3(kMT), 0, stream, a);
+  if (!pipe && a.lo_tiles) return CPIR_ERR_INVALID_ARGUMENT;  // only the pipelined kernel reads the planar image
+  if (pipe && a.lo_tiles) hipLaunchKernelGGL(mat_x_mat_mfma_pipe_kernel<true>, dim3(grid), dim3(kMT), 0, stream, a);
+  else if (pipe) hipLaunchKernelGGL(mat_x_mat_mfma_pipe_kernel<false>, dim3(grid), dim3(kMT), 0, stream, a);
   else hipLaunchKernelGGL(mat_x_mat_mfma_kernel, dim3(grid), dim3(kMT), 0, stream, a);
   const uint32_t k_term = (uint32_t)inner * (0x80808080u * 0x8080u);
   uint64_t fb = (rows * cols + kThreads - 1) / kThreads;

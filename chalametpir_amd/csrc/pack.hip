@@ -353,6 +353,11 @@ struct PackStreamArgs {
   uint4* tiles;
   uint32_t* colsum;
   uint32_t* or_of_entries;
+  // optional: the byte (field >> 8) XOR 0x80 of every field as a plane of 1 KiB MFMA operand pieces [column tile][k-block of 64 slots],
+  // laid out like the low-byte pieces inside the tiles -- the second operand plane of the hint matmul (matmul_mfma.hip), whose first
+  // plane ARE the low-byte pieces of the image; written in the same pass so that D is read once for both products
+  uint4* hi_plane;
+  uint32_t kb_total;  // k-blocks of 64 slots in the plane: ceil(N / 64)
 };
 
 // GUARD: this step reaches past the last slot (only the last step of a database whose N is not a multiple of 512)
@@ -409,11 +414,12 @@ __device__ __forceinline__ void pack_stream_unit(const PackStreamArgs& a, uint4*
     }
     seen |= seen_kb;
     asm volatile("" : "+v"(seen));  // materialise here: otherwise the OR tree over all 8 k-blocks is built at the end and every value lives until then
-    uint32_t W[4][4];
+    uint32_t W[4][4], WH[4][4];
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
       for (int d = 0; d < 4; d++) {
+        WH[i][d] = 0x80808080u;
         const uint32_t lo = gather_byte4(v[4 * d][i], v[4 * d + 1][i], v[4 * d + 2][i], v[4 * d + 3][i], 0x0400u) & a.low_mask;
         lowsum[i] = __builtin_amdgcn_sad_u8(lo, 0u, lowsum[i]);
         W[i][d] = lo ^ 0x80808080u;  // signed-byte operand
@@ -423,6 +429,7 @@ __device__ __forceinline__ void pack_stream_unit(const PackStreamArgs& a, uint4*
           const uint32_t hi = gather_byte4(v[4 * d][i], v[4 * d + 1][i], v[4 * d + 2][i], v[4 * d + 3][i], 0x0501u) & HMASK;
 #pragma unroll
           for (int p = 0; p < HB; p++) plane[i][p][kb >> 1] |= ((hi >> p) & 0x01010101u) << (4 * (kb & 1) + d);
+          WH[i][d] = hi ^ 0x80808080u;
         }
       }
     // materialise the accumulators now (as `seen` above): the compiler would otherwise sink this k-block's plane arithmetic to where the
@@ -444,6 +451,19 @@ __device__ __forceinline__ void pack_stream_unit(const PackStreamArgs& a, uint4*
       if (T < a.col_tiles) a.tiles[((uint64_t)T * a.ks_total + ks) * ST16 + kb * 64 + lane] = x;
     }
     __builtin_amdgcn_wave_barrier();
+    if (HB > 0 && a.hi_plane) {  // wave-uniform: the same four pieces of the high-byte plane, through the same window
+      const uint32_t kbg = ks * 8 + kb;
+#pragma unroll
+      for (int i = 0; i < 4; i++) my_stage[stage_swz(piece0 + i)] = make_uint4(WH[i][0], WH[i][1], WH[i][2], WH[i][3]);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint4 x = my_stage[stage_swz(64 * k + lane)];
+        const uint32_t T = stripe * 4 + k;
+        if (T < a.col_tiles && kbg < a.kb_total) a.hi_plane[((uint64_t)T * a.kb_total + kbg) * 64 + lane] = x;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
     // one k-block's 16 loads per lane in flight at a time (16 KiB per wave); the other waves of the SIMD hide the latency
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -520,13 +540,14 @@ __global__ void __launch_bounds__(kThreads) planar_export_kernel(const uint8_t* 
 }
 
 int launch_planar_pack(const uint32_t* src, uint64_t ld, bool from_ref, const cpir_dtc_layout& L, uint32_t* dtc, uint32_t* or_of_entries,
-                       hipStream_t stream) {
+                       hipStream_t stream, uint4* hi_plane = nullptr) {
   const uint32_t hb = planar_hi_planes(L.mat_elem_bit_len);
   const uint64_t ks_total = (L.num_slots + CPIR_PLANAR_SLOTS_PER_TILE - 1) / CPIR_PLANAR_SLOTS_PER_TILE;
   const uint32_t col_tiles = L.rows_padded / 16;
   if (!planar_offered(L.mat_elem_bit_len) || ks_total > 0x7fffffffull || col_tiles > 65535u) return CPIR_ERR_INVALID_ARGUMENT;
   uint32_t* colsum = dtc + (uint64_t)L.rows_padded * L.words_per_row_padded;
   CPIR_HIP_TRY(hipMemsetAsync(colsum, 0, (size_t)L.rows_padded * sizeof(uint32_t), stream));
+  if (from_ref && hi_plane) return CPIR_ERR_INVALID_ARGUMENT;
   if (from_ref) {
     const dim3 grid((unsigned)ks_total, col_tiles);
     hipLaunchKernelGGL((planar_pack_kernel<true>), grid, dim3(kThreads), 0, stream, src, ld, L.num_slots, L.num_cols, L.mat_elem_bit_len,
@@ -542,6 +563,8 @@ int launch_planar_pack(const uint32_t* src, uint64_t ld, bool from_ref, const cp
   pa.D = src, pa.ld = ld, pa.N = L.num_slots, pa.C = L.num_cols, pa.col_tiles = col_tiles, pa.stripe_groups = stripe_groups;
   pa.ks_total = (uint32_t)ks_total, pa.tiles = reinterpret_cast<uint4*>(dtc), pa.colsum = colsum, pa.or_of_entries = or_of_entries;
   pa.low_mask = L.mat_elem_bit_len < 8 ? ((1u << L.mat_elem_bit_len) - 1u) * 0x01010101u : 0xFFFFFFFFu;
+  pa.hi_plane = hb ? hi_plane : nullptr;
+  pa.kb_total = (uint32_t)((L.num_slots + 63) / 64);
 #define LAUNCH_PP2(HB_, VEC_)                                                                                                       \
   do {                                                                                                                              \
     if (full_steps)                                                                                                                 \
@@ -581,13 +604,19 @@ uint32_t grid_for(const Device* dev, uint64_t total) {
 
 }  // namespace
 
+uint64_t planar_hi_plane_bytes(const cpir_dtc_layout& L) {
+  if (L.packing != CPIR_PACK_PLANAR || planar_hi_planes(L.mat_elem_bit_len) == 0) return 0;
+  return (uint64_t)(L.rows_padded / 16) * ((L.num_slots + 63) / 64) * 1024;
+}
+
 int launch_transpose_compress(const Device* dev, const uint32_t* D, uint64_t ldd, const cpir_dtc_layout& L, uint32_t* dtc,
-                              uint32_t* or_of_entries, hipStream_t stream) {
+                              uint32_t* or_of_entries, hipStream_t stream, void* hi_plane) {
   (void)dev;
   if (!D || !dtc || ldd < L.num_cols) return CPIR_ERR_INVALID_ARGUMENT;
   CPIR_TRY(check_layout(L));
   if (reinterpret_cast<uintptr_t>(dtc) % 16 != 0) return CPIR_ERR_INVALID_ARGUMENT;
-  if (L.packing == CPIR_PACK_PLANAR) return launch_planar_pack(D, ldd, false, L, dtc, or_of_entries, stream);
+  if (hi_plane && (L.packing != CPIR_PACK_PLANAR || reinterpret_cast<uintptr_t>(hi_plane) % 16 != 0)) return CPIR_ERR_INVALID_ARGUMENT;
+  if (L.packing == CPIR_PACK_PLANAR) return launch_planar_pack(D, ldd, false, L, dtc, or_of_entries, stream, reinterpret_cast<uint4*>(hi_plane));
   if (L.packing == CPIR_PACK_DENSE64) {
     const uint64_t chunks = L.words_per_row_padded / L.chunk_words;
     if (chunks * 16 > 0x7fffffffull) return CPIR_ERR_INVALID_ARGUMENT;

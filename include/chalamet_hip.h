@@ -203,6 +203,20 @@ int cpir_dtc_layout_for_packing(uint64_t num_slots, uint32_t num_cols, uint32_t 
 int cpir_op_transpose_compress(cpir_device* dev, const uint32_t* D, uint64_t ldd, const cpir_dtc_layout* layout,
                                uint32_t* dtc, uint32_t* or_of_entries, void* stream);
 
+/* The packed image as the right-hand side of the hint product (server.rs:61 + 64-67 with ONE pass over D): for the planar packing with
+ * b >= 9 the image's low-byte operand pieces are also the first operand plane of the matrix-core matmul (csrc/matmul_mfma.hip); the
+ * second plane -- the byte (field >> 8) XOR 0x80 of every field, cpir_packed_rhs_plane_bytes(layout) bytes, 0 where the pairing is not
+ * offered -- is written by the same pass when `hi_plane` (device, 16-byte aligned) is given.  Otherwise as cpir_op_transpose_compress. */
+uint64_t cpir_packed_rhs_plane_bytes(const cpir_dtc_layout* layout);
+int cpir_op_transpose_compress_with_plane(cpir_device* dev, const uint32_t* D, uint64_t ldd, const cpir_dtc_layout* layout,
+                                          uint32_t* dtc, uint32_t* or_of_entries, void* hi_plane, void* stream);
+/* M (rows x layout->num_cols, leading dim ldm) (+)= A (rows x layout->num_slots, leading dim lda, 16-byte aligned, lda and num_slots
+ * multiples of 4) * D, with D given as its packed image `dtc` and the plane written by cpir_op_transpose_compress_with_plane.  Equal to
+ * cpir_op_mat_x_mat on the unpacked D whenever every entry of D is below 2^b (the image holds the entries masked to b bits, matrix.rs:121;
+ * the OR of the entries from the packing pass proves it).  CPIR_ERR_INVALID_ARGUMENT where the pairing is not offered. */
+int cpir_op_mat_x_packed(cpir_device* dev, const uint32_t* A, uint64_t lda, const uint32_t* dtc, const cpir_dtc_layout* layout,
+                         const void* hi_plane, uint32_t* M, uint64_t ldm, uint64_t rows, int accumulate, void* stream);
+
 /* Inverse direction for import/export of the reference's own compressed matrix (C x W, row-major, as held in
  * Server.compressed_transposed_parsed_db_mat_d, server.rs:18): pad/normalise into the device layout, and strip. */
 int cpir_op_dtc_import(cpir_device* dev, const uint32_t* compressed_rowmajor, const cpir_dtc_layout* layout, uint32_t* dtc,

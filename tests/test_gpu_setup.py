@@ -210,6 +210,65 @@ def test_mat_x_mat_on_the_matrix_cores(orc, device):
             assert np.array_equal(_host(M), base + want), ("accumulate", rows, inner, cols)
 
 
+def test_mat_x_packed_takes_the_packed_image_as_right_hand_side(orc, device):
+    """cpir_op_transpose_compress_with_plane + cpir_op_mat_x_packed == impl Mul for &Matrix (matrix.rs:1040-1059) on the unpacked D:
+    the low-byte operand pieces of the planar image + the high-byte plane written in the same pass are the right-hand side of the
+    matrix-core matmul.  One to six bit planes, ragged rows / columns / k tails and super-tiles, extreme limbs in A, accumulate mode; the
+    image is bit-identical to the one cpir_op_transpose_compress writes; not offered for b <= 8 or the other packings."""
+    import torch
+
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(4711)
+    stream = torch.cuda.current_stream()
+    extremes_a = np.array([0, 0xFFFFFFFF, 0x80808080, 0x7F7F7F7F, 0x00FF807F, 0x80000000, 1, 0x01010101], dtype=np.uint32)
+    for b, rows, N, C in ((9, 1, 4, 1), (9, 128, 512, 16), (10, 129, 64 * 5 + 4, 17), (9, 257, 8192 + 60, 940), (12, 300, 4 * 3333, 33),
+                          (14, 77, 512 * 9 - 4, 130), (11, 1774, 64 * 17, 20), (9, 16, 1 << 17, 16)):
+        L = cp.dtc_layout_for(N, C, b, packing=2)
+        assert L.packing == 2 and cp.packed_rhs_plane_bytes(L) == (L.rows_padded // 16) * ((N + 63) // 64) * 1024
+        A = random_query(rng, rows * N).reshape(rows, N)
+        A.reshape(-1)[rng.integers(0, A.size, size=min(A.size, 4096))] = rng.choice(extremes_a, size=min(A.size, 4096))
+        if rows >= 3:
+            A[1] = 0xFFFFFFFF
+            A[2] = 0x80808080
+        D = random_db_matrix(rng, N, C, b)
+        if C >= 3:
+            D[:, 1] = (1 << b) - 1
+            D[:, 2] = 0
+        want = orc.mul(A, D)
+        A_dev, D_dev = _dev(A), _dev(D)
+        dtc = torch.full((L.total_words,), -1, dtype=torch.int32, device="cuda")
+        dtc_plain = torch.full((L.total_words,), -1, dtype=torch.int32, device="cuda")
+        plane = torch.full((cp.packed_rhs_plane_bytes(L) // 4,), -1, dtype=torch.int32, device="cuda")
+        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        device.transpose_compress_with_plane(D_dev, L, dtc, plane, or_of_entries=flag, stream=stream)
+        device.transpose_compress(D_dev, L, dtc_plain, stream=stream)
+        torch.cuda.synchronize()
+        assert torch.equal(dtc, dtc_plain)
+        assert int(flag.item()) >> b == 0
+        ldm = C + 3
+        M = torch.full((rows, ldm), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+        device.mat_x_packed(A_dev, dtc, L, plane, M, rows, ldm=ldm, stream=stream)
+        torch.cuda.synchronize()
+        got = _host(M)
+        assert np.array_equal(got[:, :C], want), (b, rows, N, C)
+        assert np.all(got[:, C:] == 0x5A5A5A5A)  # padding of M untouched
+        base = random_query(rng, rows * C).reshape(rows, C)
+        M2 = _dev(base).clone()
+        device.mat_x_packed(A_dev, dtc, L, plane, M2, rows, accumulate=True, stream=stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(_host(M2), base + want), ("accumulate", b, rows, N, C)
+    # where the pairing is not offered
+    for L in (cp.dtc_layout_for(4096, 16, 8, packing=2), cp.dtc_layout_for(4096, 16, 9, packing=0)):
+        assert cp.packed_rhs_plane_bytes(L) == 0
+        dtc = torch.zeros(L.total_words, dtype=torch.int32, device="cuda")
+        some = torch.zeros(1 << 16, dtype=torch.int32, device="cuda")
+        with pytest.raises(cp.ChalametPIRError):
+            device.transpose_compress_with_plane(some, L, dtc, some, stream=stream)
+        with pytest.raises(cp.ChalametPIRError):
+            device.mat_x_packed(some, dtc, L, some, some, 1, stream=stream)
+
+
 def test_mat_x_mat_dimension_errors(device):
     import torch
 
@@ -223,7 +282,11 @@ def test_mat_x_mat_dimension_errors(device):
 
 # (the last case makes A 85 MB: two 64 MiB staging blocks, neither a multiple of the 168-byte sponge rate -- the squeeze continues
 # across calls mid-block -- and two chunks of the pipelined hint matmul wait on different upload events)
-@pytest.mark.parametrize("b,N,C", [(9, 3 * 1100 + 1, 97), (10, 5000, 64), (12, 2049, 33), (7, 4097, 130), (9, 12001, 8)])
+# (N a multiple of 4 and b >= 9: the hint's right-hand side comes from the packed image itself + the high-byte plane written beside it --
+# ragged last k-steps and super-tiles, one to six bit planes, column counts around the 16- and 128-column tiles; the other cases take the
+# byte-plane split or the VALU kernels)
+@pytest.mark.parametrize("b,N,C", [(9, 3 * 1100 + 1, 97), (10, 5000, 64), (12, 2049, 33), (7, 4097, 130), (9, 12001, 8),
+                                   (9, 4 * 1537, 131), (14, 512 * 3, 17), (10, 516, 1), (11, 64 * 41, 129), (9, 512 * 8 + 60, 260)])
 def test_setup_from_matrix_matches_oracle(b, N, C, orc, device):
     """Server::setup minus the encoder (reference server.rs:59-67): hint = A(seed)*D and the resident packed DB"""
     import chalametpir_amd as cp
@@ -253,6 +316,13 @@ def test_setup_uses_unmasked_entries_for_the_hint(orc, device):
     N, C, b = 1500, 20, 9
     D = random_query(rng, N * C).reshape(N, C)  # full-range u32
     seed = rng.bytes(32)
+    want_hint, want_dtc = orc.server_setup_from_matrix(seed, D, b)
+    srv, hint = cp.Server.setup_from_matrix(seed, D, b, device=device)
+    assert np.array_equal(hint, want_hint)
+    assert np.array_equal(srv.export_compressed(), want_dtc)
+    # entries that fit 16 bits but not b: the packed image (masked to b bits) must not serve as the hint's right-hand side
+    N, C, b = 4 * 700, 37, 9
+    D = rng.integers(0, 1 << 14, size=(N, C), dtype=np.uint64).astype(np.uint32)
     want_hint, want_dtc = orc.server_setup_from_matrix(seed, D, b)
     srv, hint = cp.Server.setup_from_matrix(seed, D, b, device=device)
     assert np.array_equal(hint, want_hint)
