@@ -826,6 +826,20 @@ def setup_kernel_roofline(cp, device, torch, N, C, b, cf, mask, layout, stream):
 
     mm_ms = timed(lambda: device.mat_x_mat(A, D, M, R, N, C, rhs_max_bits=16, stream=stream))
     pk_ms = timed(lambda: device.transpose_compress(D, layout, dtc, stream=stream))
+    # what Server::setup runs where it can (planar packing, b >= 9): ONE pass over D writes the packed image and the second operand plane
+    # of the matmul, whose first plane are the image's own low-byte pieces -- no separate split of D in front of the product
+    paired = None
+    plane_bytes = cp.packed_rhs_plane_bytes(layout)
+    if plane_bytes and "mfma" in cp.mat_x_mat_kernel_name(16):
+        plane = torch.empty(plane_bytes // 4, dtype=torch.int32, device="cuda")
+        M2 = torch.empty((R, C), dtype=torch.int32, device="cuda")
+        pk2_ms = timed(lambda: device.transpose_compress_with_plane(D, layout, dtc, plane, stream=stream))
+        mm2_ms = timed(lambda: device.mat_x_packed(A, dtc, layout, plane, M2, R, stream=stream))
+        paired = {"pack_with_plane_ms": round(pk2_ms, 3), "matmul_ms": round(mm2_ms, 3), "same_hint_as_split_path": bool(torch.equal(M, M2)),
+                  "plane_bytes": plane_bytes}
+        split_ms, mm_ms = mm_ms, mm2_ms
+        pack_alone_ms, pk_ms = pk_ms, pk2_ms
+        del plane, M2
     macs = R * N * C
     b_setup = 4 * R * N + 4 * N * C + 4 * R * C
     b_pack_alg = 4 * N * C + 4 * C * -(-N // cf)
@@ -863,6 +877,15 @@ def setup_kernel_roofline(cp, device, torch, N, C, b, cf, mask, layout, stream):
         "note": "each kernel alone, one launch over the whole config, HIP events on the launch stream, synthetic A / D resident in HBM; "
                 "inside Server::setup both hide behind the host XOF (server_setup_phases_sec)",
     }
+    if paired:
+        out["hint_matmul"]["right_hand_side"] = ("the packed image's low-byte pieces + the high-byte plane written by the pack pass "
+                                                 "(cpir_op_transpose_compress_with_plane + cpir_op_mat_x_packed): D is read once")
+        out["hint_matmul"]["same_hint_as_split_path"] = paired["same_hint_as_split_path"]
+        out["hint_matmul"]["split_path_ms"] = round(split_ms, 3)  # cpir_op_mat_x_mat: byte-plane split of D (a pass of its own) + product
+        out["transpose_compress"]["writes_matmul_plane_bytes"] = paired["plane_bytes"]
+        out["transpose_compress"]["moved_bytes"] = b_pack_moved + paired["plane_bytes"]
+        out["transpose_compress"]["moved_GBps"] = round((b_pack_moved + paired["plane_bytes"]) / (pk_ms * 1e-3) / 1e9, 1)
+        out["transpose_compress"]["without_plane_ms"] = round(pack_alone_ms, 3)
     del A, D, M, dtc
     torch.cuda.empty_cache()
     return out
