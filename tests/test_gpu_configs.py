@@ -304,6 +304,23 @@ def test_hint_matmul_at_this_shape(cfg, device):
     hint = M.cpu().numpy().view(np.uint32)
     for r in (0, 1, 127, 128, R - 1):
         assert np.array_equal(hint[r], exact_sums(f, A[r])), r
+    # the same product with the right-hand side taken from the packed image + the plane written beside it (what Server::setup runs for
+    # b >= 9): same hint, bit for bit, and the same image
+    import chalametpir_amd as cp
+
+    L = f.srv.layout
+    plane_bytes = cp.packed_rhs_plane_bytes(L)
+    if plane_bytes:
+        dtc = torch.empty(int(L.total_words), dtype=torch.int32, device="cuda")
+        plane = torch.empty(plane_bytes // 4, dtype=torch.int32, device="cuda")
+        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        device.transpose_compress_with_plane(f.D, L, dtc, plane, or_of_entries=flag, stream=f.stream)
+        M2 = torch.full((R, f.C), -1, dtype=torch.int32, device="cuda")
+        device.mat_x_packed(A, dtc, L, plane, M2, R, stream=f.stream)
+        torch.cuda.synchronize()
+        assert int(flag.item()) >> f.b == 0
+        assert torch.equal(M2, M)
+        del dtc, plane, M2
     rng = np.random.default_rng(77)
     n_w = 3
     Wt = rng.integers(0, 1 << 32, size=(n_w, R), dtype=np.uint64)
