@@ -870,7 +870,7 @@ static int setup_group_from_host_matrix(const std::vector<Device*>& devs, Public
   const size_t G = devs.size();
   Server* grp = server_new(devs[0], Lfull, 0, N);
   struct Work {
-    DevBuf D_dev, flag, M_dev;
+    DevBuf D_dev, flag, M_dev, hi_plane, rowsum_ws;  // hi_plane: the second operand plane of the hint matmul, written by the pack pass
     uint32_t ored = 0;
   };
   std::vector<Work> work(G);
@@ -894,7 +894,15 @@ static int setup_group_from_host_matrix(const std::vector<Device*>& devs, Public
     hipStream_t stream = devs[g]->stream;
     TRY_(hipMemcpyAsync(work[g].D_dev.p, D + lo * C, (size_t)(hi - lo) * C * 4, hipMemcpyHostToDevice, stream));
     TRY_(hipMemsetAsync(work[g].flag.p, 0, 4, stream));
-    st = launch_transpose_compress(devs[g], (const uint32_t*)work[g].D_dev.p, C, L, child->dtc, (uint32_t*)work[g].flag.p, stream);
+    // (as setup_from_host_matrix: where the packed image can serve as the matmul's right-hand side, the pack pass prepares it; A's slab
+    // for this shard is allocated 16-byte aligned with leading dimension hi - lo)
+    const uint64_t hi_bytes = planar_hi_plane_bytes(L);
+    if (mfma_matmul_enabled() && hi_bytes && L.packing == CPIR_PACK_PLANAR && (hi - lo) % 4 == 0 && mfma_pipeline() != 0) {
+      TRY_(hipMalloc(&work[g].hi_plane.p, (size_t)hi_bytes));
+      TRY_(hipMalloc(&work[g].rowsum_ws.p, 4 * ((CPIR_LWE_DIMENSION + 127) / 128 * 128)));
+    }
+    st = launch_transpose_compress(devs[g], (const uint32_t*)work[g].D_dev.p, C, L, child->dtc, (uint32_t*)work[g].flag.p, stream,
+                                   work[g].hi_plane.p);
     if (st != CPIR_OK) return fail(st);
     TRY_(hipMemcpyAsync(&work[g].ored, work[g].flag.p, 4, hipMemcpyDeviceToHost, stream));
   }
@@ -922,8 +930,12 @@ static int setup_group_from_host_matrix(const std::vector<Device*>& devs, Public
     st = upA.finish(&A_dev, g);
     if (st != CPIR_OK) return fail(st);
     const uint64_t n = child->layout.num_slots;
-    st = launch_mat_x_mat(devs[g], A_dev, n, (const uint32_t*)work[g].D_dev.p, C, (uint32_t*)work[g].M_dev.p, C, CPIR_LWE_DIMENSION, n, C,
-                          rhs_bits, 0, devs[g]->stream);
+    if (work[g].hi_plane.p && (ored >> b) == 0 && mfma_planar_rhs_applicable(A_dev, n, child->layout))
+      st = launch_mat_x_mat_mfma_planar(devs[g], A_dev, n, child->dtc, child->layout, work[g].hi_plane.p, (uint32_t*)work[g].rowsum_ws.p,
+                                        (uint32_t*)work[g].M_dev.p, C, CPIR_LWE_DIMENSION, 0, devs[g]->stream);
+    else
+      st = launch_mat_x_mat(devs[g], A_dev, n, (const uint32_t*)work[g].D_dev.p, C, (uint32_t*)work[g].M_dev.p, C, CPIR_LWE_DIMENSION, n, C,
+                            rhs_bits, 0, devs[g]->stream);
     if (st != CPIR_OK) return fail(st);
     uint32_t* dst = hint_out;
     if (g > 0) {
@@ -942,7 +954,10 @@ static int setup_group_from_host_matrix(const std::vector<Device*>& devs, Public
   }
   grp->setup_timings[5] = now_seconds() - t0;  // partial matmuls + downloads + host sum
 #undef TRY_
-  for (size_t g = 0; g < G; g++) work[g].D_dev.dispose_async(devs[g]->ordinal);
+  for (size_t g = 0; g < G; g++) {
+    work[g].D_dev.dispose_async(devs[g]->ordinal);
+    work[g].hi_plane.dispose_async(devs[g]->ordinal);
+  }
   *out = grp;
   return CPIR_OK;
 }
