@@ -878,6 +878,7 @@ def setup_kernel_roofline(cp, device, torch, N, C, b, cf, mask, layout, stream):
                 "inside Server::setup both hide behind the host XOF (server_setup_phases_sec)",
     }
     if paired:
+        out["hint_matmul"]["kernel"] = "mat_x_mat_mfma_pipe_kernel<true>"
         out["hint_matmul"]["right_hand_side"] = ("the packed image's low-byte pieces + the high-byte plane written by the pack pass "
                                                  "(cpir_op_transpose_compress_with_plane + cpir_op_mat_x_packed): D is read once")
         out["hint_matmul"]["same_hint_as_split_path"] = paired["same_hint_as_split_path"]

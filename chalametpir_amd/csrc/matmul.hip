@@ -268,7 +268,9 @@ int mfma_ablate() { return g_mfma_ablate.load(); }
 void set_mfma_ablate(int bits) { g_mfma_ablate.store(bits); }
 
 const char* mat_x_mat_kernel_name(uint32_t rhs_max_bits) {
-  return rhs_max_bits > 16 ? "mat_x_mat_u32_kernel" : (mfma_matmul_enabled() ? "mat_x_mat_mfma_kernel" : "mat_x_mat_packed16_kernel");
+  if (rhs_max_bits > 16) return "mat_x_mat_u32_kernel";
+  if (!mfma_matmul_enabled()) return "mat_x_mat_packed16_kernel";
+  return mfma_pipeline() ? "mat_x_mat_mfma_pipe_kernel" : "mat_x_mat_mfma_kernel";  // (the pipelined kernel is a template: <false> here, <true> behind cpir_op_mat_x_packed)
 }
 
 int launch_mat_x_mat(const Device* dev, const uint32_t* A, uint64_t lda, const uint32_t* D, uint64_t ldd, uint32_t* M,

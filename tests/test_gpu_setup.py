@@ -163,7 +163,7 @@ def test_mat_x_mat_on_the_matrix_cores(orc, device):
 
     import chalametpir_amd as cp
 
-    assert cp.mat_x_mat_kernel_name(16) == "mat_x_mat_mfma_kernel" and cp.mat_x_mat_kernel_name(32) == "mat_x_mat_u32_kernel"
+    assert cp.mat_x_mat_kernel_name(16) == "mat_x_mat_mfma_pipe_kernel" and cp.mat_x_mat_kernel_name(32) == "mat_x_mat_u32_kernel"
     rng = np.random.default_rng(47)
     stream = torch.cuda.current_stream()
     extremes_a = np.array([0, 0xFFFFFFFF, 0x80808080, 0x7F7F7F7F, 0x00FF807F, 0x80000000, 1, 0x01010101], dtype=np.uint32)
