@@ -1,0 +1,798 @@
+// host_respond.hip -- Server::respond on HOST buffers (reference chalametpir_server/src/server.rs:184-190): the Server handle's life cycle,
+// the arenas that coalesce and pipeline concurrent callers, the lone caller whose query the kernel reads in place, the in-process group of
+// shards, and the extern "C" entry points cpir_server_respond*.
+#include "server_internal.hpp"
+
+namespace cpir {
+
+
+// A lone caller's query is copied into the pinned block by several threads: one core copies ~20 GB/s, the host link takes ~57, and the
+// reference's own benchmark is exactly a single caller handing over a pageable buffer (integrations/benches/online_phase.rs:81-97).
+// Three helper threads per process, created on first use; a caller that finds them busy (many concurrent callers: their own threads
+// already copy side by side) simply copies by itself.
+class StagingHelpers {
+ public:
+  static constexpr int kHelpers = 3;
+  struct Job {
+    void* dst;
+    const void* src;
+    size_t bytes;
+    std::atomic<int>* done;  // set to 1 when copied
+  };
+  ~StagingHelpers() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (std::thread& t : threads_)
+      if (t.joinable()) t.join();
+  }
+  // exclusive use for one query; false if somebody else holds the helpers
+  bool try_acquire() {
+    if (!owner_.try_lock()) return false;
+    std::lock_guard<std::mutex> lk(mu_);
+    if (threads_.empty())
+      for (int i = 0; i < kHelpers; i++) threads_.emplace_back([this] { run(); });
+    return true;
+  }
+  void release() { owner_.unlock(); }
+  void submit(const Job& j) {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      jobs_.push_back(j);
+    }
+    cv_.notify_one();
+  }
+  // the submitter helps: run one queued job, if any
+  bool help() {
+    Job j;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (jobs_.empty()) return false;
+      j = jobs_.front();
+      jobs_.pop_front();
+    }
+    memcpy(j.dst, j.src, j.bytes);
+    j.done->store(1, std::memory_order_release);
+    return true;
+  }
+
+ private:
+  void run() {
+    for (;;) {
+      Job j;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || !jobs_.empty(); });
+        if (jobs_.empty()) return;
+        j = jobs_.front();
+        jobs_.pop_front();
+      }
+      memcpy(j.dst, j.src, j.bytes);
+      j.done->store(1, std::memory_order_release);
+    }
+  }
+  std::mutex owner_, mu_;
+  std::condition_variable cv_;
+  std::deque<Job> jobs_;
+  std::vector<std::thread> threads_;
+  bool stop_ = false;
+};
+static StagingHelpers g_staging;
+
+// Wait for an event the device will signal within a few hundred microseconds: poll it for a while (a blocking wait costs tens of
+// microseconds of wake-up latency, a tenth of a lone query), then fall back to the blocking wait.
+static hipError_t wait_for_event(hipEvent_t ev) {
+  const double t0 = now_seconds();
+  for (;;) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e != hipErrorNotReady) return e;
+    if (now_seconds() - t0 > 2e-3) break;
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  (void)hipGetLastError();  // hipErrorNotReady is sticky-free, but keep the thread's error state clean
+  return hipEventSynchronize(ev);
+}
+
+void device_retain(Device* d) { d->refs.fetch_add(1); }
+void device_release(Device* d) {
+  if (d && d->refs.fetch_sub(1) == 1) {
+    DeviceGuard g(d->ordinal);
+    if (d->stream) (void)hipStreamDestroy(d->stream);
+    delete d;
+  }
+}
+
+// Where the device may read [p, p + bytes) of host memory in place (a DMA straight from the caller's buffer, or a kernel reading a lone
+// query where it lies): the device address of p if BOTH ends of the range are page-locked memory the runtime has mapped, at the same distance from each other as on the host (one mapping, or mappings laid end to end); NULL
+// otherwise (pageable memory, a registration that covers only part of the buffer).  Only a NO is remembered (per thread, for the last
+// buffer asked about: a server loop hands over the same pageable buffer again and again, and a stale no merely stages a buffer that has
+// been registered since); a yes is asked again every call, because a stale yes -- the buffer unregistered in between -- would let the
+// device read unmapped host pages.
+static const void* pinned_range_device_pointer(const void* p, size_t bytes) {
+  struct Last {
+    const char* lo = nullptr;
+    size_t bytes = 0;
+    const void* dev = nullptr;
+  };
+  static thread_local Last last;
+  const char* c = static_cast<const char*>(p);
+  if (last.lo == c && last.bytes == bytes && last.dev == nullptr) return nullptr;
+  const void* dev = nullptr;
+  hipPointerAttribute_t lo_attr, hi_attr;
+  if (bytes > 0 && hipPointerGetAttributes(&lo_attr, c) == hipSuccess && hipPointerGetAttributes(&hi_attr, c + bytes - 1) == hipSuccess) {
+    if (lo_attr.type == hipMemoryTypeHost && hi_attr.type == hipMemoryTypeHost && lo_attr.devicePointer && hi_attr.devicePointer &&
+        static_cast<const char*>(hi_attr.devicePointer) - static_cast<const char*>(lo_attr.devicePointer) == (ptrdiff_t)(bytes - 1))
+      dev = lo_attr.devicePointer;
+  } else {
+    (void)hipGetLastError();  // ordinary pageable memory: not an error worth keeping
+  }
+  last.lo = c, last.bytes = bytes, last.dev = dev;
+  return dev;
+}
+
+// an arena's query and response seats live in ONE device block and ONE pinned block (pinning is the slow call)
+static void arena_free(RespondArena& a) {
+  for (hipEvent_t e : a.seat_ev)
+    if (e) (void)hipEventDestroy(e);
+  if (a.done_ev) (void)hipEventDestroy(a.done_ev);
+  if (a.q_dev) (void)hipFree(a.q_dev);
+  if (a.q_pinned) (void)hipHostFree(a.q_pinned);
+  a = RespondArena{};
+}
+
+static void arenas_destroy(Server* srv) {
+  for (RespondArena& a : srv->arena) arena_free(a);
+  if (srv->up_stream) (void)hipStreamDestroy(srv->up_stream);
+  if (srv->run_stream) (void)hipStreamDestroy(srv->run_stream);
+  srv->up_stream = srv->run_stream = nullptr;
+  srv->streams_ready = false;
+}
+
+// spare words behind the response seats of an arena's two blocks: the fill progress of a lone query in CPIR_FILL_LINES copies (pinned
+// block; + 16 words so that the copies can start on a 64-byte line), the abort flag (device block, behind seat 0's response)
+static constexpr size_t kArenaSpareWords = (size_t)CPIR_FILL_LINES * 16 + 16;
+static void publish_fill_progress(uint32_t* lines, uint32_t steps) {
+  for (uint32_t i = 0; i < CPIR_FILL_LINES; i++) __atomic_store_n(lines + i * 16, steps, __ATOMIC_RELEASE);
+}
+
+// on first use of this arena (caller holds Server::mu).  A shard stages only its own slots of a query, but seats keep the full stride.
+static int arena_create(Server* srv, RespondArena& a) {
+  // kSeats queries, then kSeats responses (query block first: it stays 16-byte aligned)
+  // (+ 16 words behind the responses: the device block's spare words follow seat 0's response when a lone caller has only one seat
+  // to fill -- the abort flag of a polled launch; the pinned block's hold the fill progress the kernel polls)
+  const size_t qw = (size_t)srv->total_slots * Server::kSeats, rw = ((size_t)srv->layout.num_cols * Server::kSeats + 3) / 4 * 4 + kArenaSpareWords;
+  auto fail = [&](hipError_t e, const char* what) {
+    set_last_hip_error(e, what, __FILE__, __LINE__);
+    arena_free(a);
+    return e == hipErrorOutOfMemory ? CPIR_ERR_OUT_OF_DEVICE_MEMORY : CPIR_ERR_HIP;
+  };
+  hipError_t e = hipSuccess;
+  if (!srv->streams_ready) {
+    // The two streams must not share a hardware queue (uploads would then serialise with kernels): HIP multiplexes the streams of one
+    // priority level over a handful of queues in creation order, and a host process (torch, say) has usually created several already.
+    // The run stream is created at the highest priority, which has queues of its own.
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // (least, greatest): numerically greatest <= least
+    e = hipStreamCreateWithFlags(&srv->up_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&srv->run_stream, hipStreamNonBlocking, prio_hi);
+    if (e != hipSuccess) {
+      if (srv->up_stream) (void)hipStreamDestroy(srv->up_stream);
+      srv->up_stream = srv->run_stream = nullptr;
+      return fail(e, "hipStreamCreateWithFlags");
+    }
+    srv->streams_ready = true;
+  }
+  if ((e = hipMalloc(&a.q_dev, (qw + rw) * 4)) != hipSuccess) return fail(e, "hipMalloc(respond arena)");
+  if ((e = hipHostMalloc(&a.q_pinned, (qw + rw) * 4, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc(respond arena)");
+  a.r_dev = a.q_dev + qw, a.r_pinned = a.q_pinned + qw;
+  {
+    void* dp = nullptr;
+    if ((e = hipHostGetDevicePointer(&dp, a.q_pinned, 0)) != hipSuccess) return fail(e, "hipHostGetDevicePointer");
+    a.q_pinned_dev = static_cast<const uint32_t*>(dp);
+    const size_t off = (qw + rw - kArenaSpareWords + 15) / 16 * 16;  // the copies start on a 64-byte line (the block itself is page-aligned)
+    a.fill_progress = a.q_pinned + off;
+    a.fill_progress_dev = a.q_pinned_dev + off;
+  }
+  a.r0_zero = false;
+  a.seat_ev.assign(Server::kSeats, nullptr);
+  for (hipEvent_t& ev : a.seat_ev)
+    if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreateWithFlags");
+  if ((e = hipEventCreateWithFlags(&a.done_ev, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreateWithFlags");
+  return CPIR_OK;
+}
+
+
+static void group_ctx_destroy(Server* srv) {
+  for (auto& w : srv->workers) {
+    {
+      std::lock_guard<std::mutex> lk(w->mu);
+      w->stop = true;
+    }
+    w->cv.notify_all();
+    if (w->th.joinable()) w->th.join();
+  }
+  srv->workers.clear();
+  for (Server::GroupCtx& c : srv->gctx) {
+    for (size_t g = 0; g < c.lanes.size(); g++) {
+      Server::GroupLane& l = c.lanes[g];
+      DeviceGuard dg(srv->shards[g]->dev->ordinal);
+      if (l.stream) (void)hipStreamDestroy(l.stream);
+      if (l.q_dev) (void)hipFree(l.q_dev);  // q_dev and r_dev are one block
+      if (l.q_pinned) (void)hipHostFree(l.q_pinned);  // q_pinned and r_pinned are one block
+    }
+    c.lanes.clear();
+  }
+  srv->gctx_ready = false;
+}
+
+void server_destroy(Server* srv) {
+  if (!srv) return;
+  if (srv->trace_on && srv->trace.calls.load()) {
+    const Server::Trace& t = srv->trace;
+    const double n = (double)t.calls.load(), nb = (double)(t.batches.load() ? t.batches.load() : 1);
+    fprintf(stderr, "[cpir respond trace] %.0f calls in %.0f batches; us per call: seat wait %.1f, staging %.1f, copy out %.1f; followers wait %.1f; "
+                    "us per batch (leader): gate %.1f, enqueue %.1f, device %.1f; batch sizes",
+            n, nb, t.ns_seat.load() / n / 1e3, t.ns_stage.load() / n / 1e3, t.ns_out.load() / n / 1e3,
+            t.ns_follow.load() / (n - nb > 0 ? n - nb : 1) / 1e3, t.ns_gate.load() / nb / 1e3, t.ns_enqueue.load() / nb / 1e3, t.ns_gpu.load() / nb / 1e3);
+    for (int i = 1; i <= 8; i++) fprintf(stderr, " %d:%llu", i, (unsigned long long)t.batch_hist[i].load());
+    fprintf(stderr, "; served alone (query read in place) %llu, %.1f us each; of those %llu by one launch polling the copy, %u such launches gave up\n",
+            (unsigned long long)t.solo.load(), t.solo.load() ? t.ns_solo.load() / (double)t.solo.load() / 1e3 : 0.0,
+            (unsigned long long)srv->fill_polled.load(), srv->fill_aborts.load());
+  }
+  if (!srv->shards.empty()) {
+    group_ctx_destroy(srv);
+    for (Server* c : srv->shards) server_destroy(c);
+    srv->shards.clear();
+  }
+  {
+    DeviceGuard g(srv->dev->ordinal);
+    arenas_destroy(srv);
+    if (srv->dtc) (void)hipFree(srv->dtc);
+  }
+  device_release(srv->dev);
+  delete srv;
+}
+
+// one shard's part of a group respond: stage its slots of the query, upload, answer, download, wait
+static int group_shard_respond(const Server* child, Server::GroupLane& l, const uint32_t* q, uint32_t C) {
+  const size_t n = (size_t)child->layout.num_slots;
+  hipError_t e;
+  if (pinned_range_device_pointer(q + child->slot_offset, n * 4) != nullptr) {  // this shard's slots lie in page-locked memory: DMA from there
+    e = hipMemcpyAsync(l.q_dev, q + child->slot_offset, n * 4, hipMemcpyHostToDevice, l.stream);
+  } else {
+    memcpy(l.q_pinned, q + child->slot_offset, n * 4);
+    e = hipMemcpyAsync(l.q_dev, l.q_pinned, n * 4, hipMemcpyHostToDevice, l.stream);
+  }
+  int status = CPIR_OK;
+  // a shard answered from ITS slice of the query is an unsharded respond on a database of its own slots
+  if (e == hipSuccess) status = launch_respond(child->dev, child->dtc, child->layout, l.q_dev, n, 0, 1, 1, l.r_dev, nullptr, l.stream);
+  if (e == hipSuccess && status == CPIR_OK) e = hipMemcpyAsync(l.r_pinned, l.r_dev, (size_t)C * 4, hipMemcpyDeviceToHost, l.stream);
+  const hipError_t e2 = hipStreamSynchronize(l.stream);  // drain whatever was enqueued
+  if (e == hipSuccess) e = e2;
+  if (e != hipSuccess && status == CPIR_OK) {
+    set_last_hip_error(e, "group respond (shard)", __FILE__, __LINE__);
+    status = CPIR_ERR_HIP;
+  }
+  return status;
+}
+
+static void group_worker_main(Server* srv, size_t g) {
+  Server::GroupWorker& w = *srv->workers[g];
+  const Server* child = srv->shards[g];
+  (void)hipSetDevice(child->dev->ordinal);  // this thread only ever talks to its shard's device
+  const uint32_t C = srv->layout.num_cols;
+  for (;;) {
+    Server::GroupJob job;
+    {
+      std::unique_lock<std::mutex> lk(w.mu);
+      w.cv.wait(lk, [&] { return w.stop || !w.jobs.empty(); });
+      if (w.jobs.empty()) return;  // stop requested and nothing left
+      job = w.jobs.front();
+      w.jobs.pop_front();
+    }
+    const int st = group_shard_respond(child, job.ctx->lanes[g], job.q, C);
+    {
+      std::lock_guard<std::mutex> lk(job.done->mu);
+      if (st != CPIR_OK && job.done->status == CPIR_OK) job.done->status = st;
+      job.done->remaining--;
+      job.done->cv.notify_one();  // under the lock: `done` lives on the caller's stack and may go away as soon as it is released
+    }
+  }
+}
+
+// per shard: a stream, a device block (query slice + response) and a pinned block of the same shape, for every call context
+static int group_ctx_create(Server* srv) {
+  const uint32_t C = srv->layout.num_cols;
+  for (Server::GroupCtx& c : srv->gctx) {
+    c.lanes.resize(srv->shards.size());
+    for (size_t g = 0; g < srv->shards.size(); g++) {
+      Server::GroupLane& l = c.lanes[g];
+      const Server* child = srv->shards[g];
+      DeviceGuard dg(child->dev->ordinal);
+      const size_t qw = ((size_t)child->layout.num_slots + 3) / 4 * 4, words = qw + C;
+#define TRY_(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_last_hip_error(_e, #e, __FILE__, __LINE__); group_ctx_destroy(srv); \
+    return _e == hipErrorOutOfMemory ? CPIR_ERR_OUT_OF_DEVICE_MEMORY : CPIR_ERR_HIP; } } while (0)
+      TRY_(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+      TRY_(hipMalloc(&l.q_dev, words * 4));
+      TRY_(hipHostMalloc(&l.q_pinned, words * 4, hipHostMallocDefault));
+#undef TRY_
+      l.r_dev = l.q_dev + qw;
+      l.r_pinned = l.q_pinned + qw;
+    }
+  }
+  for (size_t g = 0; g < srv->shards.size(); g++) {
+    srv->workers.emplace_back(new Server::GroupWorker);
+    srv->workers.back()->th = std::thread(group_worker_main, srv, g);
+  }
+  srv->gctx_ready = true;
+  return CPIR_OK;
+}
+
+// Server::respond on a group handle: scatter the query slices, one launch per device, sum the partial responses on the host
+static int group_respond(Server* srv, const uint32_t* q, uint32_t* r_out) {
+  const uint32_t C = srv->layout.num_cols;
+  Server::GroupCtx* ctx = nullptr;
+  {
+    std::unique_lock<std::mutex> lk(srv->mu);
+    if (!srv->gctx_ready) CPIR_TRY(group_ctx_create(srv));
+    srv->cv.wait(lk, [&] {
+      for (Server::GroupCtx& c : srv->gctx)
+        if (!c.busy) {
+          ctx = &c;
+          return true;
+        }
+      return false;
+    });
+    ctx->busy = true;
+  }
+  struct Release {
+    Server* srv;
+    Server::GroupCtx* c;
+    ~Release() {
+      {
+        std::lock_guard<std::mutex> lk(srv->mu);
+        c->busy = false;
+      }
+      srv->cv.notify_all();
+    }
+  } rel{srv, ctx};
+  Server::GroupDone done;
+  done.remaining = srv->shards.size();
+  for (auto& w : srv->workers) {
+    {
+      std::lock_guard<std::mutex> lk(w->mu);
+      w->jobs.push_back(Server::GroupJob{q, ctx, &done});
+    }
+    w->cv.notify_one();
+  }
+  int status;
+  {
+    std::unique_lock<std::mutex> lk(done.mu);
+    done.cv.wait(lk, [&] { return done.remaining == 0; });
+    status = done.status;
+  }
+  if (status != CPIR_OK) return status;
+  memcpy(r_out, ctx->lanes[0].r_pinned, (size_t)C * 4);
+  for (size_t g = 1; g < srv->shards.size(); g++) {
+    const uint32_t* p = ctx->lanes[g].r_pinned;
+    for (uint32_t c = 0; c < C; c++) r_out[c] += p[c];  // u32 wrap-around
+  }
+  return CPIR_OK;
+}
+
+
+Server* server_new(Device* dev, const cpir_dtc_layout& L, uint64_t slot_offset, uint64_t total_slots) {
+  Server* s = new Server;
+  s->dev = dev;
+  device_retain(dev);
+  s->layout = L;
+  s->slot_offset = slot_offset;
+  s->total_slots = total_slots;
+  const char* tr = getenv("CPIR_RESPOND_TRACE");
+  s->trace_on = tr && tr[0] == '1';
+  return s;
+}
+
+
+// Any batch size.  With batch fusion every pass answers 4 queries from one stream of the database (remainder 2 / 1);
+// without it every query is its own pass.  Either way the passes of one kind go into ONE launch.
+int respond_batched(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
+                           uint64_t q_slot_offset, uint32_t batch, uint32_t* r, uint32_t* scratch, hipStream_t stream) {
+  if (!respond_batch_fusion()) {
+    // One launch for all passes saves a kernel fill/drain (~10 us) per query, but blocks of a long multi-pass launch drift
+    // apart and lose the L2 sharing of q: measured on MI355X it wins up to 1.3 GB per pass (196 vs 204 us) and loses at
+    // 5 GB and above (806 vs 770 us), so very large databases get one launch per query.
+    // (the matrix-core kernel keeps one launch at every size: 1 440 vs 1 505 us per query at 9.8 GB, 790 vs 799 at 5 GB)
+    if (L.packing == CPIR_PACK_PLANAR || L.total_words * 4 <= respond_multi_pass_limit_bytes()) return launch_respond(dev, dtc, L, q, q_len, q_slot_offset, 1, batch, r, scratch, stream);
+    for (uint32_t i = 0; i < batch; i++)
+      CPIR_TRY(launch_respond(dev, dtc, L, q + (uint64_t)i * q_len, q_len, q_slot_offset, 1, 1, r + (uint64_t)i * L.num_cols, scratch, stream));
+    return CPIR_OK;
+  }
+  uint32_t done = 0;
+  if (L.packing == CPIR_PACK_PLANAR) {
+    // the matrix-core kernel takes any 1..8 queries per pass: passes of 8, then one pass for the rest
+    const uint32_t W8 = CPIR_PLANAR_MAX_QUERIES_PER_PASS;
+    if (batch >= W8) {
+      CPIR_TRY(launch_respond(dev, dtc, L, q, q_len, q_slot_offset, W8, batch / W8, r, scratch, stream));
+      done = batch / W8 * W8;
+    }
+    if (done < batch)
+      CPIR_TRY(launch_respond(dev, dtc, L, q + (uint64_t)done * q_len, q_len, q_slot_offset, batch - done, 1,
+                              r + (uint64_t)done * L.num_cols, scratch, stream));
+    return CPIR_OK;
+  }
+  for (uint32_t width : {4u, 2u, 1u}) {
+    const uint32_t passes = (batch - done) / width;
+    if (passes == 0) continue;
+    CPIR_TRY(launch_respond(dev, dtc, L, q + (uint64_t)done * q_len, q_len, q_slot_offset, width, passes,
+                            r + (uint64_t)done * L.num_cols, scratch, stream));
+    done += passes * width;
+  }
+  return CPIR_OK;
+}
+
+
+}  // namespace cpir
+
+using namespace cpir;
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------------------------
+// server: respond
+// ---------------------------------------------------------------------------------------------------------------
+// A caller that found the server idle (it holds arena `a` alone, closed to others): no upload.  The step-major kernel reads each query
+// word once, so it reads them where they are: in the caller's buffer if that is page-locked and 16-byte aligned, else in the arena's
+// pinned block, filled in two halves by this thread and the staging helpers with each half's steps launched as soon as it is in place
+// (the second half is copied while the kernel works on the first).  The launches add up in r_dev, which is kept zeroed between uses.
+static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32_t* r_out) {
+  const size_t C = srv->layout.num_cols;
+  const size_t q_lo = (size_t)srv->slot_offset, words = (size_t)srv->layout.num_slots;
+  hipStream_t st = srv->run_stream;
+  std::lock_guard<std::mutex> ll(srv->launch_mu);
+  hipError_t e = hipSuccess;
+  int rc = CPIR_OK;
+  // seat 0's response and the word behind it (the abort flag of a polled launch) are kept zeroed between uses
+  if (!a->r0_zero) e = hipMemsetAsync(a->r_dev, 0, (C + 1) * 4, st);
+  a->r0_zero = false;
+  bool polled = false;
+  // the slots this server reads, q[q_lo, q_lo + words), as the device addresses them -- if the whole range is page-locked; the kernel
+  // is handed the (possibly virtual) address of q[0] and adds the offset itself
+  const uint32_t* in_place = nullptr;
+  if (e == hipSuccess && reinterpret_cast<uintptr_t>(q) % 16 == 0) {
+    const void* dp = pinned_range_device_pointer(q + q_lo, words * 4);
+    if (dp && reinterpret_cast<uintptr_t>(dp) % 16 == (q_lo * 4) % 16) in_place = static_cast<const uint32_t*>(dp) - q_lo;
+  }
+  if (e == hipSuccess && in_place) {
+    rc = launch_respond_read_once(srv->dev, srv->dtc, srv->layout, in_place, srv->total_slots, srv->slot_offset, a->r_dev, st);
+  } else if (e == hipSuccess) {
+    uint32_t* const qp = a->q_pinned;  // seat 0; same offsets as the caller's buffer
+    constexpr size_t kJob = (size_t)1 << 16;  // 256 KiB of u32, a multiple of the kernel's 512-slot step
+    constexpr size_t kStepsPerJob = kJob / CPIR_PLANAR_SLOTS_PER_TILE;
+    constexpr size_t kMaxJobs = 512;
+    const size_t n_jobs = (words + kJob - 1) / kJob;
+    const uint32_t fill_timeout_us = respond_host_fill_timeout_us();
+    if (words >= ((size_t)1 << 19) && n_jobs <= kMaxJobs && g_staging.try_acquire()) {
+      std::atomic<int> done[kMaxJobs];
+      // ONE launch, in front of the copy: the kernel takes the steps of q round-robin (front to back over the whole grid) and waits
+      // for each step's words to be in place, which this thread announces job by job in *fill_progress; the copy (~55 us for 4.7 MB)
+      // runs underneath the stream (~200 us).  A wave that has waited fill_timeout_us gives up and flags the launch as void: the query
+      // is then answered again from the (by then complete) pinned block -- a launch that cannot start before this thread moves on
+      // (synchronous launches under a debugger or a serialising profiler) costs that timeout once, and after three such launches the
+      // server stops polling and launches each half of the query when it is in place.
+      polled = fill_timeout_us > 0 && srv->fill_aborts.load(std::memory_order_relaxed) < 3;
+      if (polled) {
+        publish_fill_progress(a->fill_progress, 0u);
+        const PlanarHostFill fill{a->fill_progress_dev, a->r_dev + C, fill_timeout_us};
+        rc = launch_respond_read_once(srv->dev, srv->dtc, srv->layout, a->q_pinned_dev, srv->total_slots, srv->slot_offset, a->r_dev, st, 0, 0,
+                                      &fill);
+        if (rc != CPIR_OK) polled = false;  // nothing was launched
+      }
+      for (size_t i = 0; i < n_jobs; i++) {
+        done[i].store(0, std::memory_order_relaxed);
+        const size_t o = q_lo + i * kJob, n = (words - i * kJob < kJob) ? words - i * kJob : kJob;
+        g_staging.submit(StagingHelpers::Job{qp + o, q + o, n * 4, &done[i]});
+      }
+      auto wait_for_job = [&](size_t i) {
+        while (!done[i].load(std::memory_order_acquire))
+          if (!g_staging.help()) {
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+          }
+      };
+      if (polled) {
+        for (size_t i = 0; i < n_jobs; i++) {
+          wait_for_job(i);
+          publish_fill_progress(a->fill_progress, i + 1 == n_jobs ? 0xffffffffu : (uint32_t)((i + 1) * kStepsPerJob));
+        }
+      } else if (rc == CPIR_OK) {
+        const size_t j_half = (n_jobs + 1) / 2;
+        size_t next = 0;
+        for (int h = 0; h < 2 && rc == CPIR_OK; h++) {
+          for (; next < (h ? n_jobs : j_half); next++) wait_for_job(next);
+          const uint64_t s_lo = h ? j_half * kStepsPerJob : 0;
+          const uint64_t s_hi = h ? (words + CPIR_PLANAR_SLOTS_PER_TILE - 1) / CPIR_PLANAR_SLOTS_PER_TILE : j_half * kStepsPerJob;
+          if (s_hi > s_lo)
+            rc = launch_respond_read_once(srv->dev, srv->dtc, srv->layout, a->q_pinned_dev, srv->total_slots, srv->slot_offset, a->r_dev, st,
+                                          s_lo, s_hi);
+        }
+      }
+      for (size_t i = 0; i < n_jobs; i++) wait_for_job(i);  // every job must have run before the stack array goes away, whatever happened
+      g_staging.release();
+    } else {
+      memcpy(qp + q_lo, q + q_lo, words * 4);
+      rc = launch_respond_read_once(srv->dev, srv->dtc, srv->layout, a->q_pinned_dev, srv->total_slots, srv->slot_offset, a->r_dev, st);
+    }
+  }
+  for (int attempt = 0; attempt < 2; attempt++) {
+    if (e == hipSuccess && rc == CPIR_OK) e = hipMemcpyAsync(a->r_pinned, a->r_dev, (C + 1) * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && rc == CPIR_OK) e = hipEventRecord(a->done_ev, st);
+    if (e == hipSuccess && rc == CPIR_OK) {
+      // zeros for the next lone caller, off this one's critical path
+      if (hipMemsetAsync(a->r_dev, 0, (C + 1) * 4, st) == hipSuccess) a->r0_zero = true;
+      else (void)hipGetLastError();
+      e = wait_for_event(a->done_ev);
+    } else {
+      (void)hipStreamSynchronize(st);  // whatever was enqueued reads the caller's buffer / the pinned block: drain before returning
+    }
+    if (!(polled && e == hipSuccess && rc == CPIR_OK && a->r_pinned[C] != 0)) break;
+    // the polled launch gave up waiting: its results are void.  The pinned block is complete by now: answer from it, without polling.
+    polled = false;
+    srv->fill_aborts.fetch_add(1, std::memory_order_relaxed);
+    if (!a->r0_zero) e = hipMemsetAsync(a->r_dev, 0, (C + 1) * 4, st);
+    a->r0_zero = false;
+    if (e == hipSuccess)
+      rc = launch_respond_read_once(srv->dev, srv->dtc, srv->layout, a->q_pinned_dev, srv->total_slots, srv->slot_offset, a->r_dev, st);
+  }
+  if (polled) srv->fill_polled.fetch_add(1, std::memory_order_relaxed);
+  if (rc == CPIR_OK && e != hipSuccess) {
+    set_last_hip_error(e, "respond (query read in place)", __FILE__, __LINE__);
+    rc = CPIR_ERR_HIP;
+  }
+  if (rc == CPIR_OK) memcpy(r_out, a->r_pinned, C * 4);
+  return rc;
+}
+
+int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_rows, uint64_t q_cols, uint32_t* r_out) {
+  if (!csrv || !q || !r_out) return CPIR_ERR_INVALID_ARGUMENT;
+  Server* srv = const_cast<cpir_server*>(csrv);  // the pool is the only mutable state; it is internally locked
+  // matrix.rs:329-331: the query must be a 1 x N row vector
+  if (!(q_rows == 1 && q_cols == srv->total_slots)) return CPIR_ERR_INCOMPATIBLE_DIM_ROWVEC_X_TRANSPOSED;
+  if (!srv->shards.empty()) return group_respond(srv, q, r_out);
+  DeviceGuard g(srv->dev->ordinal);
+  const size_t N = (size_t)srv->total_slots, C = srv->layout.num_cols;
+
+  // ---- take a seat ----------------------------------------------------------------------------------------------
+  const bool tr = srv->trace_on;
+  const double t_enter = tr ? now_seconds() : 0;
+  const bool read_once_ok = respond_read_once_applicable(srv->layout);
+  std::unique_lock<std::mutex> lk(srv->mu);
+  RespondArena* a = nullptr;
+  bool solo = false;
+  for (;;) {
+    for (RespondArena& x : srv->arena)  // 1. an open arena that is still spreading
+      if (!a && x.state == RespondArena::OPEN && x.joined < Server::kSpread) a = &x;
+    if (!a)
+      for (RespondArena& x : srv->arena)  // 2. a free arena
+        if (!a && x.state == RespondArena::FREE) {
+          if (!x.q_dev) CPIR_TRY(arena_create(srv, x));
+          a = &x, x.state = RespondArena::OPEN, x.status = CPIR_OK;
+          // nobody else is filling an arena or on the device: this caller is served alone, its query read in place
+          solo = read_once_ok;
+          for (const RespondArena& y : srv->arena)
+            if (&y != a && (y.state == RespondArena::OPEN || y.state == RespondArena::LAUNCHED)) solo = false;
+          if (solo) x.state = RespondArena::LAUNCHED;  // closed at once: later callers open the next arena and upload meanwhile
+        }
+    if (!a)
+      for (RespondArena& x : srv->arena)  // 3. no arena free: fill the open one up
+        if (!a && x.state == RespondArena::OPEN && x.joined < Server::kSeats) a = &x;
+    if (a) break;
+    srv->cv.wait(lk);  // every arena is full or in flight
+  }
+  const uint32_t seat = a->joined++;
+  const bool leader = (seat == 0);
+  lk.unlock();
+  const double t_seated = tr ? now_seconds() : 0;
+  if (solo) {
+    const int st = respond_alone(srv, a, q, r_out);
+    if (tr) {
+      srv->trace.calls++, srv->trace.solo++;
+      srv->trace.ns_seat += (uint64_t)((t_seated - t_enter) * 1e9), srv->trace.ns_solo += (uint64_t)((now_seconds() - t_seated) * 1e9);
+    }
+    lk.lock();
+    a->state = RespondArena::FREE;
+    a->joined = a->staged = a->left = 0;
+    srv->cv.notify_all();
+    return st;
+  }
+
+  // ---- stage the query (the reference copies too: from_bytes .to_vec(), matrix.rs:1001-1007) and enqueue its upload -----------------
+  // (a shard reads only its own slots of the query: only those are staged and uploaded)
+  hipError_t up = hipSuccess;
+  const size_t q_lo = (size_t)srv->slot_offset, q_hi = q_lo + (size_t)srv->layout.num_slots;
+  uint32_t* const qd = a->q_dev + seat * N;
+  if (pinned_range_device_pointer(q + q_lo, (q_hi - q_lo) * 4) != nullptr) {
+    // the caller's buffer is page-locked already (cpir_host_alloc, hipHostMalloc, hipHostRegister): DMA straight from it
+    std::lock_guard<std::mutex> ul(srv->upload_mu);
+    up = hipMemcpyAsync(qd + q_lo, q + q_lo, (q_hi - q_lo) * 4, hipMemcpyHostToDevice, srv->up_stream);
+    if (up == hipSuccess) up = hipEventRecord(a->seat_ev[seat], srv->up_stream);
+  } else {
+    uint32_t* const qp = a->q_pinned + seat * N;
+    const size_t piece = (size_t)1 << 18;  // 1 MiB of u32
+    std::unique_lock<std::mutex> ul(srv->upload_mu, std::try_to_lock);
+    if (ul.owns_lock()) {
+      // nobody else is uploading: in pieces, so that the DMA of one piece runs while the next ones are being copied into the pinned
+      // block -- by this thread and, when they are free, by the staging helpers; the pieces are uploaded in order as they complete
+      // (each copy costs the copy engine ~15 us whatever its size, so with helpers the query goes up in TWO halves, each copied by all
+      // threads in 256 KiB jobs: the second half is copied while the first is on the link)
+      const size_t words = q_hi - q_lo;
+      if (words >= ((size_t)1 << 19) && g_staging.try_acquire()) {
+        constexpr size_t kJob = (size_t)1 << 16;  // 256 KiB of u32
+        constexpr size_t kMaxJobs = 512;
+        const size_t half = (words / 2 + kJob - 1) / kJob * kJob;
+        const size_t n_jobs = (words + kJob - 1) / kJob;
+        if (n_jobs <= kMaxJobs) {
+          std::atomic<int> done[kMaxJobs];
+          for (size_t i = 0; i < n_jobs; i++) {
+            done[i].store(0, std::memory_order_relaxed);
+            const size_t o = q_lo + i * kJob, n = (q_hi - o < kJob) ? q_hi - o : kJob;
+            g_staging.submit(StagingHelpers::Job{qp + o, q + o, n * 4, &done[i]});
+          }
+          size_t next = 0;
+          for (int h = 0; h < 2; h++) {
+            const size_t o_lo = q_lo + (h ? half : 0), o_hi = h ? q_hi : q_lo + half;
+            const size_t j_hi = (o_hi - q_lo + kJob - 1) / kJob;
+            for (; next < j_hi; next++)
+              while (!done[next].load(std::memory_order_acquire))
+                if (!g_staging.help()) {
+#if defined(__x86_64__)
+                  __builtin_ia32_pause();
+#endif
+                }
+            if (up == hipSuccess) up = hipMemcpyAsync(qd + o_lo, qp + o_lo, (o_hi - o_lo) * 4, hipMemcpyHostToDevice, srv->up_stream);
+          }
+        } else {
+          memcpy(qp + q_lo, q + q_lo, words * 4);
+          up = hipMemcpyAsync(qd + q_lo, qp + q_lo, words * 4, hipMemcpyHostToDevice, srv->up_stream);
+        }
+        g_staging.release();
+      } else {
+        for (size_t o = q_lo; o < q_hi && up == hipSuccess; o += piece) {
+          const size_t n = (q_hi - o < piece) ? q_hi - o : piece;
+          memcpy(qp + o, q + o, n * 4);
+          up = hipMemcpyAsync(qd + o, qp + o, n * 4, hipMemcpyHostToDevice, srv->up_stream);
+        }
+      }
+    } else {
+      // the link is busy with somebody else's query: copy while waiting, then upload in one piece when it is this query's turn
+      memcpy(qp + q_lo, q + q_lo, (q_hi - q_lo) * 4);
+      ul.lock();
+      up = hipMemcpyAsync(qd + q_lo, qp + q_lo, (q_hi - q_lo) * 4, hipMemcpyHostToDevice, srv->up_stream);
+    }
+    if (up == hipSuccess) up = hipEventRecord(a->seat_ev[seat], srv->up_stream);
+  }
+  if (up != hipSuccess) set_last_hip_error(up, "hipMemcpyAsync(query upload)", __FILE__, __LINE__);
+
+  const double t_staged = tr ? now_seconds() : 0;
+  lk.lock();
+  if (up != hipSuccess) a->status = CPIR_ERR_HIP;
+  a->staged++;
+  srv->cv.notify_all();
+  if (leader) {
+    // launch when every seat taken so far is staged AND the device is free of the previous arena's launch (or this one is full);
+    // callers keep joining until then
+    srv->cv.wait(lk, [&] {
+      if (a->staged != a->joined) return false;
+      if (a->joined == Server::kSeats) return true;
+      for (const RespondArena& x : srv->arena)
+        if (x.state == RespondArena::LAUNCHED) return false;
+      return true;
+    });
+    a->state = RespondArena::LAUNCHED;  // closed: later callers open the next arena
+    srv->cv.notify_all();
+    const uint32_t k = a->joined;
+    int st = a->status;
+    lk.unlock();
+    const double t_gate = tr ? now_seconds() : 0;
+    hipError_t e = hipSuccess;
+    if (st == CPIR_OK) {
+      std::lock_guard<std::mutex> ll(srv->launch_mu);  // the launch sequences of two arenas must not interleave on the run stream
+      for (uint32_t i = 0; i < k && e == hipSuccess; i++) e = hipStreamWaitEvent(srv->run_stream, a->seat_ev[i], 0);
+      a->r0_zero = false;
+      if (e == hipSuccess)
+        st = respond_batched(srv->dev, srv->dtc, srv->layout, a->q_dev, srv->total_slots, srv->slot_offset, k, a->r_dev, nullptr, srv->run_stream);
+      if (e == hipSuccess && st == CPIR_OK) e = hipMemcpyAsync(a->r_pinned, a->r_dev, (size_t)k * C * 4, hipMemcpyDeviceToHost, srv->run_stream);
+      if (e == hipSuccess) e = hipEventRecord(a->done_ev, srv->run_stream);
+    }
+    const double t_enq = tr ? now_seconds() : 0;
+    // always wait for what was enqueued for this arena before it can be reused: the uploads (they may have failed half way) and the launch
+    hipError_t e2 = hipSuccess;
+    if (st == CPIR_OK && e == hipSuccess) {
+      e2 = wait_for_event(a->done_ev);
+    } else {
+      (void)hipStreamSynchronize(srv->up_stream);
+      (void)hipStreamSynchronize(srv->run_stream);
+    }
+    if (e == hipSuccess) e = e2;
+    if (st == CPIR_OK && e != hipSuccess) {
+      set_last_hip_error(e, "respond launch / download", __FILE__, __LINE__);
+      st = CPIR_ERR_HIP;
+    }
+    if (tr) {
+      const double t_done = now_seconds();
+      srv->trace.batches++, srv->trace.batch_hist[k]++;
+      srv->trace.ns_gate += (uint64_t)((t_gate - t_staged) * 1e9), srv->trace.ns_enqueue += (uint64_t)((t_enq - t_gate) * 1e9);
+      srv->trace.ns_gpu += (uint64_t)((t_done - t_enq) * 1e9);
+    }
+    lk.lock();
+    a->status = st;
+    a->state = RespondArena::DONE;
+    srv->cv.notify_all();
+  } else {
+    srv->cv.wait(lk, [&] { return a->state == RespondArena::DONE; });
+    if (tr) srv->trace.ns_follow += (uint64_t)((now_seconds() - t_staged) * 1e9);
+  }
+  const int status = a->status;
+  lk.unlock();
+  const double t_out0 = tr ? now_seconds() : 0;
+  if (status == CPIR_OK) memcpy(r_out, a->r_pinned + seat * C, C * 4);
+  if (tr) {
+    srv->trace.calls++;
+    srv->trace.ns_seat += (uint64_t)((t_seated - t_enter) * 1e9), srv->trace.ns_stage += (uint64_t)((t_staged - t_seated) * 1e9);
+    srv->trace.ns_out += (uint64_t)((now_seconds() - t_out0) * 1e9);
+  }
+  lk.lock();
+  if (++a->left == a->joined) {  // last one out frees the arena
+    a->state = RespondArena::FREE;
+    a->joined = a->staged = a->left = 0;
+    srv->cv.notify_all();
+  }
+  return status;
+}
+
+int cpir_server_respond_bytes(const cpir_server* srv, const uint8_t* query, size_t query_len, uint8_t* response, size_t response_cap,
+                              size_t* response_len) {
+  if (!srv || !query || !response || !response_len) return CPIR_ERR_INVALID_ARGUMENT;
+  // Matrix::from_bytes (matrix.rs:973-1010)
+  if (query_len <= 8) return CPIR_ERR_FAILED_TO_DESERIALIZE_MATRIX;
+  uint32_t rows, cols;
+  memcpy(&rows, query, 4);
+  memcpy(&cols, query + 4, 4);
+  const uint64_t num = (uint64_t)rows * cols;
+  if (num == 0 || num * 4 != (uint64_t)(query_len - 8)) return CPIR_ERR_FAILED_TO_DESERIALIZE_MATRIX;
+  const uint32_t C = srv->layout.num_cols;
+  const size_t need = 8 + (size_t)C * 4;
+  if (response_cap < need) return CPIR_ERR_BUFFER_TOO_SMALL;
+  // query + 8 may be only byte-aligned; cpir_server_respond memcpy's from it, so no alignment is required here
+  std::vector<uint32_t> r(C);
+  CPIR_TRY(cpir_server_respond(srv, reinterpret_cast<const uint32_t*>(query + 8), rows, cols, r.data()));
+  const uint32_t one = 1;  // Matrix::to_bytes of the 1 x C response (matrix.rs:947-971)
+  memcpy(response, &one, 4);
+  memcpy(response + 4, &C, 4);
+  memcpy(response + 8, r.data(), (size_t)C * 4);
+  *response_len = need;
+  return CPIR_OK;
+}
+
+int cpir_server_respond_device(const cpir_server* srv, const uint32_t* q_dev, uint32_t* r_dev, uint32_t* scratch_dev, void* stream) {
+  if (!srv || !q_dev || !r_dev || !srv->shards.empty()) return CPIR_ERR_INVALID_ARGUMENT;  // device pointers belong to ONE device
+  DeviceGuard g(srv->dev->ordinal);
+  return launch_respond(srv->dev, srv->dtc, srv->layout, q_dev, srv->total_slots, srv->slot_offset, 1, 1, r_dev, scratch_dev,
+                        pick_stream(srv->dev, stream));
+}
+
+int cpir_server_respond_batch_device(const cpir_server* srv, const uint32_t* q_dev, uint32_t batch, uint32_t* r_dev, uint32_t* scratch_dev,
+                                     void* stream) {
+  if (!srv || !q_dev || !r_dev || batch == 0 || !srv->shards.empty()) return CPIR_ERR_INVALID_ARGUMENT;
+  DeviceGuard g(srv->dev->ordinal);
+  return respond_batched(srv->dev, srv->dtc, srv->layout, q_dev, srv->total_slots, srv->slot_offset, batch, r_dev, scratch_dev,
+                         pick_stream(srv->dev, stream));
+}
+
+
+}  // extern "C"

@@ -1,0 +1,157 @@
+// server_internal.hpp -- what the three host-side translation units of libchalamet_hip.so share: the Server handle (capi.hip: the extern "C"
+// boundary, devices, shapes, low-level operations; host_setup.hip: Server::setup; host_respond.hip: Server::respond on host buffers).
+#pragma once
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <list>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "cpir_internal.hpp"
+
+namespace cpir {
+
+// ---------------------------------------------------------------------------------------------------------------
+// Server handle
+// ---------------------------------------------------------------------------------------------------------------
+// Host callers of respond(&self) are COALESCED and PIPELINED (row f3 behind the thread-safe ABI; the reference serves an Arc<Server>
+// from many tokio tasks, examples/server.rs:45,55,85).  What a query costs on the host path is its upload (4.7 MB at 2^20 keys) more
+// than its kernel, so the front end is built around the host link:
+//   * a caller takes a seat in the OPEN arena (opening a free one if need be; the first one in is the arena's leader), copies its query
+//     into the arena's pinned block -- unless it already lies in page-locked memory -- and enqueues the upload on ONE upload stream
+//     shared by all arenas: queries cross the link one after the other, whole, in the order they were staged, so the first seats of an
+//     arena are in HBM early instead of every concurrent upload finishing at the same late moment;
+//   * the leader keeps its arena open until the device is free of the previous arena's launch (or the arena is full) and every seat
+//     taken so far is staged, then closes it and enqueues ONE batched respond for those seats on the run stream, behind the seats' upload
+//     events; callers that arrive later open the next arena and upload while this kernel runs;
+//   * a lone caller finds everything idle and is served without an upload at all: the step-major kernel reads every query word exactly
+//     once, so it reads them IN PLACE over the host link -- from the caller's buffer when that is page-locked, else from the arena's
+//     pinned block, which the caller's thread and the staging helpers fill in two halves, each half's steps launched as soon as it is
+//     in place.  (respond.host_zero_copy=0: upload first, as concurrent callers do.)
+struct RespondArena {
+  uint32_t* q_dev = nullptr;     // kSeats x total_slots u32
+  uint32_t* r_dev = nullptr;     // kSeats x C u32
+  uint32_t* q_pinned = nullptr;  // kSeats x total_slots u32
+  uint32_t* r_pinned = nullptr;  // kSeats x C u32
+  std::vector<hipEvent_t> seat_ev;  // upload of seat i has crossed the link
+  hipEvent_t done_ev = nullptr;     // the arena's responses are in r_pinned
+  const uint32_t* q_pinned_dev = nullptr;  // q_pinned as the device addresses it (a lone query is read in place)
+  uint32_t* fill_progress = nullptr;       // in the pinned block: steps of a lone query copied so far (the kernel polls it)
+  const uint32_t* fill_progress_dev = nullptr;
+  bool r0_zero = false;                    // seat 0 of r_dev holds zeros (guarded by the arena's own leader: one at a time)
+  // guarded by Server::mu
+  enum State { FREE, OPEN, LAUNCHED, DONE } state = FREE;
+  uint32_t joined = 0;  // seats taken
+  uint32_t staged = 0;  // seats whose upload is enqueued
+  uint32_t left = 0;    // seats whose caller has taken its response
+  int status = CPIR_OK; // outcome of the launch (shared by every seat)
+};
+
+struct Server {
+  std::atomic<int> refs{1};
+  Device* dev = nullptr;
+  cpir_dtc_layout layout{};
+  uint32_t* dtc = nullptr;  // device, layout.total_words u32
+  uint64_t slot_offset = 0;
+  uint64_t total_slots = 0;
+  double setup_timings[CPIR_SETUP_TIMING_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  // 3 arenas of 8 seats: a batch of up to 8 rides ONE stream of the database on the matrix cores (a respond kernel takes about as
+  // long for 8 queries as for 1, so throughput is batch size over kernel time); one arena is on the device, one is filling, one spare
+  static constexpr uint32_t kSeats = 8;
+  static constexpr uint32_t kArenas = 4;
+  // An arena takes its first kSpread callers freely; further callers prefer to open another arena (so that one arena's uploads overlap
+  // another's kernel: 8 concurrent callers split 4 + 4 instead of convoying) and fill seats kSpread.. only once no arena is free.
+  static constexpr uint32_t kSpread = 4;
+  // CPIR_RESPOND_TRACE=1: per-phase wall time of the host path, printed when the server is destroyed (diagnosis)
+  struct Trace {
+    std::atomic<uint64_t> calls{0}, solo{0}, ns_solo{0}, batches{0}, ns_seat{0}, ns_stage{0}, ns_gate{0}, ns_enqueue{0}, ns_gpu{0}, ns_follow{0}, ns_out{0};
+    std::atomic<uint64_t> batch_hist[9] = {};
+  } trace;
+  bool trace_on = false;
+  std::mutex mu;
+  std::condition_variable cv;
+  RespondArena arena[kArenas];  // each allocated on first use (a lone caller only ever needs the first)
+  bool streams_ready = false;
+  hipStream_t up_stream = nullptr;   // every query upload, FIFO
+  hipStream_t run_stream = nullptr;  // every batched respond + response download, FIFO
+  std::atomic<uint32_t> fill_aborts{0};  // lone queries whose polled launch gave up waiting for the copy (3: stop polling)
+  std::atomic<uint64_t> fill_polled{0};  // lone pageable queries answered by one launch polling the copy's progress
+  std::mutex upload_mu;              // one query's upload is enqueued at a time (whole queries, not interleaved pieces)
+  std::mutex launch_mu;              // one arena's launch sequence is enqueued at a time
+
+  // ---- group handle (cpir_server_setup_multi): the database is split along the filter slots over several devices of this
+  // process; `shards` then holds one ordinary server per device and this handle owns no packed database itself.  A host query is
+  // SCATTERED: device g receives only q[n_g : n_{g+1}] over its own host link, answers its shard, and the C-word partial
+  // responses are summed on the host (u32 wrap-around: order-independent, bit-identical to one device).
+  std::vector<Server*> shards;
+  struct GroupLane {  // per shard, per call context
+    hipStream_t stream = nullptr;
+    uint32_t *q_dev = nullptr, *r_dev = nullptr, *q_pinned = nullptr, *r_pinned = nullptr;
+  };
+  struct GroupCtx {
+    bool busy = false;
+    std::vector<GroupLane> lanes;
+  };
+  static constexpr int kGroupCtx = 4;  // concurrent callers served at once; further callers wait
+  GroupCtx gctx[kGroupCtx];
+  bool gctx_ready = false;
+  // one persistent host thread per shard does that shard's staging, enqueues and wait, so the per-device host work of a
+  // query (a few tens of microseconds each) runs side by side instead of adding up over the devices
+  struct GroupDone {  // on the caller's stack
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t remaining = 0;
+    int status = CPIR_OK;
+  };
+  struct GroupJob {
+    const uint32_t* q = nullptr;
+    GroupCtx* ctx = nullptr;
+    GroupDone* done = nullptr;
+  };
+  struct GroupWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<GroupJob> jobs;
+    bool stop = false;
+  };
+  std::vector<std::unique_ptr<GroupWorker>> workers;
+};
+
+
+inline double now_seconds() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// host_respond.hip
+void device_retain(Device* d);
+void device_release(Device* d);
+Server* server_new(Device* dev, const cpir_dtc_layout& L, uint64_t slot_offset, uint64_t total_slots);
+void server_destroy(Server* srv);
+// any batch size on device pointers: with batch fusion every pass answers up to 8 queries from one stream of the database, without it
+// every query is its own pass; either way the passes of one kind go into ONE launch
+int respond_batched(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len, uint64_t q_slot_offset,
+                    uint32_t batch, uint32_t* r, uint32_t* scratch, hipStream_t stream);
+
+// host_setup.hip
+// slots per shard are multiples of this: no packed word of either layout and no 16-byte query piece straddles two shards
+uint64_t shard_unit(const cpir_dtc_layout& L);
+struct DevBuf {  // scoped device allocation
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  void dispose_async(int ordinal);  // free in the background (on device `ordinal`) instead of at scope exit
+};
+
+}  // namespace cpir
+
+struct cpir_device : cpir::Device {};
+struct cpir_server : cpir::Server {};
+struct cpir_xof : cpir::TurboShake128 {};

@@ -21,7 +21,7 @@ from .server import Device, Server
 
 def shard_unit(layout) -> int:
     """Granularity of shard boundaries for a `cpir_dtc_layout`: lcm(slots_per_chunk, compression_factor) -- the same rule as
-    shard_unit() in csrc/capi.hip -- so that neither a chunk / super-tile of the device packing, nor a packed word of the reference's
+    shard_unit() in csrc/host_setup.hip -- so that neither a chunk / super-tile of the device packing, nor a packed word of the reference's
     representation (import / export), nor a 16-byte query load straddles two shards."""
     import ctypes
 
