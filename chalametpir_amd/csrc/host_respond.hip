@@ -447,8 +447,8 @@ extern "C" {
 // ---------------------------------------------------------------------------------------------------------------
 // A caller that found the server idle (it holds arena `a` alone, closed to others): no upload.  The step-major kernel reads each query
 // word once, so it reads them where they are: in the caller's buffer if that is page-locked and 16-byte aligned, else in the arena's
-// pinned block, filled in two halves by this thread and the staging helpers with each half's steps launched as soon as it is in place
-// (the second half is copied while the kernel works on the first).  The launches add up in r_dev, which is kept zeroed between uses.
+// pinned block, which this thread and the staging helpers fill front to back while the kernel -- launched FIRST -- waits for each step's
+// words (see below; two plain launches, each when its half is in place, if polling is off).  r_dev is kept zeroed between uses.
 static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32_t* r_out) {
   const size_t C = srv->layout.num_cols;
   const size_t q_lo = (size_t)srv->slot_offset, words = (size_t)srv->layout.num_slots;

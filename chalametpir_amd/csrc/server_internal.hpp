@@ -31,8 +31,8 @@ namespace cpir {
 //     events; callers that arrive later open the next arena and upload while this kernel runs;
 //   * a lone caller finds everything idle and is served without an upload at all: the step-major kernel reads every query word exactly
 //     once, so it reads them IN PLACE over the host link -- from the caller's buffer when that is page-locked, else from the arena's
-//     pinned block, which the caller's thread and the staging helpers fill in two halves, each half's steps launched as soon as it is
-//     in place.  (respond.host_zero_copy=0: upload first, as concurrent callers do.)
+//     pinned block, which the caller's thread and the staging helpers fill front to back WHILE the kernel, launched first, polls the
+//     copy's progress (respond_alone in host_respond.hip).  (respond.host_zero_copy=0: upload first, as concurrent callers do.)
 struct RespondArena {
   uint32_t* q_dev = nullptr;     // kSeats x total_slots u32
   uint32_t* r_dev = nullptr;     // kSeats x C u32
