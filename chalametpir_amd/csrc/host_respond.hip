@@ -576,14 +576,15 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
   bool solo = false;
   for (;;) {
     for (RespondArena& x : srv->arena)  // 1. an open arena that is still spreading
-      if (!a && x.state == RespondArena::OPEN && x.joined < Server::kSpread) a = &x;
+      if (!a && x.state == RespondArena::OPEN && x.joined < srv->spread()) a = &x;
     if (!a)
       for (RespondArena& x : srv->arena)  // 2. a free arena
         if (!a && x.state == RespondArena::FREE) {
           if (!x.q_dev) CPIR_TRY(arena_create(srv, x));
           a = &x, x.state = RespondArena::OPEN, x.status = CPIR_OK;
-          // nobody else is filling an arena or on the device: this caller is served alone, its query read in place
-          solo = read_once_ok;
+          // nobody else is filling an arena or on the device, and no company expected (with recent concurrent callers a lone launch
+          // would only split the batch they are about to form): this caller is served alone, its query read in place
+          solo = read_once_ok && srv->spread() == 1;
           for (const RespondArena& y : srv->arena)
             if (&y != a && (y.state == RespondArena::OPEN || y.state == RespondArena::LAUNCHED)) solo = false;
           if (solo) x.state = RespondArena::LAUNCHED;  // closed at once: later callers open the next arena and upload meanwhile
@@ -596,6 +597,7 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
   }
   const uint32_t seat = a->joined++;
   const bool leader = (seat == 0);
+  srv->caller_enters();
   lk.unlock();
   const double t_seated = tr ? now_seconds() : 0;
   if (solo) {
@@ -605,6 +607,7 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
       srv->trace.ns_seat += (uint64_t)((t_seated - t_enter) * 1e9), srv->trace.ns_solo += (uint64_t)((now_seconds() - t_seated) * 1e9);
     }
     lk.lock();
+    srv->inside--;
     a->state = RespondArena::FREE;
     a->joined = a->staged = a->left = 0;
     srv->cv.notify_all();
@@ -686,13 +689,30 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
   if (leader) {
     // launch when every seat taken so far is staged AND the device is free of the previous arena's launch (or this one is full);
     // callers keep joining until then
-    srv->cv.wait(lk, [&] {
+    // ... and, when the device is free right away, for a moment longer if company is expected (spread() callers make a batch and fewer
+    // have joined): callers that were answered together come back within tens of microseconds of each other, and the first one back
+    // would otherwise launch alone and leave the rest to the next pass (8 kB values, 8 callers: passes of 1 and 7 alternating).  The
+    // moment is a tenth of the kernel's time, at most 100 us.
+    const auto gate_ready = [&] {
       if (a->staged != a->joined) return false;
       if (a->joined == Server::kSeats) return true;
       for (const RespondArena& x : srv->arena)
         if (x.state == RespondArena::LAUNCHED) return false;
       return true;
-    });
+    };
+    const double window = srv->batching_window_seconds();
+    double t_ready = -1;  // when the gate was first found open (the moment counts from there, not from when this caller arrived:
+                          // the callers of the pass that has just finished are the company to wait for)
+    for (;;) {
+      if (!gate_ready()) {
+        srv->cv.wait(lk);
+        continue;
+      }
+      const double now = now_seconds();
+      if (t_ready < 0) t_ready = now;
+      if (a->joined >= srv->spread() || now - t_ready >= window) break;
+      srv->cv.wait_for(lk, std::chrono::duration<double>(window - (now - t_ready)));
+    }
     a->state = RespondArena::LAUNCHED;  // closed: later callers open the next arena
     srv->cv.notify_all();
     const uint32_t k = a->joined;
@@ -747,6 +767,7 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
     srv->trace.ns_out += (uint64_t)((now_seconds() - t_out0) * 1e9);
   }
   lk.lock();
+  srv->inside--;
   if (++a->left == a->joined) {  // last one out frees the arena
     a->state = RespondArena::FREE;
     a->joined = a->staged = a->left = 0;

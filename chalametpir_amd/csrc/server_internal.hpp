@@ -65,9 +65,40 @@ struct Server {
   // long for 8 queries as for 1, so throughput is batch size over kernel time); one arena is on the device, one is filling, one spare
   static constexpr uint32_t kSeats = 8;
   static constexpr uint32_t kArenas = 4;
-  // An arena takes its first kSpread callers freely; further callers prefer to open another arena (so that one arena's uploads overlap
-  // another's kernel: 8 concurrent callers split 4 + 4 instead of convoying) and fill seats kSpread.. only once no arena is free.
-  static constexpr uint32_t kSpread = 4;
+  // An arena takes its first spread() callers freely; further callers prefer to open another arena (so that one arena's uploads overlap
+  // another's kernel) and fill the seats beyond only once no arena is free.  With T callers recently seen inside respond at the same
+  // time, a kernel of K us (about the same for 1..4 queries) and u us of upload per query: two arenas of T/2 that alternate between
+  // uploading and computing cost max(2K/T, u) per query, one arena of T costs u + K/T -- so spread() is T/2 where K < T*u (2^20 keys x
+  // 1 kB: 8 callers 4 + 4, 4 callers 2 + 2 -- a fixed spread of 4 left four callers in 3 + 1: 7.0 instead of 8.0 k queries/s) and T where
+  // the kernel outweighs the uploads (8 kB values: 8 callers in ONE pass).  K and u are estimated from the layout: resident bytes at
+  // 6.8 TB/s, query bytes at 55 GB/s + 15 us.
+  uint32_t inside = 0, peak_inside = 1, calls_below_peak = 0;  // guarded by mu
+  void caller_enters() {
+    inside++;
+    if (inside >= peak_inside) {
+      peak_inside = inside, calls_below_peak = 0;
+    } else if (++calls_below_peak >= 8) {  // the peak decays when the callers have gone: one step per 8 calls below it
+      peak_inside = inside > peak_inside - 1 ? inside : peak_inside - 1, calls_below_peak = 0;
+    }
+  }
+  bool kernel_outweighs_uploads() const {  // K >= T * u: one arena for all recent callers
+    const double k_us = (double)layout.total_words * 4 / 6.8e6, u_us = (double)layout.num_slots * 4 / 55e3 + 15;
+    return k_us >= peak_inside * u_us;
+  }
+  // how long a leader whose gate is open waits for the company spread() promises: only where one pass is to answer ALL recent callers
+  // (they come back within tens of microseconds of each other, and the first one back would otherwise launch alone: 8 kB values, 4
+  // callers: passes of 1 and 3 alternating, 1 270 queries/s; with the moment's wait passes of 4, 1 960).  A tenth of the kernel's time, at
+  // most 100 us.  Where two arenas alternate the device is busy when a leader is ready, which is wait enough (and waiting on top of it
+  // cost 3 callers at 2^20 keys x 1 kB a fifth of their throughput).
+  double batching_window_seconds() const {
+    if (!kernel_outweighs_uploads()) return 0;
+    const double w = (double)layout.total_words * 4 / 6.8e12 * 0.1;
+    return w < 100e-6 ? w : 100e-6;
+  }
+  uint32_t spread() const {
+    const uint32_t s = kernel_outweighs_uploads() ? peak_inside : (peak_inside + 1) / 2;
+    return s < 1 ? 1 : (s > kSeats ? kSeats : s);
+  }
   // CPIR_RESPOND_TRACE=1: per-phase wall time of the host path, printed when the server is destroyed (diagnosis)
   struct Trace {
     std::atomic<uint64_t> calls{0}, solo{0}, ns_solo{0}, batches{0}, ns_seat{0}, ns_stage{0}, ns_gate{0}, ns_enqueue{0}, ns_gpu{0}, ns_follow{0}, ns_out{0};
