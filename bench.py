@@ -590,6 +590,8 @@ def host_path_timing(server, q_pool, N, torch):
         "one_caller_queries_per_sec": round(1.0 / lat, 1),
         "one_caller_pinned_query_us_per_query": round(lat_pinned * 1e6, 1),
         "one_caller_pinned_query_upload_first_us_per_query": round(lat_pinned_upload * 1e6, 1),
+        "four_callers_queries_per_sec": round(throughput(4, 64, False), 1),
+        "four_callers_pinned_queries_per_sec": round(throughput(4, 64, True), 1),
         "eight_callers_queries_per_sec": round(throughput(8, 48, False), 1),
         "eight_callers_pinned_queries_per_sec": round(throughput(8, 48, True), 1),
         "sixteen_callers_queries_per_sec": round(throughput(16, 24, False), 1),
