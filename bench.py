@@ -394,6 +394,22 @@ def main() -> int:
         cp.tuning_set("respond.batch_fusion", 1)  # the library's own default: coalesced callers share one stream of the database
         result["respond_host_path"] = host_path_timing(sharded.local, q_pool, N, torch)
         cp.tuning_set("respond.batch_fusion", 0)
+    # the same host path from plain C threads (examples/host_respond_bench.c, built by the Makefile): what a caller without an interpreter
+    # sees.  A child process with a deadline, after this process's own host-path timing: an optional extra that can never take the
+    # headline down with it.
+    if world == 1 and not args.no_host_path and args.config in ("cfg2", "cfg3", "cfg5", "cfg1"):
+        exe = os.path.join(ROOT, "chalametpir_amd", "lib", "host_respond_bench")
+        if os.path.exists(exe):
+            import subprocess
+
+            try:
+                cp_run = subprocess.run([exe, str(n_keys.bit_length() - 1), str(value_bytes), str(arity)], capture_output=True, text=True, timeout=120)
+                if cp_run.returncode == 0:
+                    result["respond_host_path_native"] = json.loads(cp_run.stdout.strip().splitlines()[-1])
+                else:
+                    log(f"host_respond_bench failed (rc {cp_run.returncode}): {cp_run.stderr[-300:]}")
+            except Exception as exc:  # noqa: BLE001
+                log(f"host_respond_bench skipped: {exc}")
     if world == 1 and not args.no_host_path:
         n_vis = torch.cuda.device_count()
         k = args.group_shards or (n_vis if n_vis >= 2 else 0)
