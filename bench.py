@@ -443,12 +443,20 @@ def main() -> int:
             result.update(setup_kv_timing(cp, device, n_keys, arity, value_bytes))
 
     if world > 1 and not args.no_setup:
-        extra = setup_timing_sharded(cp, device, torch, dist, N, C, b, mask, lo, hi, rank, stream, full_layout)
+        # (an exception here -- not a hang -- must not cost the headline line: it is reported in the line instead)
+        try:
+            extra = setup_timing_sharded(cp, device, torch, dist, N, C, b, mask, lo, hi, rank, stream, full_layout)
+        except Exception as exc:  # noqa: BLE001
+            log(f"rank {rank}: sharded setup timing failed: {exc!r}")
+            extra = {"server_setup_error": repr(exc)}
         if rank == 0:
             result.update(extra)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as exc:  # noqa: BLE001
+            log(f"rank {rank}: process group teardown: {exc!r}")
     if rank == 0:
         print(json.dumps(result), flush=True)
     return 0
