@@ -1,4 +1,4 @@
-"""world_size-2 and -3 gloo runs of the N-sharding + integer-sum exchange (the multi-GPU path of SURVEY.md 8e), on CPU."""
+"""world_size-2, -3 and -8 gloo runs of the N-sharding + integer-sum exchange (the multi-GPU path of SURVEY.md 8e), on CPU."""
 import os
 import subprocess
 import sys
@@ -30,7 +30,7 @@ def test_shard_range_properties():
         shard_range(10, 3 * 1024, 2, 2)
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_exchange_under_gloo(world, orc):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     port = 29511 + world
