@@ -137,6 +137,8 @@ def build(force: bool = False) -> str:
     if force:
         subprocess.run(["make", "-C", CSRC_DIR, "clean"], check=True, stdout=subprocess.DEVNULL)
     subprocess.run(["make", "-C", CSRC_DIR, "-j8", "-s"], check=True)
+    # bench-only tools (hbm_read_ceiling, host_respond_bench): their failure must not fail the library build
+    subprocess.run(["make", "-C", CSRC_DIR, "-j8", "-s", "-k", "tools"], check=False)
     return LIB_PATH
 
 

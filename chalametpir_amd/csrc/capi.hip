@@ -3,6 +3,12 @@
 // Server::respond on host buffers in host_respond.hip (reference chalametpir_server/src/server.rs:47-78, 103-167, 184-190).
 #include "server_internal.hpp"
 
+#include <execinfo.h>
+#include <signal.h>
+#include <sys/prctl.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
 namespace cpir {
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -15,6 +21,46 @@ void set_last_hip_error(hipError_t e, const char* what, const char* file, int li
   (void)hipGetLastError();  // clear the sticky per-thread error so later calls report their own failures
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// CPIR_ABORT_BACKTRACE=1 (read when the library is loaded): on SIGABRT print which thread aborted and its native stack to fd 2, then
+// hand over to the handler that was installed before (Python's faulthandler, or the default action).  An abort() raised by the
+// runtime's own threads (a GPU memory fault reported by ROCr, a failed runtime assertion, glibc's heap checks) otherwise leaves no
+// trace of WHERE it came from.  Diagnosis only; the test suite switches it on (tests/conftest.py).
+// ---------------------------------------------------------------------------------------------------------------
+static struct sigaction g_prev_abort;
+static void abort_backtrace_handler(int sig, siginfo_t* info, void* uctx) {
+  char name[32] = "?";
+  (void)prctl(PR_GET_NAME, name, 0, 0, 0);
+  char line[160];
+  const int n = snprintf(line, sizeof(line), "\n[cpir] SIGABRT on thread '%s' (tid %ld, pid %ld); native stack:\n", name,
+                         (long)syscall(SYS_gettid), (long)getpid());
+  if (n > 0) (void)!write(2, line, (size_t)n);
+  void* frames[64];
+  const int depth = backtrace(frames, 64);
+  backtrace_symbols_fd(frames, depth, 2);
+  (void)!write(2, "[cpir] end of native stack\n", 27);
+  if ((g_prev_abort.sa_flags & SA_SIGINFO) && g_prev_abort.sa_sigaction) {
+    g_prev_abort.sa_sigaction(sig, info, uctx);
+  } else if (g_prev_abort.sa_handler != SIG_DFL && g_prev_abort.sa_handler != SIG_IGN && g_prev_abort.sa_handler) {
+    g_prev_abort.sa_handler(sig);
+  }
+  signal(SIGABRT, SIG_DFL);  // (the previous handler normally re-raises by itself)
+  raise(SIGABRT);
+}
+
+__attribute__((constructor)) static void install_abort_backtrace() {
+  const char* on = getenv("CPIR_ABORT_BACKTRACE");
+  if (!on || on[0] != '1') return;
+  void* warm[4];
+  (void)backtrace(warm, 4);  // loads libgcc's unwinder now, not inside the handler
+  struct sigaction sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.sa_sigaction = abort_backtrace_handler;
+  sa.sa_flags = SA_SIGINFO | SA_NODEFER;
+  sigemptyset(&sa.sa_mask);
+  (void)sigaction(SIGABRT, &sa, &g_prev_abort);
+}
 
 static bool has_device(int* count) {
   int n = 0;

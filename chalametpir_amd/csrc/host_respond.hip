@@ -60,6 +60,7 @@ class StagingHelpers {
 
  private:
   void run() {
+    (void)pthread_setname_np(pthread_self(), "cpir-stage");
     for (;;) {
       Job j;
       {
@@ -283,6 +284,7 @@ static int group_shard_respond(const Server* child, Server::GroupLane& l, const 
 static void group_worker_main(Server* srv, size_t g) {
   Server::GroupWorker& w = *srv->workers[g];
   const Server* child = srv->shards[g];
+  (void)pthread_setname_np(pthread_self(), "cpir-group");
   (void)hipSetDevice(child->dev->ordinal);  // this thread only ever talks to its shard's device
   const uint32_t C = srv->layout.num_cols;
   for (;;) {

@@ -31,6 +31,7 @@ class BackgroundDisposer {
     }
     auto done = std::make_shared<std::atomic<bool>>(false);
     jobs_.push_back(Job{std::thread([f = std::move(f), done] {
+                          (void)pthread_setname_np(pthread_self(), "cpir-dispose");
                           f();
                           done->store(true, std::memory_order_release);
                         }),
@@ -114,6 +115,7 @@ class PublicMatrixUpload {
     for (int i = 0; i < 2; i++) CPIR_HIP_TRY(hipHostMalloc(&pinned_[i], (size_t)rows_per_block_ * N_ * 4, hipHostMallocPortable));
     memcpy(seed_, seed, 32);
     worker_ = std::thread([this] {
+      (void)pthread_setname_np(pthread_self(), "cpir-xof");
       const int st = run();
       std::lock_guard<std::mutex> lk(prog_mu_);
       status_ = st, run_done_ = true;

@@ -6,6 +6,10 @@ import pytest
 # idle OpenMP workers of the oracle must sleep, not spin (a GPU box gives the container a CPU quota far below the CPUs it shows);
 # has to be in the environment before libgomp is loaded
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+# an abort() raised on one of the runtime's own threads (ROCr reporting a GPU memory fault, a runtime assertion) says which thread and
+# from where (capi.hip: install_abort_backtrace); read when the library is loaded.  pytest.ini's --capture=sys keeps fd 2 uncaptured,
+# so that text -- and ROCr's own message in front of it -- reaches the log of whoever runs the suite.
+os.environ.setdefault("CPIR_ABORT_BACKTRACE", "1")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
