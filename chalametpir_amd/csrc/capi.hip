@@ -23,18 +23,20 @@ void set_last_hip_error(hipError_t e, const char* what, const char* file, int li
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// CPIR_ABORT_BACKTRACE=1 (read when the library is loaded): on SIGABRT print which thread aborted and its native stack to fd 2, then
+// CPIR_ABORT_BACKTRACE=1 (read when the library is loaded): on SIGABRT / SIGSEGV / SIGBUS print which thread aborted and its native stack to fd 2, then
 // hand over to the handler that was installed before (Python's faulthandler, or the default action).  An abort() raised by the
 // runtime's own threads (a GPU memory fault reported by ROCr, a failed runtime assertion, glibc's heap checks) otherwise leaves no
 // trace of WHERE it came from.  Diagnosis only; the test suite switches it on (tests/conftest.py).
 // ---------------------------------------------------------------------------------------------------------------
-static struct sigaction g_prev_abort;
+static struct sigaction g_prev_fatal[NSIG];
 static void abort_backtrace_handler(int sig, siginfo_t* info, void* uctx) {
+  const struct sigaction g_prev_abort = g_prev_fatal[sig];
   char name[32] = "?";
   (void)prctl(PR_GET_NAME, name, 0, 0, 0);
   char line[160];
-  const int n = snprintf(line, sizeof(line), "\n[cpir] SIGABRT on thread '%s' (tid %ld, pid %ld); native stack:\n", name,
-                         (long)syscall(SYS_gettid), (long)getpid());
+  const int n = snprintf(line, sizeof(line), "\n[cpir] signal %d (%s) on thread '%s' (tid %ld, pid %ld), fault address %p; native stack:\n", sig,
+                         sig == SIGABRT ? "SIGABRT" : sig == SIGSEGV ? "SIGSEGV" : sig == SIGBUS ? "SIGBUS" : "fatal", name,
+                         (long)syscall(SYS_gettid), (long)getpid(), info ? info->si_addr : nullptr);
   if (n > 0) (void)!write(2, line, (size_t)n);
   void* frames[64];
   const int depth = backtrace(frames, 64);
@@ -45,8 +47,8 @@ static void abort_backtrace_handler(int sig, siginfo_t* info, void* uctx) {
   } else if (g_prev_abort.sa_handler != SIG_DFL && g_prev_abort.sa_handler != SIG_IGN && g_prev_abort.sa_handler) {
     g_prev_abort.sa_handler(sig);
   }
-  signal(SIGABRT, SIG_DFL);  // (the previous handler normally re-raises by itself)
-  raise(SIGABRT);
+  signal(sig, SIG_DFL);  // (the previous handler normally re-raises by itself)
+  raise(sig);
 }
 
 __attribute__((constructor)) static void install_abort_backtrace() {
@@ -59,7 +61,7 @@ __attribute__((constructor)) static void install_abort_backtrace() {
   sa.sa_sigaction = abort_backtrace_handler;
   sa.sa_flags = SA_SIGINFO | SA_NODEFER;
   sigemptyset(&sa.sa_mask);
-  (void)sigaction(SIGABRT, &sa, &g_prev_abort);
+  for (int sig : {SIGABRT, SIGSEGV, SIGBUS}) (void)sigaction(sig, &sa, &g_prev_fatal[sig]);
 }
 
 static bool has_device(int* count) {

@@ -281,8 +281,10 @@ static int group_shard_respond(const Server* child, Server::GroupLane& l, const 
   return status;
 }
 
-static void group_worker_main(Server* srv, size_t g) {
-  Server::GroupWorker& w = *srv->workers[g];
+// (the worker is handed its own GroupWorker: srv->workers is still growing while the first threads start, and reading the vector from
+// here raced with its reallocation -- found by MALLOC_PERTURB_, which fills the freed storage)
+static void group_worker_main(Server* srv, Server::GroupWorker* worker, size_t g) {
+  Server::GroupWorker& w = *worker;
   const Server* child = srv->shards[g];
   (void)pthread_setname_np(pthread_self(), "cpir-group");
   (void)hipSetDevice(child->dev->ordinal);  // this thread only ever talks to its shard's device
@@ -326,10 +328,9 @@ static int group_ctx_create(Server* srv) {
       l.r_pinned = l.q_pinned + qw;
     }
   }
-  for (size_t g = 0; g < srv->shards.size(); g++) {
-    srv->workers.emplace_back(new Server::GroupWorker);
-    srv->workers.back()->th = std::thread(group_worker_main, srv, g);
-  }
+  srv->workers.reserve(srv->shards.size());
+  for (size_t g = 0; g < srv->shards.size(); g++) srv->workers.emplace_back(new Server::GroupWorker);
+  for (size_t g = 0; g < srv->shards.size(); g++) srv->workers[g]->th = std::thread(group_worker_main, srv, srv->workers[g].get(), g);
   srv->gctx_ready = true;
   return CPIR_OK;
 }
