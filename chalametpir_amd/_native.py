@@ -67,6 +67,7 @@ SIGNATURES = {
     "cpir_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(vp)]),
     "cpir_host_free": (None, [vp]),
     "cpir_tuning_set": (C.c_int, [C.c_char_p, C.c_int]),
+    "cpir_tuning_reset": (None, []),
     "cpir_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "cpir_device_open": (C.c_int, [C.c_int, C.POINTER(vp)]),
     "cpir_device_close": (None, [vp]),

@@ -108,11 +108,13 @@ void device_release(Device* d) {
 }
 
 // Where the device may read [p, p + bytes) of host memory in place (a DMA straight from the caller's buffer, or a kernel reading a lone
-// query where it lies): the device address of p if BOTH ends of the range are page-locked memory the runtime has mapped, at the same distance from each other as on the host (one mapping, or mappings laid end to end); NULL
-// otherwise (pageable memory, a registration that covers only part of the buffer).  Only a NO is remembered (per thread, for the last
-// buffer asked about: a server loop hands over the same pageable buffer again and again, and a stale no merely stages a buffer that has
-// been registered since); a yes is asked again every call, because a stale yes -- the buffer unregistered in between -- would let the
-// device read unmapped host pages.
+// query where it lies): the device address of p if the WHOLE range lies inside ONE page-locked allocation / registration the runtime has
+// mapped; NULL otherwise (pageable memory, a registration that covers only part of the buffer, two registrations that merely touch).
+// The runtime is asked for the extent of the allocation that holds p (range start + size); where it cannot tell, both ends of the range
+// are looked up instead and must belong to mappings laid end to end.  Only a NO is remembered (per thread, for the last buffer asked
+// about: a server loop hands over the same pageable buffer again and again, and a stale no merely stages a buffer that has been
+// registered since); a yes is asked again every call, because a stale yes -- the buffer unregistered in between -- would let the device
+// read unmapped host pages.
 static const void* pinned_range_device_pointer(const void* p, size_t bytes) {
   struct Last {
     const char* lo = nullptr;
@@ -123,11 +125,28 @@ static const void* pinned_range_device_pointer(const void* p, size_t bytes) {
   const char* c = static_cast<const char*>(p);
   if (last.lo == c && last.bytes == bytes && last.dev == nullptr) return nullptr;
   const void* dev = nullptr;
-  hipPointerAttribute_t lo_attr, hi_attr;
-  if (bytes > 0 && hipPointerGetAttributes(&lo_attr, c) == hipSuccess && hipPointerGetAttributes(&hi_attr, c + bytes - 1) == hipSuccess) {
-    if (lo_attr.type == hipMemoryTypeHost && hi_attr.type == hipMemoryTypeHost && lo_attr.devicePointer && hi_attr.devicePointer &&
-        static_cast<const char*>(hi_attr.devicePointer) - static_cast<const char*>(lo_attr.devicePointer) == (ptrdiff_t)(bytes - 1))
-      dev = lo_attr.devicePointer;
+  hipPointerAttribute_t lo_attr;
+  if (bytes > 0 && hipPointerGetAttributes(&lo_attr, c) == hipSuccess && lo_attr.type == hipMemoryTypeHost && lo_attr.devicePointer) {
+    const char* dp = static_cast<const char*>(lo_attr.devicePointer);
+    void* range_start = nullptr;
+    size_t range_size = 0;
+    hipPointer_attribute which[2] = {HIP_POINTER_ATTRIBUTE_RANGE_START_ADDR, HIP_POINTER_ATTRIBUTE_RANGE_SIZE};
+    void* out[2] = {&range_start, &range_size};
+    if (hipDrvPointerGetAttributes(2, which, out, reinterpret_cast<hipDeviceptr_t>(const_cast<char*>(c))) == hipSuccess && range_start && range_size) {
+      // the start is reported in the address space the allocation was made in: the host's for registered / hipHostMalloc'ed memory
+      const char* rs = static_cast<const char*>(range_start);
+      const bool host_side = rs <= c && c + bytes <= rs + range_size;
+      const bool dev_side = rs <= dp && dp + bytes <= rs + range_size;
+      if (host_side || dev_side) dev = dp;
+    } else {
+      (void)hipGetLastError();
+      hipPointerAttribute_t hi_attr;
+      if (hipPointerGetAttributes(&hi_attr, c + bytes - 1) == hipSuccess && hi_attr.type == hipMemoryTypeHost && hi_attr.devicePointer &&
+          static_cast<const char*>(hi_attr.devicePointer) - dp == (ptrdiff_t)(bytes - 1))
+        dev = dp;
+      else
+        (void)hipGetLastError();
+    }
   } else {
     (void)hipGetLastError();  // ordinary pageable memory: not an error worth keeping
   }
@@ -188,7 +207,9 @@ static int arena_create(Server* srv, RespondArena& a) {
     srv->streams_ready = true;
   }
   if ((e = hipMalloc(&a.q_dev, (qw + rw) * 4)) != hipSuccess) return fail(e, "hipMalloc(respond arena)");
-  if ((e = hipHostMalloc(&a.q_pinned, (qw + rw) * 4, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc(respond arena)");
+  // COHERENT (fine-grained) on purpose, whatever HIP_HOST_COHERENT says: a polled launch reads the fill progress and the query words
+  // while the host is still writing them (respond_alone), which only works on memory the device does not cache
+  if ((e = hipHostMalloc(&a.q_pinned, (qw + rw) * 4, hipHostMallocCoherent)) != hipSuccess) return fail(e, "hipHostMalloc(respond arena)");
   a.r_dev = a.q_dev + qw, a.r_pinned = a.q_pinned + qw;
   {
     void* dp = nullptr;
@@ -475,10 +496,14 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
   } else if (e == hipSuccess) {
     uint32_t* const qp = a->q_pinned;  // seat 0; same offsets as the caller's buffer
     constexpr size_t kJob = (size_t)1 << 16;  // 256 KiB of u32, a multiple of the kernel's 512-slot step
+    static_assert(kJob % CPIR_PLANAR_SLOTS_PER_TILE == 0, "a copy job must end on a step boundary: the kernel is told whole steps");
     constexpr size_t kStepsPerJob = kJob / CPIR_PLANAR_SLOTS_PER_TILE;
     constexpr size_t kMaxJobs = 512;
     const size_t n_jobs = (words + kJob - 1) / kJob;
-    const uint32_t fill_timeout_us = respond_host_fill_timeout_us();
+    // how long a wave waits for the words of a step (the tuning value, default 2 ms), but never less than the whole copy would take at
+    // 5 GB/s -- a quarter of what ONE core copies: the last steps of a long query are legitimately waited for that long
+    uint32_t fill_timeout_us = respond_host_fill_timeout_us();
+    if (fill_timeout_us > 0 && words * 4 / 5000 > fill_timeout_us) fill_timeout_us = (uint32_t)(words * 4 / 5000);
     if (words >= ((size_t)1 << 19) && n_jobs <= kMaxJobs && g_staging.try_acquire()) {
       std::atomic<int> done[kMaxJobs];
       // ONE launch, in front of the copy: the kernel takes the steps of q round-robin (front to back over the whole grid) and waits
@@ -487,7 +512,9 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
       // is then answered again from the (by then complete) pinned block -- a launch that cannot start before this thread moves on
       // (synchronous launches under a debugger or a serialising profiler) costs that timeout once, and after three such launches the
       // server stops polling and launches each half of the query when it is in place.
-      polled = fill_timeout_us > 0 && srv->fill_aborts.load(std::memory_order_relaxed) < 3;
+      // (no 128-byte line of the pinned block may straddle two copy jobs -- a wave that has seen job i's count could otherwise fetch a
+      // line whose tail belongs to job i + 1: the shard must start on a line boundary, which every shard_unit() multiple does)
+      polled = fill_timeout_us > 0 && srv->fill_aborts.load(std::memory_order_relaxed) < 3 && (q_lo * 4) % 128 == 0;
       if (polled) {
         publish_fill_progress(a->fill_progress, 0u);
         const PlanarHostFill fill{a->fill_progress_dev, a->r_dev + C, fill_timeout_us};
@@ -552,7 +579,14 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
     if (e == hipSuccess)
       rc = launch_respond_read_once(srv->dev, srv->dtc, srv->layout, a->q_pinned_dev, srv->total_slots, srv->slot_offset, a->r_dev, st);
   }
-  if (polled) srv->fill_polled.fetch_add(1, std::memory_order_relaxed);
+  if (polled) {
+    srv->fill_polled.fetch_add(1, std::memory_order_relaxed);
+    // a launch that kept up pays back one that did not: three void launches IN A ROW (a host that cannot feed the kernel: synchronous
+    // launches, a throttled CPU quota) switch polling off, a stall now and then does not
+    uint32_t n = srv->fill_aborts.load(std::memory_order_relaxed);
+    while (n > 0 && n < 3 && !srv->fill_aborts.compare_exchange_weak(n, n - 1, std::memory_order_relaxed)) {
+    }
+  }
   if (rc == CPIR_OK && e != hipSuccess) {
     set_last_hip_error(e, "respond (query read in place)", __FILE__, __LINE__);
     rc = CPIR_ERR_HIP;

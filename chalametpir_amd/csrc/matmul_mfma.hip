@@ -816,11 +816,19 @@ int launch_mat_x_mat_mfma(const Device* dev, const uint32_t* A, uint64_t lda, co
   return launch_product(dev, a, colsum, accumulate, stream);
 }
 
+// the hand-pipelined kernel is on and can address a row tile of A (and the k-steps of the right-hand side) with 32-bit byte offsets:
+// with lda = N that is N < 2^23 slots.  Asked BEFORE a path is chosen (setup falls back to the split right-hand side or the VALU
+// matmul), and again by launch_product.
+static bool mfma_pipe_addressable(uint64_t lda, uint64_t inner) {
+  const uint64_t ks = (inner + kBK - 1) / kBK;
+  return mfma_pipeline() != 0 && ((uint64_t)(kBM - 1) * lda + inner) * 4 < (1ull << 32) && ks * 2048 + 2048 < (1ull << 32);
+}
+
 bool mfma_planar_rhs_applicable(const uint32_t* A, uint64_t lda, const cpir_dtc_layout& L) {
   // the image must hold at least one bit plane (b >= 9; below that the high-byte plane does not exist), the hand-pipelined kernel must
   // be on and able to address everything with 32-bit byte offsets
   const uint64_t ks512 = (L.num_slots + CPIR_PLANAR_SLOTS_PER_TILE - 1) / CPIR_PLANAR_SLOTS_PER_TILE;
-  return L.packing == CPIR_PACK_PLANAR && L.mat_elem_bit_len >= 9 && mfma_pipeline() != 0 &&
+  return L.packing == CPIR_PACK_PLANAR && L.mat_elem_bit_len >= 9 && mfma_pipe_addressable(lda, L.num_slots) &&
          mfma_matmul_applicable(A, lda, L.num_slots, L.num_cols, 16) && ks512 * (L.chunk_words / 4) * 16 + (1u << 20) < (1ull << 32);
 }
 
@@ -864,11 +872,11 @@ static int launch_product(const Device* dev, MfmaArgs& a, const uint32_t* colsum
   a.S = (uint32_t)(S ? S : 1);
   a.ablate = (uint32_t)mfma_ablate();
 
+  // the hand-pipelined kernel addresses a row tile of A with 32-bit byte offsets
+  const bool pipe = mfma_pipe_addressable(lda, inner);
+  if (!pipe && a.lo_tiles) return CPIR_ERR_INVALID_ARGUMENT;  // only the pipelined kernel reads the planar image (callers ask mfma_planar_rhs_applicable first)
   CPIR_HIP_TRY(hipMemsetAsync(a.rowsum, 0, 4 * round_up((uint32_t)rows, kBM), stream));
   if (!accumulate) CPIR_HIP_TRY(hipMemset2DAsync(M, ldm * sizeof(uint32_t), 0, cols * sizeof(uint32_t), rows, stream));
-  // the hand-pipelined kernel addresses a row tile of A with 32-bit byte offsets
-  const bool pipe = mfma_pipeline() != 0 && ((uint64_t)(kBM - 1) * lda + inner) * 4 < (1ull << 32) && (uint64_t)a.KS * 2048 + 2048 < (1ull << 32);
-  if (!pipe && a.lo_tiles) return CPIR_ERR_INVALID_ARGUMENT;  // only the pipelined kernel reads the planar image
   if (pipe && a.lo_tiles) hipLaunchKernelGGL(mat_x_mat_mfma_pipe_kernel<true>, dim3(grid), dim3(kMT), 0, stream, a);
   else if (pipe) hipLaunchKernelGGL(mat_x_mat_mfma_pipe_kernel<false>, dim3(grid), dim3(kMT), 0, stream, a);
   else hipLaunchKernelGGL(mat_x_mat_mfma_kernel, dim3(grid), dim3(kMT), 0, stream, a);

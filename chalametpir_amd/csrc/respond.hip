@@ -294,7 +294,7 @@ struct Tuning {
   int interleave_passes = -1;  // order of the passes of one launch: 0 slice order, 1 interleaved, -1 by shard size
   int planar_blocks_per_cu = 0;  // the matrix-core kernel (respond_planar.hip): 0 = by pass order (2 streaming, 3 sharing)
   int multi_pass_limit_mb = 2560;  // unfused batches: databases above this size get one launch per query
-  int host_fill_timeout_us = 20000;  // a lone pageable host query: ONE launch polling the copy's progress, each wave for at most this long (0: off)
+  int host_fill_timeout_us = 2000;  // a lone pageable host query: ONE launch polling the copy's progress, each wave for at most this long (0: off)
   int host_zero_copy = 1;          // a lone host query is read by the kernel in place (page-locked memory), not uploaded first
   int ks_major = 1;                // the step-major matrix-core kernel: 0 never, 1 fused batches + lone launches, 2 wherever it applies
 };
@@ -391,6 +391,17 @@ extern "C" int cpir_tuning_set(const char* key, int value) {
     return CPIR_ERR_INVALID_ARGUMENT;
   }
   return CPIR_OK;
+}
+
+// every key back to the default it had when the library was loaded (a test suite that flips keys must not leak them into later tests)
+extern "C" void cpir_tuning_reset(void) {
+  std::lock_guard<std::mutex> lk(g_tuning_mu);
+  g_tuning = Tuning{};
+  set_default_dense(true);
+  set_default_planar(true);
+  set_mfma_matmul(true);
+  set_mfma_pipeline(1);
+  set_mfma_ablate(0);
 }
 
 uint64_t respond_multi_pass_limit_bytes() {

@@ -393,6 +393,9 @@ respond_planar_ks_kernel(const PlanarArgs a) {
       }
       __builtin_amdgcn_s_sleep(64);  // ~2 us between polls of a wave: a poll is a 64-byte read over the host link
     }
+    // the query words of the step are fetched AFTER this point, in program order: nothing may be hoisted above the loop (the control
+    // dependency already orders the hardware's requests; this pins the compiler).  Wavefront scope: no cache maintenance is emitted.
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
   const uint32_t half = lane >> 5, l32 = lane & 31;
   auto a_issue = [&](uint4(&raw)[2 * NS], uint32_t ks_, uint32_t pass_) {

@@ -258,6 +258,11 @@ def tuning_set(key: str, value: int) -> None:
     _check(_native.load().cpir_tuning_set(key.encode(), int(value)))
 
 
+def tuning_reset() -> None:
+    """every tuning key back to its default (cpir_tuning_reset)"""
+    _native.load().cpir_tuning_reset()
+
+
 class _FlatKvDb:
     """HashMap<&[u8], &[u8]> flattened into the cpir_kv_db arrays (iteration order of the mapping = key order)."""
 

@@ -253,7 +253,7 @@ int cpir_op_synth_fill(cpir_device* dev, uint32_t* out, uint64_t count, uint64_t
  *   (1, the default: cpir_server_respond serves a caller that finds the server idle without an upload, the kernel reading the
  *   query in place from page-locked host memory; 0: always stage + upload first), "respond.host_fill_timeout_us" 0..1000000
  *   (a lone PAGEABLE query of 2^19+ words: one launch in front of the copy into pinned memory, every wave waiting at most this long
- *   in all for the words it needs -- default 20000; 0: two launches, each when its half of the query is in place), "matmul.mfma" {0,1} (1, the default:
+ *   for the words of a step -- default 2000, raised to what copying the whole query takes at 5 GB/s; 0: two launches, each when its half of the query is in place), "matmul.mfma" {0,1} (1, the default:
  *   cpir_op_mat_x_mat and the setup paths run right-hand sides below 2^16 on the i8 matrix cores; 0: on the integer VALU),
  *   "matmul.pipeline" {0,1} (1, the default: the software-pipelined matrix-core kernel; 0: its first cut),
  *   "matmul.ablate" (diagnosis only, results are WRONG while it is non-zero: bit mask of parts of the matrix-core matmul to skip),
@@ -262,6 +262,8 @@ int cpir_op_synth_fill(cpir_device* dev, uint32_t* out, uint64_t count, uint64_t
  *   offered and enabled, else dense64 where offered and enabled, else the reference packing).
  * Process-wide; results are bit-identical for every setting. */
 int cpir_tuning_set(const char* key, int value);
+/* Every key back to its default (what a test harness calls between tests: the knobs are process-wide state). */
+void cpir_tuning_reset(void);
 /* Name of the dominant kernel last launched by cpir_op_respond for this layout (for matching rocprof traces). */
 const char* cpir_respond_kernel_name(const cpir_dtc_layout* layout);
 

@@ -55,3 +55,14 @@ def device(native):
     except ImportError:
         pass
     return cp.Device(0)
+
+
+@pytest.fixture(autouse=True)
+def _tuning_defaults_between_tests(request):
+    """the library's tuning keys are process-wide: whatever a test (or a fixture of its module) flipped is put back to the defaults
+    after it, so that no test depends on which tests ran before it.  (Only for tests that load the library anyway.)"""
+    yield
+    if "native" in request.fixturenames or "device" in request.fixturenames:
+        import chalametpir_amd as cp
+
+        cp.tuning_reset()

@@ -215,7 +215,7 @@ def test_every_documented_tuning_key_is_accepted_and_bounded():
     source = open(os.path.join(ROOT, "chalametpir_amd", "csrc", "respond.hip")).read()
     accepted = set(re.findall(r'!strcmp\(key, "([a-z_.]+)"\)', source))
     assert accepted == documented, (sorted(accepted - documented), sorted(documented - accepted))
-    defaults = {"respond.ks_major": 1, "respond.host_zero_copy": 1, "respond.host_fill_timeout_us": 20000, "respond.batch_fusion": 1,
+    defaults = {"respond.ks_major": 1, "respond.host_zero_copy": 1, "respond.host_fill_timeout_us": 2000, "respond.batch_fusion": 1,
                 "respond.interleave_passes": -1, "matmul.mfma": 1}
     for key, value in defaults.items():
         cp.tuning_set(key, value)

@@ -396,7 +396,7 @@ def test_partly_registered_query_buffer_is_not_read_in_place(orc, device):
 
 def test_lone_pageable_query_polled_launch_and_its_fallbacks(orc, device):
     """a lone pageable query of 2^19+ words: ONE launch in front of the copy, the kernel waiting for each step's words
-    (respond.host_fill_timeout_us, default 20 ms per wave).  With a 1 us limit every wave gives up at once: the launch is flagged void and
+    (respond.host_fill_timeout_us, default 2 ms per wave and step).  With a 1 us limit every wave gives up at once: the launch is flagged void and
     the query answered again from the complete pinned block; after three such launches the server stops polling (two launches, each
     when its half is in place); 0 switches polling off from the start.  Same answers throughout."""
     import chalametpir_amd as cp
@@ -416,7 +416,7 @@ def test_lone_pageable_query_polled_launch_and_its_fallbacks(orc, device):
                     assert np.array_equal(srv.respond_array(q), w), (timeout_us, rep)
             srv.close()
     finally:
-        cp.tuning_set("respond.host_fill_timeout_us", 20000)
+        cp.tuning_set("respond.host_fill_timeout_us", 2000)
 
 
 def test_random_shapes_every_kernel_order(orc, device):

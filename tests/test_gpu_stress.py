@@ -1,0 +1,168 @@
+"""Life-cycle stress of the HOST entry point (cpir_server_respond), part of `-m gpu` (what scripts/lifecycle_soak.py and scripts/soak.py
+do for minutes, here for a bounded number of rounds): servers of three shapes are created, asked by
+
+  * a lone caller with a PAGEABLE query (2^19+ words: one launch polling the copy's progress; below: staged, read in place from the
+    arena's pinned block),
+  * a lone caller whose query lies in page-locked memory (cpir_host_alloc: read in place from the caller's buffer),
+  * a lone caller whose buffer is hipHostRegister'ed, asked, unregistered and asked again at the SAME address (must be staged then),
+  * bursts of concurrent callers mixing pageable and page-locked buffers (arenas coalesce and pipeline them),
+
+cloned, closed while the clone keeps answering, and destroyed -- interleaved, so that arenas, streams, pinned blocks and registrations are
+created and torn down next to each other.  Every response is compared with the oracle.  Models the reference's serving loop: one
+Arc<Server> answered from many tasks, servers replaced while others serve (chalametpir_server/examples/server.rs:45-93)."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from _cases import random_db_matrix, random_query
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [((1 << 19) + 4096 * 3 + 5, 24, 9), (77_824, 130, 10), (600_000, 7, 12), (3 * 1536 + 1, 19, 6)]
+
+
+def _register(rt, arr):
+    """hipHostRegister over the pages that hold `arr` (torch's binding of the runtime call); returns the registered base address"""
+    base = arr.ctypes.data // 4096 * 4096
+    end = (arr.ctypes.data + arr.nbytes + 4095) // 4096 * 4096
+    err = rt.cudaHostRegister(base, end - base, 0)
+    assert int(err) == 0, err
+    return base
+
+
+@pytest.mark.parametrize("order", ["forward", "reversed"])
+def test_server_lifecycle_under_mixed_callers(order, orc, device):
+    import torch
+
+    import chalametpir_amd as cp
+
+    rt = torch.cuda.cudart()
+    can_register = hasattr(rt, "cudaHostRegister") and hasattr(rt, "cudaHostUnregister")
+    rng = np.random.default_rng(31337)
+    shapes = SHAPES if order == "forward" else SHAPES[::-1]
+    t_end = time.time() + 25  # a bound, not a target: three rounds over the shapes normally take well under that
+    responses = 0
+    for rnd in range(3):
+        for N, C, b in shapes:
+            if time.time() > t_end:
+                break
+            D = random_db_matrix(rng, N, C, b)
+            dtc = orc.row_wise_compress(orc.transpose(D), b)
+            srv = cp.Server.from_compressed(dtc, N, b, device=device)
+
+            def want(q):
+                return orc.row_vector_x_compressed_transposed_matrix(q, dtc, N, b)[0]
+
+            bad = []
+
+            def ask(server, buf, q, tag):
+                if not np.array_equal(server.respond_array(buf), want(q)):
+                    bad.append((rnd, N, C, b, tag))
+
+            # lone callers: pageable, page-locked, registered -> unregistered at the same address
+            q = random_query(rng, N)
+            ask(srv, q, q, "pageable")
+            pin = cp.PinnedArray(N)
+            pin.array[:] = q
+            ask(srv, pin.array, q, "page-locked")
+            if can_register:
+                raw = np.zeros(N + 2048, dtype=np.uint32)
+                off = (-raw.ctypes.data % 4096) // 4
+                qr = raw[off:off + N]
+                qr[:] = random_query(rng, N)
+                _register(rt, qr)
+                try:
+                    ask(srv, qr, qr.copy(), "registered")
+                finally:
+                    rt.cudaHostUnregister(qr.ctypes.data // 4096 * 4096)
+                ask(srv, qr, qr.copy(), "unregistered-again")
+            # a burst of concurrent callers on the one handle, pageable and page-locked buffers mixed
+            qs = [random_query(rng, N) for _ in range(6)]
+            pins = [cp.PinnedArray(N) for _ in range(2)]
+            for pa, qq in zip(pins, qs):
+                pa.array[:] = qq
+            ts = [threading.Thread(target=ask, args=(srv, pins[i].array if i < 2 else qs[i], qs[i], f"burst{i}")) for i in range(6)]
+            [t.start() for t in ts]
+            [t.join() for t in ts]
+            # Clone shares the database; the original goes away while the clone keeps serving (server.rs:15 #[derive(Clone)])
+            clone = srv.clone()
+            srv.close()
+            q2 = random_query(rng, N)
+            ask(clone, q2, q2, "clone-after-close")
+            ask(clone, pin.array, q, "clone-page-locked")
+            clone.close()
+            for pa in pins:
+                pa.close()
+            pin.close()
+            assert not bad, bad
+            responses += 12 if can_register else 10
+    assert responses >= 10 * len(SHAPES)  # at least one full round fitted the bound
+
+
+def test_polled_and_plain_lone_launches_agree_while_servers_come_and_go(orc, device):
+    """the polled launch (kernel started in front of the copy of a lone pageable query) against the plain paths on the same queries, with
+    a second server being created, asked and destroyed between the calls: same answers whichever path served them"""
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(99)
+    b, N, C = 9, (1 << 19) + 2048 + 7, 9
+    D = random_db_matrix(rng, N, C, b)
+    dtc = orc.row_wise_compress(orc.transpose(D), b)
+    qs = [random_query(rng, N) for _ in range(4)]
+    wants = [orc.row_vector_x_compressed_transposed_matrix(q, dtc, N, b)[0] for q in qs]
+    small = (4 * 1024 + 3, 5, 10)
+    Ds = random_db_matrix(rng, *small)
+    dtcs = orc.row_wise_compress(orc.transpose(Ds), small[2])
+    qsmall = random_query(rng, small[0])
+    wsmall = orc.row_vector_x_compressed_transposed_matrix(qsmall, dtcs, small[0], small[2])[0]
+    srv = cp.Server.from_compressed(dtc, N, b, device=device)
+    for timeout_us, zero_copy in ((20000, 1), (0, 1), (20000, 0), (2000, 1)):
+        cp.tuning_set("respond.host_fill_timeout_us", timeout_us)
+        cp.tuning_set("respond.host_zero_copy", zero_copy)
+        for q, w in zip(qs, wants):
+            assert np.array_equal(srv.respond_array(q), w), (timeout_us, zero_copy)
+            other = cp.Server.from_compressed(dtcs, small[0], small[2], device=device)
+            assert np.array_equal(other.respond_array(qsmall), wsmall)
+            other.close()
+    srv.close()
+
+
+def test_mat_x_packed_beyond_the_pipelined_kernels_reach_is_refused_up_front(device):
+    """N >= 2^23 slots: the hand-pipelined matmul cannot address a 128-row tile of A with 32-bit byte offsets.  cpir_op_mat_x_packed must
+    say so BEFORE touching M (mfma_planar_rhs_applicable is what Server::setup asks to choose its path), and cpir_op_mat_x_mat still
+    multiplies that shape -- matrix cores and VALU agree, spot-checked against numpy on rebuilt entries."""
+    import torch
+
+    import chalametpir_amd as cp
+    from _cases import synth_u32_at
+
+    stream = torch.cuda.current_stream()
+    b, rows, N, C = 9, 3, (1 << 23) + 512, 16
+    L = cp.dtc_layout_for(N, C, b, packing=2)
+    D = torch.empty((N, C), dtype=torch.int32, device="cuda")
+    A = torch.empty((rows, N), dtype=torch.int32, device="cuda")
+    device.synth_fill(D, N * C, 0xD0, mask=(1 << b) - 1, stream=stream)
+    device.synth_fill(A, rows * N, 0xA0, stream=stream)
+    dtc = torch.empty(L.total_words, dtype=torch.int32, device="cuda")
+    plane = torch.empty(cp.packed_rhs_plane_bytes(L) // 4, dtype=torch.int32, device="cuda")
+    device.transpose_compress_with_plane(D, L, dtc, plane, stream=stream)
+    M = torch.full((rows, C), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+    with pytest.raises(cp.ChalametPIRError):
+        device.mat_x_packed(A, dtc, L, plane, M, rows, stream=stream)
+    torch.cuda.synchronize()
+    assert bool((M == 0x5A5A5A5A).all())  # refused before M was zeroed
+    got = {}
+    for mfma in (1, 0):
+        cp.tuning_set("matmul.mfma", mfma)
+        Mx = torch.empty((rows, C), dtype=torch.int32, device="cuda")
+        device.mat_x_mat(A, D, Mx, rows, N, C, rhs_max_bits=16, stream=stream)
+        torch.cuda.synchronize()
+        got[mfma] = Mx.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got[0], got[1])
+    n = np.arange(N, dtype=np.uint64)
+    for r, c in ((0, 0), (2, 15), (1, 7)):
+        a = synth_u32_at(np.uint64(r) * np.uint64(N) + n, 0xA0).astype(np.uint64)
+        d = synth_u32_at(n * np.uint64(C) + np.uint64(c), 0xD0, (1 << b) - 1).astype(np.uint64)
+        assert int((a * d).sum(dtype=np.uint64) & np.uint64(0xFFFFFFFF)) == int(got[1][r, c])
