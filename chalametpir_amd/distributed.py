@@ -62,11 +62,14 @@ def reduce_u32_(t, dst: int = 0, group=None):
 def scatter_public_matrix(seed_mu: bytes, total_slots: int, unit, device=None, group=None, rows: int = 1774, block_bytes: int = 64 << 20):
     """This rank's column slab  A[:, n_g : n_{g+1}]  of the public matrix A = generate_from_seed(rows, total_slots, seed_mu)
     (reference matrix.rs:541-558, server.rs:59), with ONE expansion of the sponge per process group instead of one per rank: rank 0
-    squeezes A block of rows by block of rows (the XOF is sequential: ~2 GB/s on one core) into page-locked memory, uploads the block
-    and sends every other rank its column slab of the block (point-to-point: RCCL send/recv over xGMI under the "nccl" backend) while it
-    squeezes the next block;
-    every rank receives straight into the rows of its slab.  `unit` as in shard_range.  Returns (slab [rows x n_g] int32 on `device`,
-    lo, hi).  Works on CPU tensors under gloo (device=None): that is how the CPU test drives it."""
+    squeezes A block of rows by block of rows (the XOF is sequential: ~2 GB/s on one core) into page-locked memory and hands every other
+    rank its column slab of the block while it squeezes the next one; every rank receives straight into the rows of its slab.
+      * "nccl" (RCCL over xGMI): the block is uploaded once, the slabs are cut on the device and all of a block's sends go out as ONE
+        batch (dist.batch_isend_irecv: one grouped launch per block instead of one per peer);
+      * a host-staged backend (gloo -- the CPU tests and the one-GPU rehearsal): the slabs are cut from the page-locked block on the host
+        and sent as CPU tensors; receivers upload what arrives.  (Sending device tensors through gloo copies them back to pageable host
+        memory first: 162 s for 8.4 GB in a two-rank rehearsal.)
+    `unit` as in shard_range.  Returns (slab [rows x n_g] int32 on `device`, lo, hi).  device=None: CPU tensors (the CPU test)."""
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -77,51 +80,76 @@ def scatter_public_matrix(seed_mu: bytes, total_slots: int, unit, device=None, g
     bounds = [shard_range(total_slots, unit, r, world) for r in range(world)]
     lo, hi = bounds[rank]
     dev = torch.device("cpu") if device is None else torch.device(device)
+    on_gpu = dev.type == "cuda"
+    via_host = dist.get_backend(group) != "nccl"  # the collective moves host memory
     slab = torch.empty((rows, hi - lo), dtype=torch.int32, device=dev)
     rb = max(1, min(rows, block_bytes // (4 * total_slots)))
     src = dist.get_global_rank(group, 0) if group is not None else 0
+    peer = (lambda g: dist.get_global_rank(group, g)) if group is not None else (lambda g: g)
+    depth = 4  # blocks in flight
     if rank == 0:
         xof = SeedExpander(seed_mu)
         host = [torch.empty((rb, total_slots), dtype=torch.int32) for _ in range(2)]
-        if dev.type == "cuda":
+        if on_gpu:
             host = [h.pin_memory() for h in host]
         staged = [None, None]  # event after the upload that last read host buffer i
-    pending = []
+    elif on_gpu and via_host and hi > lo:
+        landing = [torch.empty((rb, hi - lo), dtype=torch.int32).pin_memory() for _ in range(depth + 1)]
+    pending = []  # (works, what they must outlive, upload to run once they are done)
+
+    def retire(entry):
+        works, _keep, then = entry
+        for w in works:
+            w.wait()
+        if then is not None:
+            then()
+
     for i, r0 in enumerate(range(0, rows, rb)):
         n = min(rb, rows - r0)
         recv = slab[r0:r0 + n]  # n whole rows of the slab: contiguous
         if rank == 0:
             b = i & 1
             if staged[b] is not None:  # the upload that read this host buffer two blocks ago must be done before it is overwritten
-                if dev.type == "cuda":
-                    staged[b][0].synchronize()
+                staged[b].synchronize()
                 staged[b] = None
-            xof.squeeze_into(host[b].numpy().view(np.uint32)[:n])  # releases the GIL: the previous block's upload + scatter run meanwhile
-            blk = host[b][:n].to(dev, non_blocking=True) if dev.type == "cuda" else host[b][:n].clone()  # never send from the staging buffer itself
-            if dev.type == "cuda":
-                ev = torch.cuda.Event()
-                ev.record()
-                staged[b] = (ev,)
-            recv.copy_(blk[:, lo:hi])  # rank 0's own slab
-            works, keep = [], []
-            parts = {g: blk[:, bounds[g][0]:bounds[g][1]].contiguous() for g in range(1, world) if bounds[g][1] > bounds[g][0]}
-            if dev.type == "cuda" and dist.get_backend(group) != "nccl":
-                torch.cuda.current_stream().synchronize()  # a host-staged backend (gloo: the one-GPU test hook) must not read a slab still being written
+            xof.squeeze_into(host[b].numpy().view(np.uint32)[:n])  # releases the GIL: the previous block's transfers run meanwhile
+            ops, keep = [], []
+            if on_gpu and not via_host:
+                blk = host[b][:n].to(dev, non_blocking=True)  # the whole block once; slabs are cut on the device
+                recv.copy_(blk[:, lo:hi])
+                cut = lambda a_, z_: blk[:, a_:z_].contiguous()  # noqa: E731
+            else:
+                if on_gpu:
+                    recv.copy_(host[b][:n, lo:hi], non_blocking=True)  # rank 0's own slab, straight from the page-locked block
+                else:
+                    recv.copy_(host[b][:n, lo:hi])
+                # (a copy, always -- .contiguous() would hand back the staging buffer itself when one rank holds every column)
+                cut = lambda a_, z_: host[b][:n, a_:z_].clone(memory_format=torch.contiguous_format)  # noqa: E731
+            if on_gpu:
+                staged[b] = torch.cuda.Event()
+                staged[b].record()
             for g in range(1, world):  # shards differ in size (ragged tail, empty shards), so point-to-point rather than dist.scatter
                 a_, z_ = bounds[g]
                 if z_ > a_:
-                    part = parts[g]
+                    part = cut(a_, z_)
                     keep.append(part)
-                    works.append(dist.isend(part, dst=dist.get_global_rank(group, g) if group is not None else g, group=group))
-            pending.append((works, keep))
+                    ops.append(dist.P2POp(dist.isend, part, peer(g), group))
+            works = []
+            if ops:
+                works = dist.batch_isend_irecv(ops) if not via_host else [dist.isend(op.tensor, op.peer, group=group) for op in ops]
+            pending.append((works, keep, None))
         elif hi > lo:
-            pending.append(([dist.irecv(recv, src=src, group=group)], None))
-        while len(pending) > 4:  # bounded queue of transfers in flight
-            for w in pending.pop(0)[0]:
-                w.wait()
-    for works, _ in pending:
-        for w in works:
-            w.wait()
+            if on_gpu and via_host:
+                land = landing[i % len(landing)][:n]
+                pending.append(([dist.irecv(land, src=src, group=group)], land, (lambda dst=recv, s_=land: dst.copy_(s_, non_blocking=True))))
+            else:
+                pending.append(([dist.irecv(recv, src=src, group=group)], None, None))
+        while len(pending) > depth:  # bounded queue of transfers in flight
+            retire(pending.pop(0))
+    while pending:
+        retire(pending.pop(0))
+    if on_gpu:
+        torch.cuda.current_stream().synchronize()
     if rank == 0:
         xof.close()
     return slab, lo, hi

@@ -87,3 +87,15 @@ def test_bench_json_contract():
     cpu = d["cpu_baseline"]
     assert cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1 and cpu["value"] > 0 and isinstance(cpu["sample"], str)
     assert cpu["gpu_results_bit_exact"] is True
+
+
+def test_rccl_backend_single_rank():
+    """the backend bench.py --gpus N really uses ("nccl" = RCCL), as far as a one-GPU box can take it: one rank, device tensors, the
+    product's own collectives and the device path of scatter_public_matrix (tests/_rccl_worker.py)"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", "29655", os.path.join(ROOT, "tests", "_rccl_worker.py")]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "rccl single rank ok" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
