@@ -885,9 +885,9 @@ def setup_kernel_roofline(cp, device, torch, N, C, b, cf, mask, layout, stream):
     # what Server::setup runs where it can (planar packing, b >= 9): ONE pass over D writes the packed image and the second operand plane
     # of the matmul, whose first plane are the image's own low-byte pieces -- no separate split of D in front of the product
     paired = None
-    plane_bytes = cp.packed_rhs_plane_bytes(layout)
-    if plane_bytes and "mfma" in cp.mat_x_mat_kernel_name(16):
-        plane = torch.empty(plane_bytes // 4, dtype=torch.int32, device="cuda")
+    plane_bytes = cp.packed_rhs_plane_bytes(layout)  # 0 with one bit plane (b = 9): the matmul expands it from the image itself
+    if cp.packed_rhs_offered(layout) and "mfma" in cp.mat_x_mat_kernel_name(16):
+        plane = torch.empty(plane_bytes // 4, dtype=torch.int32, device="cuda") if plane_bytes else None
         M2 = torch.empty((R, C), dtype=torch.int32, device="cuda")
         pk2_ms = timed(lambda: device.transpose_compress_with_plane(D, layout, dtc, plane, stream=stream))
         mm2_ms = timed(lambda: device.mat_x_packed(A, dtc, layout, plane, M2, R, stream=stream))
@@ -937,9 +937,12 @@ def setup_kernel_roofline(cp, device, torch, N, C, b, cf, mask, layout, stream):
                 "inside Server::setup both hide behind the host XOF (server_setup_phases_sec)",
     }
     if paired:
-        out["hint_matmul"]["kernel"] = "mat_x_mat_mfma_pipe_kernel<true>"
-        out["hint_matmul"]["right_hand_side"] = ("the packed image's low-byte pieces + the high-byte plane written by the pack pass "
-                                                 "(cpir_op_transpose_compress_with_plane + cpir_op_mat_x_packed): D is read once")
+        out["hint_matmul"]["kernel"] = "mat_x_mat_mfma_pipe_kernel<image + bit plane>" if not paired["plane_bytes"] else "mat_x_mat_mfma_pipe_kernel<image + byte plane>"
+        out["hint_matmul"]["right_hand_side"] = (
+            "the packed image's low-byte pieces + its one bit plane expanded to the high-byte operand in registers (cpir_op_mat_x_packed): "
+            "D is read once and the pack pass writes nothing but the image" if not paired["plane_bytes"] else
+            "the packed image's low-byte pieces + the high-byte plane written by the pack pass "
+            "(cpir_op_transpose_compress_with_plane + cpir_op_mat_x_packed): D is read once")
         out["hint_matmul"]["same_hint_as_split_path"] = paired["same_hint_as_split_path"]
         out["hint_matmul"]["split_path_ms"] = round(split_ms, 3)  # cpir_op_mat_x_mat: byte-plane split of D (a pass of its own) + product
         out["transpose_compress"]["writes_matmul_plane_bytes"] = paired["plane_bytes"]

@@ -89,6 +89,7 @@ SIGNATURES = {
     "cpir_shard_unit": (C.c_uint64, [C.POINTER(DtcLayout)]),
     "cpir_op_transpose_compress": (C.c_int, [vp, u32p, C.c_uint64, C.POINTER(DtcLayout), u32p, u32p, vp]),
     "cpir_packed_rhs_plane_bytes": (C.c_uint64, [C.POINTER(DtcLayout)]),
+    "cpir_packed_rhs_offered": (C.c_int, [C.POINTER(DtcLayout)]),
     "cpir_op_transpose_compress_with_plane": (C.c_int, [vp, u32p, C.c_uint64, C.POINTER(DtcLayout), u32p, u32p, vp, vp]),
     "cpir_op_mat_x_packed": (C.c_int, [vp, u32p, C.c_uint64, u32p, C.POINTER(DtcLayout), vp, u32p, C.c_uint64, C.c_uint64, C.c_int, vp]),
     "cpir_op_dtc_import": (C.c_int, [vp, u32p, C.POINTER(DtcLayout), u32p, vp]),

@@ -233,6 +233,10 @@ int cpir_op_transpose_compress(cpir_device* dev, const uint32_t* D, uint64_t ldd
   return launch_transpose_compress(dev, D, ldd, *layout, dtc, or_of_entries, pick_stream(dev, stream));
 }
 
+int cpir_packed_rhs_offered(const cpir_dtc_layout* layout) {
+  return layout && check_layout(*layout) == CPIR_OK && layout->packing == CPIR_PACK_PLANAR && layout->mat_elem_bit_len >= 9;
+}
+
 uint64_t cpir_packed_rhs_plane_bytes(const cpir_dtc_layout* layout) {
   if (!layout || check_layout(*layout) != CPIR_OK) return 0;
   return planar_hi_plane_bytes(*layout);
@@ -241,14 +245,14 @@ uint64_t cpir_packed_rhs_plane_bytes(const cpir_dtc_layout* layout) {
 int cpir_op_transpose_compress_with_plane(cpir_device* dev, const uint32_t* D, uint64_t ldd, const cpir_dtc_layout* layout, uint32_t* dtc,
                                           uint32_t* or_of_entries, void* hi_plane, void* stream) {
   if (!dev || !layout) return CPIR_ERR_INVALID_ARGUMENT;
-  if (hi_plane && planar_hi_plane_bytes(*layout) == 0) return CPIR_ERR_INVALID_ARGUMENT;
+  if (!cpir_packed_rhs_offered(layout) || (hi_plane != nullptr) != (planar_hi_plane_bytes(*layout) != 0)) return CPIR_ERR_INVALID_ARGUMENT;
   DeviceGuard g(dev->ordinal);
   return launch_transpose_compress(dev, D, ldd, *layout, dtc, or_of_entries, pick_stream(dev, stream), hi_plane);
 }
 
 int cpir_op_mat_x_packed(cpir_device* dev, const uint32_t* A, uint64_t lda, const uint32_t* dtc, const cpir_dtc_layout* layout,
                          const void* hi_plane, uint32_t* M, uint64_t ldm, uint64_t rows, int accumulate, void* stream) {
-  if (!dev || !layout || !A || !dtc || !hi_plane || !M || rows == 0) return CPIR_ERR_INVALID_ARGUMENT;
+  if (!dev || !layout || !A || !dtc || !M || rows == 0) return CPIR_ERR_INVALID_ARGUMENT;  // (hi_plane: NULL exactly where the plane has 0 bytes)
   CPIR_TRY(check_layout(*layout));
   if (!mfma_matmul_enabled() || !mfma_planar_rhs_applicable(A, lda, *layout)) return CPIR_ERR_INVALID_ARGUMENT;
   DeviceGuard g(dev->ordinal);

@@ -247,10 +247,10 @@ static int setup_from_host_matrix(Device* dev, PublicMatrixUpload& upA, const ui
   // in the same pass over D.  (Otherwise D is split into byte planes in a pass of its own, or multiplied on the VALU.)
   const uint32_t* A_dev = upA.device_ptr();
   DevBuf hi_plane, rowsum_ws;
-  const uint64_t hi_bytes = planar_hi_plane_bytes(L);
-  bool planar_rhs = mfma_matmul_enabled() && hi_bytes && mfma_planar_rhs_applicable(A_dev, N, L);
+  const uint64_t hi_bytes = planar_hi_plane_bytes(L);  // 0 with one bit plane (b = 9): the matmul expands it from the image itself
+  bool planar_rhs = mfma_matmul_enabled() && mfma_planar_rhs_applicable(A_dev, N, L);
   if (planar_rhs) {
-    TRY_(hipMalloc(&hi_plane.p, (size_t)hi_bytes));
+    if (hi_bytes) TRY_(hipMalloc(&hi_plane.p, (size_t)hi_bytes));
     TRY_(hipMalloc(&rowsum_ws.p, 4 * 128));
   }
   int st = launch_transpose_compress(dev, (const uint32_t*)D_dev.p, C, L, srv->dtc, (uint32_t*)flag.p, stream, hi_plane.p);
@@ -371,8 +371,8 @@ static int setup_group_from_host_matrix(const std::vector<Device*>& devs, Public
     // (as setup_from_host_matrix: where the packed image can serve as the matmul's right-hand side, the pack pass prepares it; A's slab
     // for this shard is allocated 16-byte aligned with leading dimension hi - lo)
     const uint64_t hi_bytes = planar_hi_plane_bytes(L);
-    if (mfma_matmul_enabled() && hi_bytes && L.packing == CPIR_PACK_PLANAR && (hi - lo) % 4 == 0 && mfma_pipeline() != 0) {
-      TRY_(hipMalloc(&work[g].hi_plane.p, (size_t)hi_bytes));
+    if (mfma_matmul_enabled() && L.packing == CPIR_PACK_PLANAR && L.mat_elem_bit_len >= 9 && (hi - lo) % 4 == 0 && mfma_pipeline() != 0) {
+      if (hi_bytes) TRY_(hipMalloc(&work[g].hi_plane.p, (size_t)hi_bytes));  // (one bit plane: none, the matmul expands it from the image)
       TRY_(hipMalloc(&work[g].rowsum_ws.p, 4 * ((CPIR_LWE_DIMENSION + 127) / 128 * 128)));
     }
     st = launch_transpose_compress(devs[g], (const uint32_t*)work[g].D_dev.p, C, L, child->dtc, (uint32_t*)work[g].flag.p, stream,
@@ -404,7 +404,7 @@ static int setup_group_from_host_matrix(const std::vector<Device*>& devs, Public
     st = upA.finish(&A_dev, g);
     if (st != CPIR_OK) return fail(st);
     const uint64_t n = child->layout.num_slots;
-    if (work[g].hi_plane.p && (ored >> b) == 0 && mfma_planar_rhs_applicable(A_dev, n, child->layout))
+    if (work[g].rowsum_ws.p && (ored >> b) == 0 && mfma_planar_rhs_applicable(A_dev, n, child->layout))
       st = launch_mat_x_mat_mfma_planar(devs[g], A_dev, n, child->dtc, child->layout, work[g].hi_plane.p, (uint32_t*)work[g].rowsum_ws.p,
                                         (uint32_t*)work[g].M_dev.p, C, CPIR_LWE_DIMENSION, 0, devs[g]->stream);
     else

@@ -151,6 +151,9 @@ struct MfmaArgs {
   // the first 8 KiB of every super-tile of the image ([column tile][step of 512 slots][(8 + HB) KiB]), the high-byte pieces come from the
   // plane pack.hip writes next to it ([column tile][k-block of 64][1 KiB]).  Slots and columns past the end hold field 0 there (bytes
   // 0x80, not 0x00 as in `planes`), so the kernel feeds A = 0x80808080 (all limbs zero) for k >= inner.
+  // With ONE bit plane (b = 9) there is no high-byte plane at all (hi_plane NULL): the high byte of a field is that one bit, and every wave
+  // expands its dword of the image's bit plane into the 1 KiB operand piece in registers (8 VALU operations per k-step) -- the pack pass
+  // then writes nothing but the image, 1.11 GB less at 2^20 keys.
   const uint4* lo_tiles;
   const uint4* hi_plane;
   uint32_t lo_st16;      // uint4 per super-tile: (8 + HB) * 64
@@ -385,13 +388,20 @@ __device__ __forceinline__ void pipe_load_quad(const MfmaArgs& a, const PipeLane
   u.issued += 1;
 }
 
+// kinds of right-hand side of the pipelined kernel
+constexpr int kRhsPlanes = 0;    // byte planes of rhs_split_kernel
+constexpr int kRhsImage = 1;     // planar respond image (low-byte pieces) + the high-byte plane of the pack pass
+constexpr int kRhsImageBit = 2;  // planar respond image with ONE bit plane (b = 9): the high-byte pieces are expanded from it in registers
+
 // request this wave's two 1 KiB pieces of D(ks) into stage `st` of the LDS ring (LDS-DMA: the destination is M0 + lane * 16); returns the
-// value of `issued` after the request
-template <bool PLANAR>
+// value of `issued` after the request.  kRhsImageBit: only the low-byte piece; the high-byte piece is expanded from the bit plane
+// (pipe_load_bits / pipe_store_hi_from_bit).
+template <int RHS>
 __device__ __forceinline__ uint32_t pipe_dma_b(const MfmaArgs& a, PipeUnit& u, uint32_t lds_b0, uint32_t lane, uint32_t wave, uint32_t ks, uint32_t st) {
-  constexpr bool planar = PLANAR;
+  constexpr bool planar = RHS != kRhsPlanes;
+  constexpr int kPieces = RHS == kRhsImageBit ? 1 : 2;
 #pragma unroll
-  for (int e = 0; e < 2; e++) {
+  for (int e = 0; e < kPieces; e++) {
     const uint4* const base = uniform_ptr(planar && e ? u.h_base : u.b_base);
     const uint32_t piece = planar ? (e ? ks * 64u : (ks >> 3) * a.lo_st16 + (ks & 7u) * 64u) : (ks * 2u + (uint32_t)e) * 64u;  // in uint4
     const uint32_t off = piece * 16u + lane * 16u;
@@ -402,8 +412,29 @@ __device__ __forceinline__ uint32_t pipe_dma_b(const MfmaArgs& a, PipeUnit& u, u
                  : "v"(off), "s"(dst), "s"(base)
                  : "memory");
   }
-  u.issued += 2;
+  u.issued += kPieces;
   return u.issued;
+}
+
+// kRhsImageBit: request this lane's dword of the bit plane of k-step ks's super-tile into `h`: k-blocks 2w and 2w + 1 of a super-tile share
+// dword w of the lane's 16 bytes of the plane (which follows the 8 KiB of low-byte pieces)
+__device__ __forceinline__ void pipe_load_bits(const MfmaArgs& a, PipeUnit& u, uint32_t lane, uint32_t ks, uint32_t& h) {
+  const uint32_t* const base = reinterpret_cast<const uint32_t*>(uniform_ptr(u.b_base));
+  const uint32_t off = ((ks >> 3) * a.lo_st16 + 512u) * 16u + ((ks & 7u) >> 1) * 4u + lane * 16u;
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(h) : "v"(off), "s"(base) : "memory");
+  u.issued += 1;
+}
+
+// kRhsImageBit: this wave's high-byte piece of k-step `ks` (k-block ks & 7 of its super-tile) from the bit-plane dword `h` into stage `st`:
+// bit 8*jj + 4*(kb & 1) + d of the dword is the high bit of slot 16*g + 4*d + jj of the k-block (pack.hip), i.e. byte jj of dword d of the
+// piece; the operand byte is that bit XOR 0x80.  The caller has waited for the load of `h` and runs lds_barrier() behind this.
+__device__ __forceinline__ void pipe_store_hi_from_bit(uint4* lds, uint32_t lane, uint32_t wave, uint32_t st, uint32_t sh /* 4 * (ks & 1) */, uint32_t h) {
+  uint4 v;
+  v.x = ((h >> (sh + 0u)) & 0x01010101u) | 0x80808080u;
+  v.y = ((h >> (sh + 1u)) & 0x01010101u) | 0x80808080u;
+  v.z = ((h >> (sh + 2u)) & 0x01010101u) | 0x80808080u;
+  v.w = ((h >> (sh + 3u)) & 0x01010101u) | 0x80808080u;
+  lds[(2 * kPiecesA + st * kPiecesB + wave * 2 + 1) * 64 + lane] = v;
 }
 
 // the four byte limbs of four consecutive words: limb i = bytes i of (x, y, z, w), eight v_perm_b32 (a 4 x 4 byte transpose in two stages)
@@ -487,27 +518,39 @@ __device__ __forceinline__ void mfma_group_with_conversion(v4i (&acc)[2][4], con
 }
 
 // One (row tile, column tile, K sub-range) unit for one wave.  Register set S0 carries the even k-steps (relative to k0), S1 the odd ones.
-template <bool SUM, bool PLANAR>
+template <bool SUM, int RHS>
 __device__ __forceinline__ void mfma_pipe_unit(const MfmaArgs& a, const PipeLane& pl, PipeUnit& u, uint4* lds, uint32_t lds_b0, uint32_t lane,
                                                uint32_t wave, uint32_t k0, uint32_t T, v4i (&acc)[4][2][4]) {
+  constexpr bool PLANAR = RHS != kRhsPlanes;
+  constexpr bool BIT = RHS == kRhsImageBit;
   const uint32_t wm = wave >> 2, wn = wave & 3;
   v4i S0[4], S1[4];
+  // kRhsImageBit: ONE register carries the bit-plane dword of the next k-step.  At the end of k-step t (behind the wait that covers its
+  // load, in front of the barrier) the piece of k-step t + 1 is expanded from it into stage (t + 1) % 3, and the dword of k-step t + 2 is
+  // requested into the same register -- the LAST request of the k-step, so the steady-state waits keep their shape (see `steady`).
+  uint32_t H = 0;
+  const uint32_t sh_even = 4u * (k0 & 1u), sh_odd = 4u * ((k0 + 1u) & 1u);  // 4 * (k-block & 1) of the even / odd k-steps (relative to k0)
   // ---- prologue: the first two k-steps are requested, A(0) is converted, A(2) requested behind it ----
 #pragma unroll
   for (int j = 0; j < 4; j++) pipe_load_quad(a, pl, u, S0[j], j, k0);
-  const uint32_t bm0 = pipe_dma_b<PLANAR>(a, u, lds_b0, lane, wave, k0, 0);
+  const uint32_t bm0 = pipe_dma_b<RHS>(a, u, lds_b0, lane, wave, k0, 0);
+  if constexpr (BIT) pipe_load_bits(a, u, lane, k0, H);
   uint32_t bm_next = 0;  // `issued` after the request for the D stage of the NEXT k-step
   if (T > 1) {
 #pragma unroll
     for (int j = 0; j < 4; j++) pipe_load_quad(a, pl, u, S1[j], j, k0 + 1);
-    bm_next = pipe_dma_b<PLANAR>(a, u, lds_b0, lane, wave, k0 + 1, 1);
+    bm_next = pipe_dma_b<RHS>(a, u, lds_b0, lane, wave, k0 + 1, 1);
   }
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(S0[0]), "+v"(S0[1]), "+v"(S0[2]), "+v"(S0[3])::"memory");
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(S0[0]), "+v"(S0[1]), "+v"(S0[2]), "+v"(S0[3]), "+v"(H)::"memory");
   (void)bm0;
+  if constexpr (BIT) pipe_store_hi_from_bit(lds, lane, wave, 0, sh_even, H);
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     pipe_store_quad(a, pl, u, lds, S0[j], j, 0, k0);
     if (T > 2) pipe_load_quad(a, pl, u, S0[j], j, k0 + 2);
+  }
+  if constexpr (BIT) {  // (behind the quads, as in every k-step: the steady-state waits count on that order)
+    if (T > 1) pipe_load_bits(a, u, lane, k0 + 1, H);
   }
   uint32_t set_mark = u.issued;  // `issued` after the last request into the set that is converted NEXT ... (tracked per parity below)
   uint32_t mark0 = u.issued, mark1 = (T > 1) ? bm_next - 2 : 0;  // after the loads of S0 (A(2)) / S1 (A(1))
@@ -516,9 +559,9 @@ __device__ __forceinline__ void mfma_pipe_unit(const MfmaArgs& a, const PipeLane
 
   // k-step t: MFMAs of t from A buffer t & 1 and D stage t % 3, with the conversion of A(t + 1) (register set of parity (t + 1) & 1, re-requested
   // quad by quad with A(t + 3)) interleaved behind the four MFMA groups
-  auto step = [&](uint32_t t, v4i(&set)[4], uint32_t& mark) {
+  auto step = [&](uint32_t t, v4i(&set)[4], uint32_t& mark, uint32_t sh_next) {
     uint32_t bm_new = 0;
-    if (t + 2 < T) bm_new = pipe_dma_b<PLANAR>(a, u, lds_b0, lane, wave, k0 + t + 2, (t + 2) % kStagesB);
+    if (t + 2 < T) bm_new = pipe_dma_b<RHS>(a, u, lds_b0, lane, wave, k0 + t + 2, (t + 2) % kStagesB);
     const bool conv = t + 1 < T;
     if (conv) {
       wait_vm_at_most<8>(u.issued - mark);
@@ -554,7 +597,16 @@ __device__ __forceinline__ void mfma_pipe_unit(const MfmaArgs& a, const PipeLane
       if (conv && t + 3 < T) pipe_load_quad(a, pl, u, set[m], m, k0 + t + 3);
     }
     if (conv) mark = u.issued;
-    if (t + 1 < T) wait_vm_at_most<10>(u.issued - bm_next);  // this wave's pieces of D(t + 1) have landed
+    if (t + 1 < T) {
+      if constexpr (BIT) {
+        // (these few k-steps at the edges of a unit simply drain: the dword of k-step t + 1 and its low-byte piece have landed)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(H)::"memory");
+        pipe_store_hi_from_bit(lds, lane, wave, (t + 1) % kStagesB, sh_next, H);
+        if (t + 2 < T) pipe_load_bits(a, u, lane, k0 + t + 2, H);
+      } else {
+        wait_vm_at_most<10>(u.issued - bm_next);  // this wave's pieces of D(t + 1) have landed
+      }
+    }
     bm_next = bm_new;
     lds_barrier();
   };
@@ -578,7 +630,7 @@ __device__ __forceinline__ void mfma_pipe_unit(const MfmaArgs& a, const PipeLane
     const uint32_t dma_voff = lane * 16u;
     const uint32_t dma_dst0 = lds_b0 + wave * 2048u;  // this wave's two pieces inside a stage
     uint32_t st_read = 0, st_dma = 2;                // stage of k-step t, stage that receives D(t + 2)
-    auto steady = [&](uint32_t t, v4i(&set)[4], const uint32_t a_par /* (t + 1) & 1 */, const uint32_t r_par /* t & 1 */) {
+    auto steady = [&](uint32_t t, v4i(&set)[4], const uint32_t a_par /* (t + 1) & 1 */, const uint32_t r_par /* t & 1 */, const uint32_t sh_next) {
       // the first fragments are requested from LDS before anything else, so that their latency runs while the DMA is being issued
       const uint4* A_ = lds + r_par * kPiecesA * 64;
       const uint4* B_ = lds + (2 * kPiecesA + st_read * kPiecesB) * 64;
@@ -600,7 +652,14 @@ __device__ __forceinline__ void mfma_pipe_unit(const MfmaArgs& a, const PipeLane
         uint32_t keep;
         // (the second piece lands 1 KiB behind the first: M0 + 1024, and the immediate offset moves source and destination alike, so its
         // base is passed 1 KiB early)
-        if constexpr (PLANAR) {
+        if constexpr (BIT) {
+          // the low-byte piece by LDS-DMA; the bit-plane dword of the same k-step is requested at the END of this k-step (below)
+          const uint4* const lo = uniform_ptr(u.b_base + ((ks_dma >> 3) * lo_st16 + (ks_dma & 7u) * 64u));
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep)
+                       : "v"(dma_voff), "s"(dst), "s"(lo)
+                       : "memory");
+        } else if constexpr (PLANAR) {
           const uint4* const lo = uniform_ptr(u.b_base + ((ks_dma >> 3) * lo_st16 + (ks_dma & 7u) * 64u));
           const uint4* const hi_early = uniform_ptr(u.h_base + ks_dma * 64u - 64);
           asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %1, %4 offset:1024\n\ts_mov_b32 m0, %0"
@@ -635,28 +694,42 @@ __device__ __forceinline__ void mfma_pipe_unit(const MfmaArgs& a, const PipeLane
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(set[m]) : "v"(aoffq[m]), "s"(a_run) : "memory");
       }
       a_run += kBK;
-      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      if constexpr (BIT) {
+        // Requests of a k-step s, in order: low-byte DMA of D(s + 2), four quads of A(s + 3), bit dword of D(s + 2).  Outstanding here, newest
+        // first: quads of this k-step (4), DMA of D(t + 2) -- five that may stay in flight; behind them the bit dword of D(t + 1), the quads of
+        // the previous k-step and the DMA of D(t + 1), which must all have landed (the steady wait of the byte-plane kernels, vmcnt(10),
+        // covers the same requests: theirs come in pairs at the head of a k-step).
+        asm volatile("s_waitcnt vmcnt(5)" : "+v"(H)::"memory");
+        pipe_store_hi_from_bit(lds, lane, wave, st_read == 2 ? 0 : st_read + 1, sh_next, H);
+        const uint32_t* const bits =
+            uniform_ptr(reinterpret_cast<const uint32_t*>(u.b_base + ((ks_dma >> 3) * lo_st16 + 512u)) + ((ks_dma & 7u) >> 1));
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(H) : "v"(dma_voff), "s"(bits) : "memory");
+        ks_dma++;
+      } else {
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      }
       lds_barrier();
       st_read = st_read == 2 ? 0 : st_read + 1;
       st_dma = st_dma == 2 ? 0 : st_dma + 1;
       (void)t;
     };
     for (uint32_t t = 0; t < Ts; t += 2) {
-      steady(t, S1, 1, 0);
-      steady(t + 1, S0, 0, 1);
+      steady(t, S1, 1, 0, sh_odd);
+      steady(t + 1, S0, 0, 1, sh_even);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain once; the remaining steps run on the generic path with exact bookkeeping
     u.issued = 0, mark0 = 0, mark1 = 0, bm_next = 0;
   }
   for (uint32_t t = Ts; t < T; t += 2) {  // (unrolled by two so that the register set of each step is a compile-time choice; Ts is even)
-    step(t, S1, mark1);
-    if (t + 1 < T) step(t + 1, S0, mark0);
+    step(t, S1, mark1, sh_odd);
+    if (t + 1 < T) step(t + 1, S0, mark0, sh_even);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <bool PLANAR>
+template <int RHS>
 __global__ void __launch_bounds__(kMT) __attribute__((amdgpu_waves_per_eu(2, 2))) mat_x_mat_mfma_pipe_kernel(const MfmaArgs a) {
+  constexpr bool PLANAR = RHS != kRhsPlanes;
   __shared__ uint4 lds[kPipePieces * 64];
 
   const uint32_t lane = threadIdx.x & 63;
@@ -691,7 +764,7 @@ __global__ void __launch_bounds__(kMT) __attribute__((amdgpu_waves_per_eu(2, 2))
     if constexpr (PLANAR) {  // (column tiles past the image's last one are computed from its last tile and never stored)
       const uint32_t T16 = ct * 8 + wave < a.b_col_tiles ? ct * 8 + wave : a.b_col_tiles - 1;
       u.b_base = uniform_ptr(a.lo_tiles + (uint64_t)T16 * a.lo_ks512 * a.lo_st16);
-      u.h_base = uniform_ptr(a.hi_plane + (uint64_t)T16 * a.kb_total * 64);
+      u.h_base = RHS == kRhsImage ? uniform_ptr(a.hi_plane + (uint64_t)T16 * a.kb_total * 64) : u.b_base;
     } else {
       u.b_base = uniform_ptr(a.planes + (uint64_t)(ct * 8 + wave) * a.KS * 128);  // 2 pieces of 64 uint4 per k-step
       u.h_base = u.b_base;
@@ -715,8 +788,8 @@ __global__ void __launch_bounds__(kMT) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
         for (int s2 = 0; s2 < 4; s2++) acc[m][n][s2] = v4i{0, 0, 0, 0};
 
-    if (u.sum_rows) mfma_pipe_unit<true, PLANAR>(a, pl, u, lds, lds_b0, lane, wave, k0, k1 - k0, acc);
-    else mfma_pipe_unit<false, PLANAR>(a, pl, u, lds, lds_b0, lane, wave, k0, k1 - k0, acc);
+    if (u.sum_rows) mfma_pipe_unit<true, RHS>(a, pl, u, lds, lds_b0, lane, wave, k0, k1 - k0, acc);
+    else mfma_pipe_unit<false, RHS>(a, pl, u, lds, lds_b0, lane, wave, k0, k1 - k0, acc);
 
     // ---- this unit's part of the output tile: sum_s acc_s << 8s, one u32 atomic per element ----
     const uint32_t fr = lane & 15, fq = lane >> 4;
@@ -835,8 +908,10 @@ bool mfma_planar_rhs_applicable(const uint32_t* A, uint64_t lda, const cpir_dtc_
 int launch_mat_x_mat_mfma_planar(const Device* dev, const uint32_t* A, uint64_t lda, const uint32_t* dtc, const cpir_dtc_layout& L,
                                  const void* hi_plane, uint32_t* rowsum_ws, uint32_t* M, uint64_t ldm, uint64_t rows, int accumulate,
                                  hipStream_t stream) {
-  if (!A || !dtc || !hi_plane || !rowsum_ws || !M || rows == 0 || lda < L.num_slots || ldm < L.num_cols) return CPIR_ERR_INVALID_ARGUMENT;
+  if (!A || !dtc || !rowsum_ws || !M || rows == 0 || lda < L.num_slots || ldm < L.num_cols) return CPIR_ERR_INVALID_ARGUMENT;
   if (!mfma_planar_rhs_applicable(A, lda, L)) return CPIR_ERR_INVALID_ARGUMENT;
+  // one bit plane (b = 9): the high-byte pieces come out of the image itself and no plane is taken; more planes: the pack pass's plane
+  if ((planar_hi_plane_bytes(L) != 0) != (hi_plane != nullptr)) return CPIR_ERR_INVALID_ARGUMENT;
   MfmaArgs a;
   a.A = A, a.lda = lda, a.M = M, a.ldm = ldm, a.rows = rows, a.inner = L.num_slots, a.cols = L.num_cols;
   a.planes = nullptr;
@@ -877,8 +952,9 @@ static int launch_product(const Device* dev, MfmaArgs& a, const uint32_t* colsum
   if (!pipe && a.lo_tiles) return CPIR_ERR_INVALID_ARGUMENT;  // only the pipelined kernel reads the planar image (callers ask mfma_planar_rhs_applicable first)
   CPIR_HIP_TRY(hipMemsetAsync(a.rowsum, 0, 4 * round_up((uint32_t)rows, kBM), stream));
   if (!accumulate) CPIR_HIP_TRY(hipMemset2DAsync(M, ldm * sizeof(uint32_t), 0, cols * sizeof(uint32_t), rows, stream));
-  if (pipe && a.lo_tiles) hipLaunchKernelGGL(mat_x_mat_mfma_pipe_kernel<true>, dim3(grid), dim3(kMT), 0, stream, a);
-  else if (pipe) hipLaunchKernelGGL(mat_x_mat_mfma_pipe_kernel<false>, dim3(grid), dim3(kMT), 0, stream, a);
+  if (pipe && a.lo_tiles && !a.hi_plane) hipLaunchKernelGGL(mat_x_mat_mfma_pipe_kernel<kRhsImageBit>, dim3(grid), dim3(kMT), 0, stream, a);
+  else if (pipe && a.lo_tiles) hipLaunchKernelGGL(mat_x_mat_mfma_pipe_kernel<kRhsImage>, dim3(grid), dim3(kMT), 0, stream, a);
+  else if (pipe) hipLaunchKernelGGL(mat_x_mat_mfma_pipe_kernel<kRhsPlanes>, dim3(grid), dim3(kMT), 0, stream, a);
   else hipLaunchKernelGGL(mat_x_mat_mfma_kernel, dim3(grid), dim3(kMT), 0, stream, a);
   const uint32_t k_term = (uint32_t)inner * (0x80808080u * 0x8080u);
   uint64_t fb = (rows * cols + kThreads - 1) / kThreads;

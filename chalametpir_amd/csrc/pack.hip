@@ -605,7 +605,8 @@ uint32_t grid_for(const Device* dev, uint64_t total) {
 }  // namespace
 
 uint64_t planar_hi_plane_bytes(const cpir_dtc_layout& L) {
-  if (L.packing != CPIR_PACK_PLANAR || planar_hi_planes(L.mat_elem_bit_len) == 0) return 0;
+  // (one bit plane, b = 9: the hint matmul expands its high-byte operand from the image's own bit plane -- no plane to write)
+  if (L.packing != CPIR_PACK_PLANAR || planar_hi_planes(L.mat_elem_bit_len) <= 1) return 0;
   return (uint64_t)(L.rows_padded / 16) * ((L.num_slots + 63) / 64) * 1024;
 }
 

@@ -105,16 +105,17 @@ class Device:
                                                     _stream_ptr(stream)))
 
     def transpose_compress_with_plane(self, D, layout: DtcLayout, dtc, hi_plane, *, ldd=None, or_of_entries=None, stream=None) -> None:
-        """transpose_compress that also writes the second operand plane of the hint matmul (planar packing, b >= 9): D is read once
-        for the packed image and for hint = A * D (mat_x_packed)"""
+        """transpose_compress that also writes the second operand plane of the hint matmul (planar packing, b >= 10; with b = 9 there is
+        no plane -- hi_plane None -- and this is plain transpose_compress): D is read once for the packed image and for hint = A * D"""
         _check(self._lib.cpir_op_transpose_compress_with_plane(self._h, _tensor_ptr(D), ldd or layout.num_cols, C.byref(layout), _tensor_ptr(dtc),
                                                                _tensor_ptr(or_of_entries) if or_of_entries is not None else None,
-                                                               _tensor_ptr(hi_plane), _stream_ptr(stream)))
+                                                               _tensor_ptr(hi_plane) if hi_plane is not None else None, _stream_ptr(stream)))
 
     def mat_x_packed(self, A, dtc, layout: DtcLayout, hi_plane, M, rows: int, *, lda=None, ldm=None, accumulate: bool = False, stream=None) -> None:
         """M (+)= A * D with D given as its packed image + the plane of transpose_compress_with_plane (entries of D below 2^b)"""
         _check(self._lib.cpir_op_mat_x_packed(self._h, _tensor_ptr(A), lda or layout.num_slots, _tensor_ptr(dtc), C.byref(layout),
-                                              _tensor_ptr(hi_plane), _tensor_ptr(M), ldm or layout.num_cols, rows, int(accumulate),
+                                              _tensor_ptr(hi_plane) if hi_plane is not None else None, _tensor_ptr(M), ldm or layout.num_cols, rows,
+                                              int(accumulate),
                                               _stream_ptr(stream)))
 
     def respond(self, dtc, layout: DtcLayout, q, r, *, q_len=None, q_slot_offset: int = 0, stream=None) -> None:
@@ -145,9 +146,14 @@ def dtc_layout_for(num_slots: int, num_cols: int, mat_elem_bit_len: int, packing
     return L
 
 
+def packed_rhs_offered(layout: DtcLayout) -> bool:
+    """whether Device.mat_x_packed takes an image of this layout as its right-hand side (planar packing, b >= 9)"""
+    return bool(_native.load().cpir_packed_rhs_offered(C.byref(layout)))
+
+
 def packed_rhs_plane_bytes(layout: DtcLayout) -> int:
-    """bytes of the second operand plane Device.transpose_compress_with_plane writes (0 where the pairing is not offered: b <= 8 or
-    another packing)"""
+    """bytes of the second operand plane Device.transpose_compress_with_plane writes: 0 with b = 9 (the matmul expands the image's one
+    bit plane itself) and where the pairing is not offered at all (packed_rhs_offered)"""
     return int(_native.load().cpir_packed_rhs_plane_bytes(C.byref(layout)))
 
 

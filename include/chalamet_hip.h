@@ -204,14 +204,18 @@ int cpir_op_transpose_compress(cpir_device* dev, const uint32_t* D, uint64_t ldd
                                uint32_t* dtc, uint32_t* or_of_entries, void* stream);
 
 /* The packed image as the right-hand side of the hint product (server.rs:61 + 64-67 with ONE pass over D): for the planar packing with
- * b >= 9 the image's low-byte operand pieces are also the first operand plane of the matrix-core matmul (csrc/matmul_mfma.hip); the
- * second plane -- the byte (field >> 8) XOR 0x80 of every field, cpir_packed_rhs_plane_bytes(layout) bytes, 0 where the pairing is not
- * offered -- is written by the same pass when `hi_plane` (device, 16-byte aligned) is given.  Otherwise as cpir_op_transpose_compress. */
+ * b >= 9 (cpir_packed_rhs_offered) the image's low-byte operand pieces are also the first operand plane of the matrix-core matmul
+ * (csrc/matmul_mfma.hip).  The second plane is the byte (field >> 8) XOR 0x80 of every field:
+ *   b = 9  : that byte is the image's ONE bit plane; the matmul expands it in registers and no plane exists (plane bytes 0, hi_plane NULL);
+ *   b >= 10: cpir_packed_rhs_plane_bytes(layout) bytes, written by the same pass into `hi_plane` (device, 16-byte aligned).
+ * Otherwise as cpir_op_transpose_compress.  CPIR_ERR_INVALID_ARGUMENT where the pairing is not offered or hi_plane does not match. */
+int cpir_packed_rhs_offered(const cpir_dtc_layout* layout);
 uint64_t cpir_packed_rhs_plane_bytes(const cpir_dtc_layout* layout);
 int cpir_op_transpose_compress_with_plane(cpir_device* dev, const uint32_t* D, uint64_t ldd, const cpir_dtc_layout* layout,
                                           uint32_t* dtc, uint32_t* or_of_entries, void* hi_plane, void* stream);
 /* M (rows x layout->num_cols, leading dim ldm) (+)= A (rows x layout->num_slots, leading dim lda, 16-byte aligned, lda and num_slots
- * multiples of 4) * D, with D given as its packed image `dtc` and the plane written by cpir_op_transpose_compress_with_plane.  Equal to
+ * multiples of 4) * D, with D given as its packed image `dtc` and the plane written by cpir_op_transpose_compress_with_plane (NULL where that
+ * plane has 0 bytes: b = 9).  Equal to
  * cpir_op_mat_x_mat on the unpacked D whenever every entry of D is below 2^b (the image holds the entries masked to b bits, matrix.rs:121;
  * the OR of the entries from the packing pass proves it).  CPIR_ERR_INVALID_ARGUMENT where the pairing is not offered. */
 int cpir_op_mat_x_packed(cpir_device* dev, const uint32_t* A, uint64_t lda, const uint32_t* dtc, const cpir_dtc_layout* layout,

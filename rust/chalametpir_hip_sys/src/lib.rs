@@ -100,6 +100,7 @@ unsafe extern "C" {
     pub fn cpir_op_transpose_compress(dev: *mut cpir_device, d: *const u32, ldd: u64, layout: *const cpir_dtc_layout,
                                       dtc: *mut u32, or_of_entries: *mut u32, stream: *mut c_void) -> c_int;
     pub fn cpir_packed_rhs_plane_bytes(layout: *const cpir_dtc_layout) -> u64;
+    pub fn cpir_packed_rhs_offered(layout: *const cpir_dtc_layout) -> c_int;
     pub fn cpir_op_transpose_compress_with_plane(dev: *mut cpir_device, d: *const u32, ldd: u64, layout: *const cpir_dtc_layout,
                                                  dtc: *mut u32, or_of_entries: *mut u32, hi_plane: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn cpir_op_mat_x_packed(dev: *mut cpir_device, a: *const u32, lda: u64, dtc: *const u32, layout: *const cpir_dtc_layout,

@@ -309,10 +309,10 @@ def test_hint_matmul_at_this_shape(cfg, device):
     import chalametpir_amd as cp
 
     L = f.srv.layout
-    plane_bytes = cp.packed_rhs_plane_bytes(L)
-    if plane_bytes:
+    plane_bytes = cp.packed_rhs_plane_bytes(L)  # 0 with b = 9: the matmul expands the image's one bit plane itself
+    if cp.packed_rhs_offered(L):
         dtc = torch.empty(int(L.total_words), dtype=torch.int32, device="cuda")
-        plane = torch.empty(plane_bytes // 4, dtype=torch.int32, device="cuda")
+        plane = torch.empty(plane_bytes // 4, dtype=torch.int32, device="cuda") if plane_bytes else None
         flag = torch.zeros(1, dtype=torch.int32, device="cuda")
         device.transpose_compress_with_plane(f.D, L, dtc, plane, or_of_entries=flag, stream=f.stream)
         M2 = torch.full((R, f.C), -1, dtype=torch.int32, device="cuda")

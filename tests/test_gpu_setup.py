@@ -225,7 +225,9 @@ def test_mat_x_packed_takes_the_packed_image_as_right_hand_side(orc, device):
     for b, rows, N, C in ((9, 1, 4, 1), (9, 128, 512, 16), (10, 129, 64 * 5 + 4, 17), (9, 257, 8192 + 60, 940), (12, 300, 4 * 3333, 33),
                           (14, 77, 512 * 9 - 4, 130), (11, 1774, 64 * 17, 20), (9, 16, 1 << 17, 16)):
         L = cp.dtc_layout_for(N, C, b, packing=2)
-        assert L.packing == 2 and cp.packed_rhs_plane_bytes(L) == (L.rows_padded // 16) * ((N + 63) // 64) * 1024
+        # one bit plane (b = 9): the matmul expands the high byte from the image's own plane, no plane is written; more: one byte per field
+        assert L.packing == 2 and cp.packed_rhs_offered(L)
+        assert cp.packed_rhs_plane_bytes(L) == (0 if b == 9 else (L.rows_padded // 16) * ((N + 63) // 64) * 1024)
         A = random_query(rng, rows * N).reshape(rows, N)
         A.reshape(-1)[rng.integers(0, A.size, size=min(A.size, 4096))] = rng.choice(extremes_a, size=min(A.size, 4096))
         if rows >= 3:
@@ -239,7 +241,7 @@ def test_mat_x_packed_takes_the_packed_image_as_right_hand_side(orc, device):
         A_dev, D_dev = _dev(A), _dev(D)
         dtc = torch.full((L.total_words,), -1, dtype=torch.int32, device="cuda")
         dtc_plain = torch.full((L.total_words,), -1, dtype=torch.int32, device="cuda")
-        plane = torch.full((cp.packed_rhs_plane_bytes(L) // 4,), -1, dtype=torch.int32, device="cuda")
+        plane = torch.full((cp.packed_rhs_plane_bytes(L) // 4,), -1, dtype=torch.int32, device="cuda") if cp.packed_rhs_plane_bytes(L) else None
         flag = torch.zeros(1, dtype=torch.int32, device="cuda")
         device.transpose_compress_with_plane(D_dev, L, dtc, plane, or_of_entries=flag, stream=stream)
         device.transpose_compress(D_dev, L, dtc_plain, stream=stream)
@@ -258,9 +260,18 @@ def test_mat_x_packed_takes_the_packed_image_as_right_hand_side(orc, device):
         device.mat_x_packed(A_dev, dtc, L, plane, M2, rows, accumulate=True, stream=stream)
         torch.cuda.synchronize()
         assert np.array_equal(_host(M2), base + want), ("accumulate", b, rows, N, C)
+    # a plane where none belongs (b = 9) and none where one does (b = 10) are refused
+    some = torch.zeros(1 << 16, dtype=torch.int32, device="cuda")
+    for bb, pl in ((9, some), (10, None)):
+        L = cp.dtc_layout_for(4096, 16, bb, packing=2)
+        dtc = torch.zeros(L.total_words, dtype=torch.int32, device="cuda")
+        with pytest.raises(cp.ChalametPIRError):
+            device.transpose_compress_with_plane(some, L, dtc, pl, stream=stream)
+        with pytest.raises(cp.ChalametPIRError):
+            device.mat_x_packed(some, dtc, L, pl, some, 1, stream=stream)
     # where the pairing is not offered
     for L in (cp.dtc_layout_for(4096, 16, 8, packing=2), cp.dtc_layout_for(4096, 16, 9, packing=0)):
-        assert cp.packed_rhs_plane_bytes(L) == 0
+        assert cp.packed_rhs_plane_bytes(L) == 0 and not cp.packed_rhs_offered(L)
         dtc = torch.zeros(L.total_words, dtype=torch.int32, device="cuda")
         some = torch.zeros(1 << 16, dtype=torch.int32, device="cuda")
         with pytest.raises(cp.ChalametPIRError):

@@ -146,7 +146,8 @@ def test_mat_x_packed_beyond_the_pipelined_kernels_reach_is_refused_up_front(dev
     device.synth_fill(D, N * C, 0xD0, mask=(1 << b) - 1, stream=stream)
     device.synth_fill(A, rows * N, 0xA0, stream=stream)
     dtc = torch.empty(L.total_words, dtype=torch.int32, device="cuda")
-    plane = torch.empty(cp.packed_rhs_plane_bytes(L) // 4, dtype=torch.int32, device="cuda")
+    assert cp.packed_rhs_offered(L) and cp.packed_rhs_plane_bytes(L) == 0  # b = 9: the high byte comes out of the image's own bit plane
+    plane = None
     device.transpose_compress_with_plane(D, L, dtc, plane, stream=stream)
     M = torch.full((rows, C), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
     with pytest.raises(cp.ChalametPIRError):
