@@ -15,6 +15,11 @@
 #include "device_bytes.hpp"
 
 namespace cpir {
+
+static std::atomic<int> g_pack_rows{-1};  // tuning "pack.rows": -1 by width, 0 the 64-column waves, 1 whole rows per block
+int pack_rows_mode() { return g_pack_rows.load(); }
+void set_pack_rows_mode(int m) { g_pack_rows.store(m); }
+
 namespace {
 
 constexpr int kTileCols = 64;   // columns of D (= rows of DtC) per block
@@ -510,6 +515,167 @@ __global__ void __launch_bounds__(kThreads) planar_pack_stream_kernel(const Pack
   pack_stream_unit<HB, VEC, GUARD>(a, stage[wave], lane, sg * 4 + wave, ks);
 }
 
+// ---- the same pass with WHOLE ROWS per block (wide databases) ---------------------------------------------------------------------
+// pack_stream_unit gives a wave 64 columns, so one load instruction fetches 4 x 256 bytes from 4 rows 16 apart and a block reads 1 KiB
+// pieces of its rows: the memory system sees short segments from many rows at once.  Here a wave owns 256 adjacent columns (16 column
+// tiles): lane l holds columns 4l .. 4l + 3 of the stripe, one load instruction reads 1 KiB CONTIGUOUS of one row, and the four waves of
+// a block cover 1024 columns -- with C <= 1024 (2^20 keys x 1 kB values: 940) a block streams whole rows, 16 consecutive rows = one
+// contiguous run of D per batch.  A batch is 16 rows (one slot group g of a k-block); the 512 slots of a step are walked slot group by
+// slot group (g outer, the 8 k-blocks inner), so that the bit planes of a (column, slot group) -- which span all 8 k-blocks -- still
+// accumulate in four registers per column and plane.  What a batch produces for a column tile is the QUARTER of an operand piece that
+// belongs to slot group g: 16 lanes x 16 bytes = 256 contiguous bytes, so every store instruction writes four 256-byte runs (the
+// streaming kernel writes 1 KiB runs; reads outnumber writes 3.5 to 1).
+// position of fragment p = 4 * lane + i (written) / 64 * k + lane (read back) in the wave's staging window: the low two bits are XOR-ed with
+// bits 4..5, so that the 8 lanes a ds_write_b128 serves together -- 64 bytes apart -- fall into 8 different 16-byte bank groups; a
+// permutation inside aligned groups of 4 fragments, so the linear read-back stays conflict-free
+__device__ __forceinline__ uint32_t rows_swz(uint32_t p) { return p ^ ((p >> 4) & 3u); }
+
+template <int HB, bool VEC, bool GUARD>
+__device__ __forceinline__ void pack_rows_unit(const PackStreamArgs& a, uint4* my_stage, uint32_t lane, uint32_t wstripe, uint32_t ks) {
+  constexpr uint32_t ST16 = (8 + HB) * 64;  // uint4 per super-tile
+  constexpr uint32_t HMASK = ((1u << HB) - 1u) * 0x01010101u;
+  constexpr int HP = HB ? HB : 1;
+  const uint32_t c0 = wstripe * 256 + 4 * lane;  // this lane's first column
+  const uint32_t T0 = wstripe * 16;              // the wave's first column tile
+  const uint64_t n0 = (uint64_t)ks * CPIR_PLANAR_SLOTS_PER_TILE;
+  bool cvalid[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) cvalid[i] = c0 + i < a.C;
+  const uint32_t csafe = cvalid[0] ? c0 : 0;  // (as pack_stream_unit: a lane wholly past C reads column 0.. of the same rows and zeroes them)
+  uint32_t colsum_acc[4] = {0, 0, 0, 0}, seen = 0;
+
+#pragma unroll 1
+  for (uint32_t g = 0; g < 4; g++) {
+    uint32_t plane[4][HP][4];
+    uint32_t lowsum[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int p = 0; p < HP; p++)
+#pragma unroll
+        for (int w = 0; w < 4; w++) plane[i][p][w] = 0;
+#pragma unroll
+    for (int kb = 0; kb < 8; kb++) {
+      uint32_t v[16][4];
+      const uint64_t nb = n0 + 64 * kb + 16 * g;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const uint64_t n = nb + j;
+        const uint64_t nr = (!GUARD || n < a.N) ? n : a.N - 1;  // clamped rows are zeroed below
+        if constexpr (VEC) {
+          const uint4 t = *reinterpret_cast<const uint4*>(a.D + nr * a.ld + csafe);
+          v[j][0] = t.x, v[j][1] = t.y, v[j][2] = t.z, v[j][3] = t.w;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; i++) v[j][i] = a.D[nr * a.ld + (cvalid[i] ? c0 + i : 0)];
+        }
+      }
+      uint32_t seen_kb = 0;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const bool rv = !GUARD || nb + j < a.N;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          v[j][i] = (rv && cvalid[i]) ? v[j][i] : 0u;
+          seen_kb |= v[j][i];
+        }
+      }
+      seen |= seen_kb;
+      asm volatile("" : "+v"(seen));
+      uint32_t W[4][4], WH[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+          WH[i][d] = 0x80808080u;
+          const uint32_t lo = gather_byte4(v[4 * d][i], v[4 * d + 1][i], v[4 * d + 2][i], v[4 * d + 3][i], 0x0400u) & a.low_mask;
+          lowsum[i] = __builtin_amdgcn_sad_u8(lo, 0u, lowsum[i]);
+          W[i][d] = lo ^ 0x80808080u;
+          if constexpr (HB > 0) {
+            const uint32_t hi = gather_byte4(v[4 * d][i], v[4 * d + 1][i], v[4 * d + 2][i], v[4 * d + 3][i], 0x0501u) & HMASK;
+#pragma unroll
+            for (int p = 0; p < HB; p++) plane[i][p][kb >> 1] |= ((hi >> p) & 0x01010101u) << (4 * (kb & 1) + d);
+            WH[i][d] = hi ^ 0x80808080u;
+          }
+        }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        asm volatile("" : "+v"(lowsum[i]));
+#pragma unroll
+        for (int p = 0; p < HB; p++) asm volatile("" : "+v"(plane[i][p][kb >> 1]));
+      }
+      // this lane's four fragments (slot group g of k-block kb, columns c0 .. c0 + 3) -> their quarter pieces, via the staging window
+#pragma unroll
+      for (int i = 0; i < 4; i++) my_stage[rows_swz(4 * lane + i)] = make_uint4(W[i][0], W[i][1], W[i][2], W[i][3]);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint4 x = my_stage[rows_swz(64 * k + lane)];
+        const uint32_t T = T0 + 4 * k + (lane >> 4);
+        if (T < a.col_tiles) a.tiles[((uint64_t)T * a.ks_total + ks) * ST16 + kb * 64 + 16 * g + (lane & 15)] = x;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (HB > 0 && a.hi_plane) {  // wave-uniform: the same fragments of the high-byte plane, through the same window
+        const uint32_t kbg = ks * 8 + kb;
+#pragma unroll
+        for (int i = 0; i < 4; i++) my_stage[rows_swz(4 * lane + i)] = make_uint4(WH[i][0], WH[i][1], WH[i][2], WH[i][3]);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint4 x = my_stage[rows_swz(64 * k + lane)];
+          const uint32_t T = T0 + 4 * k + (lane >> 4);
+          if (T < a.col_tiles && kbg < a.kb_total) a.hi_plane[((uint64_t)T * a.kb_total + kbg) * 64 + 16 * g + (lane & 15)] = x;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // the bit planes of slot group g: one fragment per column and plane
+#pragma unroll
+    for (int p = 0; p < HB; p++) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) my_stage[rows_swz(4 * lane + i)] = make_uint4(plane[i][p][0], plane[i][p][1], plane[i][p][2], plane[i][p][3]);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint4 x = my_stage[rows_swz(64 * k + lane)];
+        const uint32_t T = T0 + 4 * k + (lane >> 4);
+        if (T < a.col_tiles) a.tiles[((uint64_t)T * a.ks_total + ks) * ST16 + 512 + p * 64 + 16 * g + (lane & 15)] = x;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    // field sums of this slot group: low bytes + 2^(8+p) * (ones in plane p)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      uint32_t sum = lowsum[i];
+#pragma unroll
+      for (int p = 0; p < HB; p++)
+        sum += (uint32_t)(__builtin_popcount(plane[i][p][0]) + __builtin_popcount(plane[i][p][1]) + __builtin_popcount(plane[i][p][2]) +
+                          __builtin_popcount(plane[i][p][3])) << (8 + p);
+      colsum_acc[i] += sum;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    if (colsum_acc[i]) atomicAdd(a.colsum + c0 + i, colsum_acc[i]);  // != 0 implies c0 + i < C
+  if (a.or_of_entries) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) seen |= __shfl_xor(seen, off, 64);
+    if (lane == 0 && seen) atomicOr(a.or_of_entries, seen);
+  }
+}
+
+template <int HB, bool VEC, bool GUARD>
+__global__ void __launch_bounds__(kThreads) planar_pack_rows_kernel(const PackStreamArgs a, uint32_t ks_first) {
+  __shared__ uint4 stage[kThreads / 64][256];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t sg = blockIdx.x % a.stripe_groups;  // groups of 1024 columns; fastest, so that co-resident blocks read whole rows
+  const uint32_t ks = ks_first + blockIdx.x / a.stripe_groups;
+  const uint32_t wstripe = sg * 4 + wave;
+  if (wstripe * 16 >= a.col_tiles) return;  // wave-uniform: nothing of this stripe exists (no block-wide barrier anywhere)
+  pack_rows_unit<HB, VEC, GUARD>(a, stage[wave], lane, wstripe, ks);
+}
+
 // field (n, c) of a planar image
 __device__ __forceinline__ uint32_t planar_field(const uint8_t* bytes, uint64_t n, uint32_t c, uint32_t hb, uint32_t ks_total) {
   const uint32_t T = c >> 4, cl = c & 15;
@@ -555,7 +721,10 @@ int launch_planar_pack(const uint32_t* src, uint64_t ld, bool from_ref, const cp
     CPIR_HIP_TRY(hipGetLastError());
     return CPIR_OK;
   }
-  const uint32_t stripe_groups = (col_tiles + 15) / 16;  // 4 waves x 4 tiles per block
+  // wide databases: whole rows per block (planar_pack_rows_kernel); narrow ones keep the 64-column waves, which waste fewer lanes there
+  const int rows_mode = pack_rows_mode();
+  const bool rows = rows_mode > 0 || (rows_mode < 0 && col_tiles >= 32);
+  const uint32_t stripe_groups = rows ? (col_tiles + 63) / 64 : (col_tiles + 15) / 16;  // 4 waves x 16 (4) tiles per block
   if (ks_total * stripe_groups > 0x7fffffffull) return CPIR_ERR_INVALID_ARGUMENT;
   const uint64_t full_steps = L.num_slots / CPIR_PLANAR_SLOTS_PER_TILE;  // steps that lie wholly inside the database
   const bool vec = (ld % 4 == 0) && (reinterpret_cast<uintptr_t>(src) % 16 == 0);
@@ -565,14 +734,17 @@ int launch_planar_pack(const uint32_t* src, uint64_t ld, bool from_ref, const cp
   pa.low_mask = L.mat_elem_bit_len < 8 ? ((1u << L.mat_elem_bit_len) - 1u) * 0x01010101u : 0xFFFFFFFFu;
   pa.hi_plane = hb ? hi_plane : nullptr;
   pa.kb_total = (uint32_t)((L.num_slots + 63) / 64);
-#define LAUNCH_PP2(HB_, VEC_)                                                                                                       \
+#define LAUNCH_PP3(KERNEL_, HB_, VEC_)                                                                                            \
   do {                                                                                                                              \
     if (full_steps)                                                                                                                 \
-      hipLaunchKernelGGL((planar_pack_stream_kernel<HB_, VEC_, false>), dim3((unsigned)(full_steps * stripe_groups)), dim3(kThreads), \
-                         0, stream, pa, 0u);                                                                                        \
+      hipLaunchKernelGGL((KERNEL_<HB_, VEC_, false>), dim3((unsigned)(full_steps * stripe_groups)), dim3(kThreads), 0, stream, pa, 0u); \
     if (full_steps < ks_total)                                                                                                      \
-      hipLaunchKernelGGL((planar_pack_stream_kernel<HB_, VEC_, true>), dim3(stripe_groups), dim3(kThreads), 0, stream, pa,         \
-                         (uint32_t)full_steps);                                                                                     \
+      hipLaunchKernelGGL((KERNEL_<HB_, VEC_, true>), dim3(stripe_groups), dim3(kThreads), 0, stream, pa, (uint32_t)full_steps);     \
+  } while (0)
+#define LAUNCH_PP2(HB_, VEC_)                                       \
+  do {                                                              \
+    if (rows) LAUNCH_PP3(planar_pack_rows_kernel, HB_, VEC_);       \
+    else LAUNCH_PP3(planar_pack_stream_kernel, HB_, VEC_);          \
   } while (0)
 #define LAUNCH_PP(HB_)               \
   do {                               \
@@ -590,6 +762,7 @@ int launch_planar_pack(const uint32_t* src, uint64_t ld, bool from_ref, const cp
     default: return CPIR_ERR_INVALID_ARGUMENT;
   }
 #undef LAUNCH_PP2
+#undef LAUNCH_PP3
 #undef LAUNCH_PP
   CPIR_HIP_TRY(hipGetLastError());
   return CPIR_OK;

@@ -261,6 +261,7 @@ int cpir_op_synth_fill(cpir_device* dev, uint32_t* out, uint64_t count, uint64_t
  *   cpir_op_mat_x_mat and the setup paths run right-hand sides below 2^16 on the i8 matrix cores; 0: on the integer VALU),
  *   "matmul.pipeline" {0,1} (1, the default: the software-pipelined matrix-core kernel; 0: its first cut),
  *   "matmul.ablate" (diagnosis only, results are WRONG while it is non-zero: bit mask of parts of the matrix-core matmul to skip),
+ *   "pack.rows" {-1,0,1} (the planar pack pass: 1 = a block streams whole rows of D, 0 = 64-column waves, -1 -- the default -- by width),
  *   "layout.dense" {0,1} and "layout.planar" {0,1}
  *   (default packing chosen by cpir_dtc_layout_for and therefore by every cpir_server_* constructor: planar where it is
  *   offered and enabled, else dense64 where offered and enabled, else the reference packing).

@@ -211,7 +211,7 @@ def test_every_documented_tuning_key_is_accepted_and_bounded():
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     header = open(os.path.join(ROOT, "include", "chalamet_hip.h")).read()
     doc = header[header.index("Tuning knobs of the respond kernel"):header.index("int cpir_tuning_set")]
-    documented = set(re.findall(r'"((?:respond|matmul|layout)\.[a-z_]+)"', doc))
+    documented = set(re.findall(r'"((?:respond|matmul|layout|pack)\.[a-z_]+)"', doc))
     source = open(os.path.join(ROOT, "chalametpir_amd", "csrc", "respond.hip")).read()
     accepted = set(re.findall(r'!strcmp\(key, "([a-z_.]+)"\)', source))
     assert accepted == documented, (sorted(accepted - documented), sorted(documented - accepted))
