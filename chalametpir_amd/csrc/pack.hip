@@ -543,91 +543,111 @@ __device__ __forceinline__ void pack_rows_unit(const PackStreamArgs& a, uint4* m
   for (int i = 0; i < 4; i++) cvalid[i] = c0 + i < a.C;
   const uint32_t csafe = cvalid[0] ? c0 : 0;  // (as pack_stream_unit: a lane wholly past C reads column 0.. of the same rows and zeroes them)
   uint32_t colsum_acc[4] = {0, 0, 0, 0}, seen = 0;
+  uint32_t plane[4][HP][4];
+  uint32_t lowsum[4] = {0, 0, 0, 0};
 
-#pragma unroll 1
-  for (uint32_t g = 0; g < 4; g++) {
-    uint32_t plane[4][HP][4];
-    uint32_t lowsum[4] = {0, 0, 0, 0};
+  // the 16 rows of batch (g_, kb_): row pointers are wave-uniform (scalar registers), the lane adds its column offset
+  auto load_batch = [&](uint4(&buf)[16], uint32_t g_, uint32_t kb_) {
+    const uint64_t nb = n0 + 64 * kb_ + 16 * g_;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint64_t n = nb + j;
+      const uint64_t nr = (!GUARD || n < a.N) ? n : a.N - 1;  // clamped rows are zeroed in process_batch
+      if constexpr (VEC) {
+        buf[j] = *reinterpret_cast<const uint4*>(a.D + nr * a.ld + csafe);
+      } else {
+        const uint32_t* row = a.D + nr * a.ld;
+        buf[j] = make_uint4(row[cvalid[0] ? c0 : 0], row[cvalid[1] ? c0 + 1 : 0], row[cvalid[2] ? c0 + 2 : 0], row[cvalid[3] ? c0 + 3 : 0]);
+      }
+    }
+  };
+
+  auto process_batch = [&](const uint4(&buf)[16], uint32_t g, int kb) {
+    const uint64_t nb = n0 + 64 * kb + 16 * g;
+    // columns past C and (GUARD) rows past N contribute zero fields.  The row condition is wave-uniform and only exists in the guarded
+    // kernel; the column condition is applied to the 16 gathered words of a column, not to its 64 loaded ones
+    uint32_t e[16][4];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const bool rv = !GUARD || nb + j < a.N;
+      e[j][0] = rv ? buf[j].x : 0u, e[j][1] = rv ? buf[j].y : 0u, e[j][2] = rv ? buf[j].z : 0u, e[j][3] = rv ? buf[j].w : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      uint32_t col_or = 0;
+#pragma unroll
+      for (int j = 0; j < 16; j++) col_or |= e[j][i];
+      seen |= cvalid[i] ? col_or : 0u;
+    }
+    asm volatile("" : "+v"(seen));
+    uint32_t W[4][4], WH[4][4];
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-      for (int p = 0; p < HP; p++)
+      for (int d = 0; d < 4; d++) {
+        WH[i][d] = 0x80808080u;
+        uint32_t lo = gather_byte4(e[4 * d][i], e[4 * d + 1][i], e[4 * d + 2][i], e[4 * d + 3][i], 0x0400u) & a.low_mask;
+        lo = cvalid[i] ? lo : 0u;
+        lowsum[i] = __builtin_amdgcn_sad_u8(lo, 0u, lowsum[i]);
+        W[i][d] = lo ^ 0x80808080u;
+        if constexpr (HB > 0) {
+          uint32_t hi = gather_byte4(e[4 * d][i], e[4 * d + 1][i], e[4 * d + 2][i], e[4 * d + 3][i], 0x0501u) & HMASK;
+          hi = cvalid[i] ? hi : 0u;
 #pragma unroll
-        for (int w = 0; w < 4; w++) plane[i][p][w] = 0;
-#pragma unroll
-    for (int kb = 0; kb < 8; kb++) {
-      uint32_t v[16][4];
-      const uint64_t nb = n0 + 64 * kb + 16 * g;
-#pragma unroll
-      for (int j = 0; j < 16; j++) {
-        const uint64_t n = nb + j;
-        const uint64_t nr = (!GUARD || n < a.N) ? n : a.N - 1;  // clamped rows are zeroed below
-        if constexpr (VEC) {
-          const uint4 t = *reinterpret_cast<const uint4*>(a.D + nr * a.ld + csafe);
-          v[j][0] = t.x, v[j][1] = t.y, v[j][2] = t.z, v[j][3] = t.w;
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; i++) v[j][i] = a.D[nr * a.ld + (cvalid[i] ? c0 + i : 0)];
+          for (int p = 0; p < HB; p++) plane[i][p][kb >> 1] |= ((hi >> p) & 0x01010101u) << (4 * (kb & 1) + d);
+          WH[i][d] = hi ^ 0x80808080u;
         }
       }
-      uint32_t seen_kb = 0;
 #pragma unroll
-      for (int j = 0; j < 16; j++) {
-        const bool rv = !GUARD || nb + j < a.N;
+    for (int i = 0; i < 4; i++) {
+      asm volatile("" : "+v"(lowsum[i]));
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          v[j][i] = (rv && cvalid[i]) ? v[j][i] : 0u;
-          seen_kb |= v[j][i];
-        }
-      }
-      seen |= seen_kb;
-      asm volatile("" : "+v"(seen));
-      uint32_t W[4][4], WH[4][4];
+      for (int p = 0; p < HB; p++) asm volatile("" : "+v"(plane[i][p][kb >> 1]));
+    }
+    // this lane's four fragments (slot group g of k-block kb, columns c0 .. c0 + 3) -> their quarter pieces, via the staging window
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 4; i++) my_stage[rows_swz(4 * lane + i)] = make_uint4(W[i][0], W[i][1], W[i][2], W[i][3]);
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int d = 0; d < 4; d++) {
-          WH[i][d] = 0x80808080u;
-          const uint32_t lo = gather_byte4(v[4 * d][i], v[4 * d + 1][i], v[4 * d + 2][i], v[4 * d + 3][i], 0x0400u) & a.low_mask;
-          lowsum[i] = __builtin_amdgcn_sad_u8(lo, 0u, lowsum[i]);
-          W[i][d] = lo ^ 0x80808080u;
-          if constexpr (HB > 0) {
-            const uint32_t hi = gather_byte4(v[4 * d][i], v[4 * d + 1][i], v[4 * d + 2][i], v[4 * d + 3][i], 0x0501u) & HMASK;
+    for (int k = 0; k < 4; k++) {
+      const uint4 x = my_stage[rows_swz(64 * k + lane)];
+      const uint32_t T = T0 + 4 * k + (lane >> 4);
+      if (T < a.col_tiles) a.tiles[((uint64_t)T * a.ks_total + ks) * ST16 + kb * 64 + 16 * g + (lane & 15)] = x;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (HB > 1 && a.hi_plane) {  // wave-uniform: the same fragments of the high-byte plane, through the same window (one bit plane: no such plane)
+      const uint32_t kbg = ks * 8 + kb;
 #pragma unroll
-            for (int p = 0; p < HB; p++) plane[i][p][kb >> 1] |= ((hi >> p) & 0x01010101u) << (4 * (kb & 1) + d);
-            WH[i][d] = hi ^ 0x80808080u;
-          }
-        }
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        asm volatile("" : "+v"(lowsum[i]));
-#pragma unroll
-        for (int p = 0; p < HB; p++) asm volatile("" : "+v"(plane[i][p][kb >> 1]));
-      }
-      // this lane's four fragments (slot group g of k-block kb, columns c0 .. c0 + 3) -> their quarter pieces, via the staging window
-#pragma unroll
-      for (int i = 0; i < 4; i++) my_stage[rows_swz(4 * lane + i)] = make_uint4(W[i][0], W[i][1], W[i][2], W[i][3]);
+      for (int i = 0; i < 4; i++) my_stage[rows_swz(4 * lane + i)] = make_uint4(WH[i][0], WH[i][1], WH[i][2], WH[i][3]);
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const uint4 x = my_stage[rows_swz(64 * k + lane)];
         const uint32_t T = T0 + 4 * k + (lane >> 4);
-        if (T < a.col_tiles) a.tiles[((uint64_t)T * a.ks_total + ks) * ST16 + kb * 64 + 16 * g + (lane & 15)] = x;
+        if (T < a.col_tiles && kbg < a.kb_total) a.hi_plane[((uint64_t)T * a.kb_total + kbg) * 64 + 16 * g + (lane & 15)] = x;
       }
       __builtin_amdgcn_wave_barrier();
-      if (HB > 0 && a.hi_plane) {  // wave-uniform: the same fragments of the high-byte plane, through the same window
-        const uint32_t kbg = ks * 8 + kb;
+    }
+  };
+
+  // (Requesting batch t + 1 before batch t is processed -- two register sets -- changes nothing: 1.12 ms either way at 2^20 keys; the pass is
+  // bound by what the memory system makes of the mix of this read stream and the scattered 256-byte writes, and where the image happens to
+  // lie relative to D moves the time by up to 10 %.)
+  uint4 buf[16];
+#pragma unroll 1
+  for (uint32_t g = 0; g < 4; g++) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) my_stage[rows_swz(4 * lane + i)] = make_uint4(WH[i][0], WH[i][1], WH[i][2], WH[i][3]);
-        __builtin_amdgcn_wave_barrier();
+    for (int i = 0; i < 4; i++) {
+      lowsum[i] = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const uint4 x = my_stage[rows_swz(64 * k + lane)];
-          const uint32_t T = T0 + 4 * k + (lane >> 4);
-          if (T < a.col_tiles && kbg < a.kb_total) a.hi_plane[((uint64_t)T * a.kb_total + kbg) * 64 + 16 * g + (lane & 15)] = x;
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
+      for (int p = 0; p < HP; p++)
+#pragma unroll
+        for (int w = 0; w < 4; w++) plane[i][p][w] = 0;
+    }
+#pragma unroll
+    for (int kb = 0; kb < 8; kb++) {
+      load_batch(buf, g, kb);
+      process_batch(buf, g, kb);
       __builtin_amdgcn_sched_barrier(0);
     }
     // the bit planes of slot group g: one fragment per column and plane
@@ -723,7 +743,8 @@ int launch_planar_pack(const uint32_t* src, uint64_t ld, bool from_ref, const cp
   }
   // wide databases: whole rows per block (planar_pack_rows_kernel); narrow ones keep the 64-column waves, which waste fewer lanes there
   const int rows_mode = pack_rows_mode();
-  const bool rows = rows_mode > 0 || (rows_mode < 0 && col_tiles >= 32);
+  // (with two or more bit planes the whole-rows kernel needs more registers than two waves per SIMD leave it: the 64-column waves stay)
+  const bool rows = rows_mode > 0 || (rows_mode < 0 && col_tiles >= 32 && hb <= 1);
   const uint32_t stripe_groups = rows ? (col_tiles + 63) / 64 : (col_tiles + 15) / 16;  // 4 waves x 16 (4) tiles per block
   if (ks_total * stripe_groups > 0x7fffffffull) return CPIR_ERR_INVALID_ARGUMENT;
   const uint64_t full_steps = L.num_slots / CPIR_PLANAR_SLOTS_PER_TILE;  // steps that lie wholly inside the database

@@ -25,21 +25,28 @@ dev.synth_fill(D, N * C, 0xD, mask=(1 << b) - 1, stream=stream)
 L = cp.dtc_layout_for(N, C, b)
 imgs = {}
 alg = 4 * N * C + 4 * C * -(-N // cf)
-for mode in (0, 1):
-    cp.tuning_set("pack.rows", mode)
-    dtc = torch.zeros(int(L.total_words), dtype=torch.int32, device="cuda")
-    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
-    dev.transpose_compress(D, L, dtc, or_of_entries=flag, stream=stream)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(reps):
-        dev.transpose_compress(D, L, dtc, stream=stream)
-    e1.record(stream)
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    imgs[mode] = dtc
-    moved = 4 * N * C + 4 * int(L.total_words)
-    print(f"{cfg} N={N} C={C} b={b} pack.rows={mode}: {ms:.3f} ms  algorithmic {alg / ms / 1e6:.0f} GB/s = {alg / ms / 1e6 / 8000:.3f} of 8 TB/s; "
-          f"moved {moved / ms / 1e6:.0f} GB/s; OR of entries {int(flag.item()):#x}", flush=True)
-print("images identical:", bool(torch.equal(imgs[0], imgs[1])), flush=True)
+moved = 4 * N * C + 4 * int(L.total_words)
+modes = [int(x) for x in os.environ.get("CPIR_PACK_MODES", "0,1").split(",")]
+# the same destination buffers for every mode (where a buffer lies in HBM relative to D shifts the time by several per cent), two of them
+bufs = [torch.zeros(int(L.total_words), dtype=torch.int32, device="cuda") for _ in range(2)]
+pad = torch.zeros(3 << 20, dtype=torch.int32, device="cuda")  # (keeps the second buffer from sitting at the same offset modulo large powers of two)
+bufs.append(torch.zeros(int(L.total_words), dtype=torch.int32, device="cuda"))
+for rnd in range(2):
+    for mode in modes:
+        cp.tuning_set("pack.rows", mode)
+        times = []
+        for dtc in bufs:
+            dev.transpose_compress(D, L, dtc, stream=stream)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(reps):
+                dev.transpose_compress(D, L, dtc, stream=stream)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1) / reps)
+        imgs[mode] = bufs[0].clone()
+        ms = min(times)
+        print(f"{cfg} N={N} C={C} b={b} pack.rows={mode}: per buffer {' '.join(f'{t:.3f}' for t in times)} ms; best: algorithmic {alg / ms / 1e6:.0f} GB/s = "
+              f"{alg / ms / 1e6 / 8000:.3f} of 8 TB/s, moved {moved / ms / 1e6:.0f} GB/s", flush=True)
+print("images identical:", all(bool(torch.equal(imgs[modes[0]], imgs[m])) for m in modes), flush=True)

@@ -38,7 +38,8 @@ def test_transpose_compress_matches_oracle(b, orc, device):
 
     rng = np.random.default_rng(200 + b)
     cf = cf_of(b)
-    for N, C in ((cf * 64 + 1, 5), (cf * 300 + cf - 1, 66), (1, 1), (cf * 2048, 130), (777, 64)):
+    # (the last two shapes are wide enough for the whole-rows pack kernel -- 512+ columns, whole and ragged steps, C % 4 != 0)
+    for N, C in ((cf * 64 + 1, 5), (cf * 300 + cf - 1, 66), (1, 1), (cf * 2048, 130), (777, 64), (1536 + 77, 530), (512, 1031)):
         D = random_db_matrix(rng, N, C, 16)  # entries wider than b: compress must mask them (matrix.rs:121)
         want = orc.row_wise_compress(orc.transpose(D), b)
         srv = cp.Server.from_device_matrix(_dev(D), N, C, b, device=device)
@@ -52,6 +53,16 @@ def test_transpose_compress_matches_oracle(b, orc, device):
         assert int(_host(flag)[0]) == int(np.bitwise_or.reduce(D, axis=None))
         if L.packing == 2:  # planar: low bytes XOR 0x80 + bit planes in MFMA operand order, then the column sums
             check_planar_image(_host(dtc), L, D, b)
+            # both pack kernels (64-column waves / whole rows per block), whatever the width: the same image, the same OR
+            for rows_mode in (0, 1):
+                cp.tuning_set("pack.rows", rows_mode)
+                other = torch.full((L.total_words,), -1, dtype=torch.int32, device="cuda")
+                flag.zero_()
+                device.transpose_compress(_dev(D), L, other, or_of_entries=flag, stream=torch.cuda.current_stream())
+                torch.cuda.synchronize()
+                assert torch.equal(other, dtc), (b, N, C, rows_mode)
+                assert int(_host(flag)[0]) == int(np.bitwise_or.reduce(D, axis=None))
+            cp.tuning_set("pack.rows", -1)
             continue
         img = _host(dtc).reshape(L.rows_padded, L.words_per_row_padded)
         assert not img[C:].any()  # padded rows are zero
@@ -247,6 +258,14 @@ def test_mat_x_packed_takes_the_packed_image_as_right_hand_side(orc, device):
         device.transpose_compress(D_dev, L, dtc_plain, stream=stream)
         torch.cuda.synchronize()
         assert torch.equal(dtc, dtc_plain)
+        for rows_mode in (0, 1):  # both pack kernels write the same image and the same high-byte plane
+            cp.tuning_set("pack.rows", rows_mode)
+            dtc2 = torch.full_like(dtc, -1)
+            plane2 = torch.full_like(plane, -1) if plane is not None else None
+            device.transpose_compress_with_plane(D_dev, L, dtc2, plane2, stream=stream)
+            torch.cuda.synchronize()
+            assert torch.equal(dtc2, dtc) and (plane is None or torch.equal(plane2, plane)), (b, N, C, rows_mode)
+        cp.tuning_set("pack.rows", -1)
         assert int(flag.item()) >> b == 0
         ldm = C + 3
         M = torch.full((rows, ldm), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
