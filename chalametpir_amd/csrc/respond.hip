@@ -436,7 +436,7 @@ uint32_t respond_host_fill_timeout_us() {
 bool respond_read_once_applicable(const cpir_dtc_layout& L) {
   std::lock_guard<std::mutex> lk(g_tuning_mu);
   // one query's responses must fit the step-major kernel's LDS accumulators (48 KiB: 12288 padded columns)
-  return g_tuning.host_zero_copy != 0 && L.packing == CPIR_PACK_PLANAR && (uint64_t)(L.num_cols + 15) / 16 * 64 <= (48u << 10);
+  return g_tuning.host_zero_copy != 0 && L.packing == CPIR_PACK_PLANAR && (uint64_t)(L.num_cols + 63) / 64 * 256 <= (48u << 10);
 }
 
 int launch_respond_read_once(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,

@@ -49,6 +49,8 @@ struct PlanarArgs {
   uint32_t num_cols;       // C
   uint32_t col_tiles;      // rows_padded / 16
   uint32_t tile_groups;    // ceil(col_tiles / kM)
+  uint32_t tg_lo, tg_n;    // step-major kernel: this launch covers tile groups [tg_lo, tg_lo + tg_n) only (a column window: its LDS accumulators
+                           // hold tg_n * 64 columns per query; wide databases answer a fused batch window by window)
   uint32_t ks_total;       // super-tile steps along the slots: ceil(N / 512)
   uint32_t ks_lo, ks_hi;   // this launch covers steps [ks_lo, ks_hi) only (the whole axis unless a host query is being pipelined)
   uint32_t nx;             // slot-axis split by blockIdx % nx (8 or 1)
@@ -323,7 +325,7 @@ respond_planar_ks_kernel(const PlanarArgs a) {
   const int wave = threadIdx.x >> 6;
   const uint32_t cl = lane & 15;
   const uint32_t grp = lane >> 4;
-  const uint32_t cpad = a.col_tiles * 16;
+  const uint32_t cpad = a.tg_n * (kM * 16);  // columns of this launch's window (padded to whole tile groups)
 
   const uint32_t nx = a.nx;
   const uint32_t xcd = blockIdx.x % nx;
@@ -333,7 +335,7 @@ respond_planar_ks_kernel(const PlanarArgs a) {
   const uint32_t kb0 = a.ks_lo + (uint32_t)(((uint64_t)ks_len * xcd) / nx);
   const uint32_t ke0 = a.ks_lo + (uint32_t)(((uint64_t)ks_len * (xcd + 1)) / nx);
   const uint32_t span = ke0 - kb0;
-  const uint32_t TG = a.tile_groups;
+  const uint32_t TG = a.tg_n;  // tile groups of the window, numbered from 0 here; tile group tg of the window is a.tg_lo + tg of the image
   // A block's work is a sequence of VISITS: (step, first tile group, one past the last tile group).
   //   contiguous order: units u = (step kb0 + u / TG, tile group u % TG) of [0, TG * span) split evenly over the blocks;
   //   strided order (nx == 1): `rounds` whole steps per block, step kb0 + r * nb + j in round r -- at any moment the grid works on nb
@@ -487,7 +489,7 @@ respond_planar_ks_kernel(const PlanarArgs a) {
     store_ksum(part, par);
   };
   auto load_tile = [&](uint4(&dst)[NL], uint32_t tg_, uint32_t ks_) {
-    const uint32_t T = tg_ * kM + wave;
+    const uint32_t T = (a.tg_lo + tg_) * kM + wave;
     const uint4* p = tiles + (T < a.col_tiles ? ((uint64_t)T * a.ks_total + ks_) * ST16 : 0) + lane;
 #pragma unroll
     for (int i = 0; i < NL; i++) dst[i] = load16<NT>(p + i * 64);
@@ -546,7 +548,8 @@ respond_planar_ks_kernel(const PlanarArgs a) {
       v4i acc_lo[NS], acc_hi[NS];
 #pragma unroll
       for (int s = 0; s < NS; s++) acc_lo[s] = v4i{0, 0, 0, 0}, acc_hi[s] = v4i{0, 0, 0, 0};
-      const uint32_t T = tg * kM + wave;
+      const uint32_t Tw = tg * kM + wave;          // tile of the window (indexes the LDS accumulators)
+      const uint32_t T = a.tg_lo * kM + Tw;        // tile of the image
       if (T < a.col_tiles) {
 #pragma unroll
         for (int kb = 0; kb < 8; kb++) {
@@ -577,7 +580,7 @@ respond_planar_ks_kernel(const PlanarArgs a) {
           if (query < nq) {
             const uint32_t qsum = (ksum[par][0][query] + ksum[par][1][query]) + (ksum[par][2][query] + ksum[par][3][query]);
             val += 128u * qsum - 0x40404000u * nvs + col_term;  // 128 * 0x80808080 = 0x40404000 mod 2^32
-            atomicAdd(&racc[query * cpad + T * 16 + cl], val);  // LDS; this wave owns tile T of every step
+            atomicAdd(&racc[query * cpad + Tw * 16 + cl], val);  // LDS; this wave owns tile T of every step
           }
         }
       }
@@ -607,7 +610,7 @@ respond_planar_ks_kernel(const PlanarArgs a) {
     // ---- this block's part of the pass's responses ----
     __syncthreads();
     for (uint32_t i2 = threadIdx.x; i2 < nq * cpad; i2 += kThreads) {
-      const uint32_t query = i2 / cpad, col = i2 % cpad, v = racc[i2];
+      const uint32_t query = i2 / cpad, col = a.tg_lo * (kM * 16) + i2 % cpad, v = racc[i2];
       if (col < a.num_cols && v) atomicAdd(a.r + ((uint64_t)pass * nq + query) * a.num_cols + col, v);
     }
     __syncthreads();
@@ -736,24 +739,35 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
   // 32.0 / 25.6, of 4 51.6 / 48.3; one query per pass, 32 passes a launch 185.3 / 185.0 (within half a per cent either way at every
   // config but 2^22 keys) -- so mode 1 keeps the tile-major kernel for that streaming case.  One-row-set step-major blocks run ONE per CU
   // (191.9 against 202.3 with two: half as many prologues and flushes, and 4 waves x 2 tiles in flight already cover the latency).
-  const size_t racc_bytes = (size_t)batch * a.col_tiles * 16 * sizeof(uint32_t);
+  // The step-major kernel keeps a pass's responses in LDS: 64 columns x batch u32 per tile group, at most 48 KiB.  Where all tile groups
+  // do not fit (8 kB values: 7 312 columns x 8 queries = 234 KB) the launch is repeated over column WINDOWS of as many tile groups as fit,
+  // each a launch of its own over all steps -- the query words are gathered once per window (a few MB against the GBs of the stream).
+  const uint32_t max_tg = (48u << 10) / (batch * kM * 16 * (uint32_t)sizeof(uint32_t));  // 24 tile groups for 8 queries, 192 for one
+  const uint32_t windows = (a.tile_groups + max_tg - 1) / max_tg;
+  const uint32_t tg_per_window = (a.tile_groups + windows - 1) / windows;
   // (a query beyond 8 MiB no longer stays in the XCDs' L2 next to the stream, and the tile-major kernel gathers every word of it once
   // per tile group: at 2^22 keys, 18.9 MB, the step-major kernel streams 727 against 743 us per query, so it takes that case too)
   const bool long_query = (uint64_t)(a.ks_hi - a.ks_lo) * CPIR_PLANAR_SLOTS_PER_TILE * 4 > (8ull << 20);
   const bool want_ks = ks_mode >= 2 || (ks_mode == 1 && (batch >= 2 || passes == 1 || long_query));
-  KernelFn fn_ks = (want_ks && !inter && racc_bytes <= (48u << 10)) ? pick_ks(hb, batch, nt) : nullptr;
+  // (a query read in place over the host link must be read ONCE: one window or nothing)
+  KernelFn fn_ks = (want_ks && !inter && (windows == 1 || ks_mode != 3)) ? pick_ks(hb, batch, nt) : nullptr;
   if (ks_mode == 3 && !fn_ks) return CPIR_ERR_INVALID_ARGUMENT;  // the caller relies on q being read once
   int bpc = blocks_per_cu > 0 ? blocks_per_cu : (fn_ks ? (batch <= 4 ? 1 : 2) : (inter ? 3 : 2));
   if (batch > 4 && bpc > 2) bpc = 2;
-  const uint64_t units = (uint64_t)a.tile_groups * (a.ks_hi - a.ks_lo);
-  uint64_t grid = (uint64_t)dev->num_cus * (uint64_t)bpc;
-  a.nx = (xcd_split && !a.strided && (a.ks_hi - a.ks_lo) >= 8 && grid % 8 == 0) ? 8u : 1u;
-  const uint64_t blocks_needed = (units + kThreads / 64 - 1) / (kThreads / 64);
-  if (grid > blocks_needed) {
-    grid = blocks_needed;
-    if (a.nx == 8) grid = (grid / 8) * 8;
-    if (grid == 0) grid = 1, a.nx = 1;
-  }
+  // grid of a launch over `tgs` tile groups
+  auto grid_for_units = [&](uint32_t tgs, uint32_t* nx_out) {
+    const uint64_t units = (uint64_t)tgs * (a.ks_hi - a.ks_lo);
+    uint64_t grid = (uint64_t)dev->num_cus * (uint64_t)bpc;
+    uint32_t nx = (xcd_split && !a.strided && (a.ks_hi - a.ks_lo) >= 8 && grid % 8 == 0) ? 8u : 1u;
+    const uint64_t blocks_needed = (units + kThreads / 64 - 1) / (kThreads / 64);
+    if (grid > blocks_needed) {
+      grid = blocks_needed;
+      if (nx == 8) grid = (grid / 8) * 8;
+      if (grid == 0) grid = 1, nx = 1;
+    }
+    *nx_out = nx;
+    return grid;
+  };
 
   const uint32_t nq = batch * passes;
   const bool first = (step_lo == 0);
@@ -761,11 +775,20 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
   if (first && !r_prezeroed) CPIR_HIP_TRY(hipMemsetAsync(r, 0, (size_t)nq * L.num_cols * sizeof(uint32_t), stream));
   if (fn_ks) {
     a.colsum = colsum;
-    hipLaunchKernelGGL(fn_ks, dim3((unsigned)grid), dim3(kThreads), racc_bytes, stream, a);
+    for (uint32_t w = 0; w < windows; w++) {
+      a.tg_lo = w * tg_per_window;
+      if (a.tg_lo >= a.tile_groups) break;
+      a.tg_n = a.tile_groups - a.tg_lo < tg_per_window ? a.tile_groups - a.tg_lo : tg_per_window;
+      const uint64_t grid = grid_for_units(a.tg_n, &a.nx);
+      const size_t racc_bytes = (size_t)batch * a.tg_n * (kM * 16) * sizeof(uint32_t);
+      hipLaunchKernelGGL(fn_ks, dim3((unsigned)grid), dim3(kThreads), racc_bytes, stream, a);
+    }
     CPIR_HIP_TRY(hipGetLastError());
     return CPIR_OK;
   }
   a.colsum = nullptr;
+  a.tg_lo = 0, a.tg_n = a.tile_groups;
+  const uint64_t grid = grid_for_units(a.tile_groups, &a.nx);
   const uint64_t range_lo = step_lo * CPIR_PLANAR_SLOTS_PER_TILE, range_hi = step_hi * CPIR_PLANAR_SLOTS_PER_TILE;
   // slices of the query per init block: at most 16 Ki slots each (a lone query must not leave a handful of blocks reading hundreds of
   // KB each in front of the main kernel: 12.6 us with 64 Ki-slot slices at 2^20 keys)

@@ -466,3 +466,33 @@ def test_random_shapes_every_kernel_order(orc, device):
             srv.close()
     finally:
         cp.tuning_set("respond.ks_major", 1)
+
+
+def test_wide_database_fused_batches_go_window_by_window(orc, device):
+    """more columns than the step-major kernel's LDS accumulators hold for a fused batch (8 queries: 1 536 columns): the launch is repeated
+    over column windows; every batch size around the window arithmetic (1 window for 1..3 queries per pass at this width, 2 for 4..8) gives
+    the same responses as single responds, tile-major and step-major dispatch alike"""
+    import torch
+
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(515)
+    stream = torch.cuda.current_stream()
+    for b, N, C in ((9, 2 * 512 + 77, 3100), (6, 700, 1601)):
+        D = random_db_matrix(rng, N, C, b)
+        dtc = orc.row_wise_compress(orc.transpose(D), b)
+        srv = cp.Server.from_compressed(dtc, N, b, device=device)
+        nq = 19
+        Q = np.stack([random_query(rng, N) for _ in range(nq)])
+        want = np.stack([orc.row_vector_x_compressed_transposed_matrix(Q[i], dtc, N, b)[0] for i in range(nq)])
+        Q_dev = torch.from_numpy(Q.view(np.int32)).cuda()
+        for ks_major in (1, 2, 0):
+            cp.tuning_set("respond.ks_major", ks_major)
+            for k in (1, 2, 3, 4, 5, 8, 9, 16, 19):
+                R = torch.full((k, C), -1, dtype=torch.int32, device="cuda")
+                srv.respond_batch_device(Q_dev, k, R, stream=stream)
+                torch.cuda.synchronize()
+                assert np.array_equal(R.cpu().numpy().view(np.uint32), want[:k]), (b, ks_major, k)
+        cp.tuning_set("respond.ks_major", 1)
+        assert np.array_equal(srv.respond_array(Q[0]), want[0])  # the host entry point (one query: one window)
+        srv.close()
