@@ -742,6 +742,8 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
   // The step-major kernel keeps a pass's responses in LDS: 64 columns x batch u32 per tile group, at most 48 KiB.  Where all tile groups
   // do not fit (8 kB values: 7 312 columns x 8 queries = 234 KB) the launch is repeated over column WINDOWS of as many tile groups as fit,
   // each a launch of its own over all steps -- the query words are gathered once per window (a few MB against the GBs of the stream).
+  // (blocks of the two-row-set kernel run two per CU and share its 160 KiB: 48 KiB each beside the 32 KiB of A fragments.  One block per CU
+  // with 112 KiB -- 3 windows instead of 5 at 8 kB values -- measured the same: 191.9 against 193.5 us per query)
   const uint32_t max_tg = (48u << 10) / (batch * kM * 16 * (uint32_t)sizeof(uint32_t));  // 24 tile groups for 8 queries, 192 for one
   const uint32_t windows = (a.tile_groups + max_tg - 1) / max_tg;
   const uint32_t tg_per_window = (a.tile_groups + windows - 1) / windows;
