@@ -28,6 +28,39 @@ void set_last_hip_error(hipError_t e, const char* what, const char* file, int li
 // runtime's own threads (a GPU memory fault reported by ROCr, a failed runtime assertion, glibc's heap checks) otherwise leaves no
 // trace of WHERE it came from.  Diagnosis only; the test suite switches it on (tests/conftest.py).
 // ---------------------------------------------------------------------------------------------------------------
+struct JournalEntry {
+  const char* what;
+  const void* p;
+  size_t bytes;
+  const char* file;
+  int line;
+  long tid;
+};
+static constexpr unsigned kJournal = 512;
+static JournalEntry g_journal[kJournal];
+static std::atomic<uint64_t> g_journal_n{0};
+
+void journal_note(const char* what, const void* p, size_t bytes, const char* file, int line) {
+  const uint64_t i = g_journal_n.fetch_add(1, std::memory_order_relaxed);
+  JournalEntry& e = g_journal[i % kJournal];
+  const char* slash = strrchr(file, '/');
+  e = JournalEntry{what, p, bytes, slash ? slash + 1 : file, line, (long)syscall(SYS_gettid)};
+}
+
+void journal_dump(int fd) {
+  const uint64_t n = g_journal_n.load(std::memory_order_relaxed);
+  const uint64_t from = n > 96 ? n - 96 : 0;
+  char line[200];
+  int k = snprintf(line, sizeof(line), "[cpir] allocation journal, entries %llu..%llu (oldest first):\n", (unsigned long long)from, (unsigned long long)n);
+  if (k > 0) (void)!write(fd, line, (size_t)k);
+  for (uint64_t i = from; i < n; i++) {
+    const JournalEntry& e = g_journal[i % kJournal];
+    k = snprintf(line, sizeof(line), "[cpir]   #%llu %-20s %p %zu bytes  %s:%d  tid %ld\n", (unsigned long long)i, e.what ? e.what : "?", e.p, e.bytes,
+                 e.file ? e.file : "?", e.line, e.tid);
+    if (k > 0) (void)!write(fd, line, (size_t)k);
+  }
+}
+
 static struct sigaction g_prev_fatal[NSIG];
 static void abort_backtrace_handler(int sig, siginfo_t* info, void* uctx) {
   const struct sigaction g_prev_abort = g_prev_fatal[sig];
@@ -42,6 +75,7 @@ static void abort_backtrace_handler(int sig, siginfo_t* info, void* uctx) {
   const int depth = backtrace(frames, 64);
   backtrace_symbols_fd(frames, depth, 2);
   (void)!write(2, "[cpir] end of native stack\n", 27);
+  journal_dump(2);
   if ((g_prev_abort.sa_flags & SA_SIGINFO) && g_prev_abort.sa_sigaction) {
     g_prev_abort.sa_sigaction(sig, info, uctx);
   } else if (g_prev_abort.sa_handler != SIG_DFL && g_prev_abort.sa_handler != SIG_IGN && g_prev_abort.sa_handler) {

@@ -35,6 +35,36 @@ void set_last_hip_error(hipError_t e, const char* what, const char* file, int li
     if (_s != CPIR_OK) return _s; \
   } while (0)
 
+// ---- allocation journal (diagnosis) ------------------------------------------------------------
+// Every device / page-locked allocation and release of the library is noted in a small ring (what, address, bytes, where, thread); the
+// fatal-signal handler (capi.hip, CPIR_ABORT_BACKTRACE=1) prints the tail of it, so that the address in a "Memory access fault by GPU"
+// line of the runtime can be matched to the block it fell into -- or used to fall into.  A few nanoseconds per call.
+void journal_note(const char* what, const void* p, size_t bytes, const char* file, int line);
+void journal_dump(int fd);  // async-signal-safe enough for a handler that is about to die
+
+inline hipError_t traced_hipMalloc(void** p, size_t n, const char* f, int l) {
+  const hipError_t e = hipMalloc(p, n);
+  journal_note(e == hipSuccess ? "hipMalloc" : "hipMalloc FAILED", p ? *p : nullptr, n, f, l);
+  return e;
+}
+inline hipError_t traced_hipHostMalloc(void** p, size_t n, unsigned flags, const char* f, int l) {
+  const hipError_t e = hipHostMalloc(p, n, flags);
+  journal_note(e == hipSuccess ? "hipHostMalloc" : "hipHostMalloc FAILED", p ? *p : nullptr, n, f, l);
+  return e;
+}
+inline hipError_t traced_hipFree(void* p, const char* f, int l) {
+  journal_note("hipFree", p, 0, f, l);
+  return hipFree(p);
+}
+inline hipError_t traced_hipHostFree(void* p, const char* f, int l) {
+  journal_note("hipHostFree", p, 0, f, l);
+  return hipHostFree(p);
+}
+#define hipMalloc(p, n) ::cpir::traced_hipMalloc(reinterpret_cast<void**>(p), (n), __FILE__, __LINE__)
+#define hipHostMalloc(p, n, flags) ::cpir::traced_hipHostMalloc(reinterpret_cast<void**>(p), (n), (flags), __FILE__, __LINE__)
+#define hipFree(p) ::cpir::traced_hipFree((p), __FILE__, __LINE__)
+#define hipHostFree(p) ::cpir::traced_hipHostFree((p), __FILE__, __LINE__)
+
 // ---- device context ---------------------------------------------------------------------------
 struct Device {
   std::atomic<int> refs{1};

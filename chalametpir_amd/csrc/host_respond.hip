@@ -492,6 +492,7 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
     if (dp && reinterpret_cast<uintptr_t>(dp) % 16 == (q_lo * 4) % 16) in_place = static_cast<const uint32_t*>(dp) - q_lo;
   }
   if (e == hipSuccess && in_place) {
+    journal_note("respond: q read in place", q + q_lo, words * 4, __FILE__, __LINE__);
     rc = launch_respond_read_once(srv->dev, srv->dtc, srv->layout, in_place, srv->total_slots, srv->slot_offset, a->r_dev, st);
   } else if (e == hipSuccess) {
     uint32_t* const qp = a->q_pinned;  // seat 0; same offsets as the caller's buffer
@@ -516,6 +517,7 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
       // line whose tail belongs to job i + 1: the shard must start on a line boundary, which every shard_unit() multiple does)
       polled = fill_timeout_us > 0 && srv->fill_aborts.load(std::memory_order_relaxed) < 3 && (q_lo * 4) % 128 == 0;
       if (polled) {
+        journal_note("respond: polled launch", a->q_pinned, words * 4, __FILE__, __LINE__);
         publish_fill_progress(a->fill_progress, 0u);
         const PlanarHostFill fill{a->fill_progress_dev, a->r_dev + C, fill_timeout_us};
         rc = launch_respond_read_once(srv->dev, srv->dtc, srv->layout, a->q_pinned_dev, srv->total_slots, srv->slot_offset, a->r_dev, st, 0, 0,
@@ -573,6 +575,7 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
     if (!(polled && e == hipSuccess && rc == CPIR_OK && a->r_pinned[C] != 0)) break;
     // the polled launch gave up waiting: its results are void.  The pinned block is complete by now: answer from it, without polling.
     polled = false;
+    journal_note("respond: polled launch VOID", a->q_pinned, words * 4, __FILE__, __LINE__);
     srv->fill_aborts.fetch_add(1, std::memory_order_relaxed);
     if (!a->r0_zero) e = hipMemsetAsync(a->r_dev, 0, (C + 1) * 4, st);
     a->r0_zero = false;
