@@ -17,7 +17,7 @@ for p in ('p1','p2','p3','p4'):
     acc=collections.defaultdict(list)
     for f in glob.glob(f'{root}/{p}/**/*counter_collection.csv',recursive=True):
         for r in csv.DictReader(open(f)):
-            if 'planar_pack_stream' in r['Kernel_Name']:
+            if 'planar_pack' in r['Kernel_Name']:
                 acc[r['Counter_Name']].append(float(r['Counter_Value']))
     for k,v in acc.items(): print(p,k,len(v),f"{sum(v)/len(v):.4g}")
 PY
