@@ -71,7 +71,21 @@ struct Device {
   int ordinal = 0;
   int num_cus = 0;
   hipStream_t stream = nullptr;  // the handle's own stream: used by the synchronous host-pointer entry points
+  // Streams live as long as the device handle, not as long as a server: servers come and go (a test suite creates hundreds), and the
+  // runtime's stream life cycle -- queues, completion handlers on its own thread -- is not something to exercise once per server.
+  //   * up_stream / run_stream: the two streams of the host path of Server::respond (every query upload, FIFO / every batched respond and
+  //     response download, FIFO, highest priority), shared by all servers on this device, created on first use; upload_mu / launch_mu
+  //     keep one query's upload pieces / one arena's launch sequence together on them;
+  //   * idle_streams: a pool of plain non-blocking streams for the transient users (the upload of A in setup, the lanes of a group).
+  std::mutex pool_mu;
+  std::vector<hipStream_t> idle_streams;
+  hipStream_t up_stream = nullptr, run_stream = nullptr;
+  std::mutex upload_mu, launch_mu;
 };
+// host_respond.hip
+int device_host_streams(Device* d);             // creates up_stream / run_stream on first use (caller has made the device current)
+hipStream_t device_stream_acquire(Device* d);   // a drained non-blocking stream from the pool (created if the pool is empty); nullptr + last error
+void device_stream_release(Device* d, hipStream_t s);  // waits for the stream to drain and returns it to the pool
 
 // RAII "make this device current for the calling thread"
 struct DeviceGuard {

@@ -102,9 +102,57 @@ void device_retain(Device* d) { d->refs.fetch_add(1); }
 void device_release(Device* d) {
   if (d && d->refs.fetch_sub(1) == 1) {
     DeviceGuard g(d->ordinal);
+    for (hipStream_t s : d->idle_streams) (void)hipStreamDestroy(s);
+    if (d->up_stream) (void)hipStreamDestroy(d->up_stream);
+    if (d->run_stream) (void)hipStreamDestroy(d->run_stream);
     if (d->stream) (void)hipStreamDestroy(d->stream);
     delete d;
   }
+}
+
+int device_host_streams(Device* d) {
+  std::lock_guard<std::mutex> lk(d->pool_mu);
+  if (d->up_stream && d->run_stream) return CPIR_OK;
+  // The two streams must not share a hardware queue (uploads would then serialise with kernels): HIP multiplexes the streams of one
+  // priority level over a handful of queues in creation order, and a host process (torch, say) has usually created several already.
+  // The run stream is created at the highest priority, which has queues of its own.
+  int prio_lo = 0, prio_hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // (least, greatest): numerically greatest <= least
+  hipStream_t up = nullptr, run = nullptr;
+  hipError_t e = hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithPriority(&run, hipStreamNonBlocking, prio_hi);
+  if (e != hipSuccess) {
+    set_last_hip_error(e, "hipStreamCreateWithFlags (host path)", __FILE__, __LINE__);
+    if (up) (void)hipStreamDestroy(up);
+    return CPIR_ERR_HIP;
+  }
+  d->up_stream = up, d->run_stream = run;
+  return CPIR_OK;
+}
+
+hipStream_t device_stream_acquire(Device* d) {
+  {
+    std::lock_guard<std::mutex> lk(d->pool_mu);
+    if (!d->idle_streams.empty()) {
+      hipStream_t s = d->idle_streams.back();
+      d->idle_streams.pop_back();
+      return s;
+    }
+  }
+  hipStream_t s = nullptr;
+  const hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    set_last_hip_error(e, "hipStreamCreateWithFlags (pool)", __FILE__, __LINE__);
+    return nullptr;
+  }
+  return s;
+}
+
+void device_stream_release(Device* d, hipStream_t s) {
+  if (!s) return;
+  (void)hipStreamSynchronize(s);  // nothing may be in flight on a pooled stream
+  std::lock_guard<std::mutex> lk(d->pool_mu);
+  d->idle_streams.push_back(s);
 }
 
 // Where the device may read [p, p + bytes) of host memory in place (a DMA straight from the caller's buffer, or a kernel reading a lone
@@ -165,11 +213,12 @@ static void arena_free(RespondArena& a) {
 }
 
 static void arenas_destroy(Server* srv) {
+  // whatever this server enqueued on the device's shared host-path streams (a trailing memset of the response seat) must be done before
+  // its blocks go (hipFree waits for the device anyway -- scripts/probes/free_sync_probe.hip -- this says it in the code)
+  if (srv->run_stream) (void)hipStreamSynchronize(srv->run_stream);
+  if (srv->up_stream) (void)hipStreamSynchronize(srv->up_stream);
   for (RespondArena& a : srv->arena) arena_free(a);
-  if (srv->up_stream) (void)hipStreamDestroy(srv->up_stream);
-  if (srv->run_stream) (void)hipStreamDestroy(srv->run_stream);
-  srv->up_stream = srv->run_stream = nullptr;
-  srv->streams_ready = false;
+  srv->up_stream = srv->run_stream = nullptr;  // (owned by the device handle)
 }
 
 // spare words behind the response seats of an arena's two blocks: the fill progress of a lone query in CPIR_FILL_LINES copies (pinned
@@ -191,20 +240,9 @@ static int arena_create(Server* srv, RespondArena& a) {
     return e == hipErrorOutOfMemory ? CPIR_ERR_OUT_OF_DEVICE_MEMORY : CPIR_ERR_HIP;
   };
   hipError_t e = hipSuccess;
-  if (!srv->streams_ready) {
-    // The two streams must not share a hardware queue (uploads would then serialise with kernels): HIP multiplexes the streams of one
-    // priority level over a handful of queues in creation order, and a host process (torch, say) has usually created several already.
-    // The run stream is created at the highest priority, which has queues of its own.
-    int prio_lo = 0, prio_hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // (least, greatest): numerically greatest <= least
-    e = hipStreamCreateWithFlags(&srv->up_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&srv->run_stream, hipStreamNonBlocking, prio_hi);
-    if (e != hipSuccess) {
-      if (srv->up_stream) (void)hipStreamDestroy(srv->up_stream);
-      srv->up_stream = srv->run_stream = nullptr;
-      return fail(e, "hipStreamCreateWithFlags");
-    }
-    srv->streams_ready = true;
+  if (!srv->up_stream) {
+    CPIR_TRY(device_host_streams(srv->dev));
+    srv->up_stream = srv->dev->up_stream, srv->run_stream = srv->dev->run_stream;
   }
   if ((e = hipMalloc(&a.q_dev, (qw + rw) * 4)) != hipSuccess) return fail(e, "hipMalloc(respond arena)");
   // COHERENT (fine-grained) on purpose, whatever HIP_HOST_COHERENT says: a polled launch reads the fill progress and the query words
@@ -242,7 +280,7 @@ static void group_ctx_destroy(Server* srv) {
     for (size_t g = 0; g < c.lanes.size(); g++) {
       Server::GroupLane& l = c.lanes[g];
       DeviceGuard dg(srv->shards[g]->dev->ordinal);
-      if (l.stream) (void)hipStreamDestroy(l.stream);
+      if (l.stream) device_stream_release(srv->shards[g]->dev, l.stream);
       if (l.q_dev) (void)hipFree(l.q_dev);  // q_dev and r_dev are one block
       if (l.q_pinned) (void)hipHostFree(l.q_pinned);  // q_pinned and r_pinned are one block
     }
@@ -341,7 +379,10 @@ static int group_ctx_create(Server* srv) {
       const size_t qw = ((size_t)child->layout.num_slots + 3) / 4 * 4, words = qw + C;
 #define TRY_(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_last_hip_error(_e, #e, __FILE__, __LINE__); group_ctx_destroy(srv); \
     return _e == hipErrorOutOfMemory ? CPIR_ERR_OUT_OF_DEVICE_MEMORY : CPIR_ERR_HIP; } } while (0)
-      TRY_(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+      if (!(l.stream = device_stream_acquire(child->dev))) {
+        group_ctx_destroy(srv);
+        return CPIR_ERR_HIP;
+      }
       TRY_(hipMalloc(&l.q_dev, words * 4));
       TRY_(hipHostMalloc(&l.q_pinned, words * 4, hipHostMallocDefault));
 #undef TRY_
@@ -477,7 +518,7 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
   const size_t C = srv->layout.num_cols;
   const size_t q_lo = (size_t)srv->slot_offset, words = (size_t)srv->layout.num_slots;
   hipStream_t st = srv->run_stream;
-  std::lock_guard<std::mutex> ll(srv->launch_mu);
+  std::lock_guard<std::mutex> ll(srv->dev->launch_mu);
   hipError_t e = hipSuccess;
   int rc = CPIR_OK;
   // seat 0's response and the word behind it (the abort flag of a polled launch) are kept zeroed between uses
@@ -661,13 +702,13 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
   uint32_t* const qd = a->q_dev + seat * N;
   if (pinned_range_device_pointer(q + q_lo, (q_hi - q_lo) * 4) != nullptr) {
     // the caller's buffer is page-locked already (cpir_host_alloc, hipHostMalloc, hipHostRegister): DMA straight from it
-    std::lock_guard<std::mutex> ul(srv->upload_mu);
+    std::lock_guard<std::mutex> ul(srv->dev->upload_mu);
     up = hipMemcpyAsync(qd + q_lo, q + q_lo, (q_hi - q_lo) * 4, hipMemcpyHostToDevice, srv->up_stream);
     if (up == hipSuccess) up = hipEventRecord(a->seat_ev[seat], srv->up_stream);
   } else {
     uint32_t* const qp = a->q_pinned + seat * N;
     const size_t piece = (size_t)1 << 18;  // 1 MiB of u32
-    std::unique_lock<std::mutex> ul(srv->upload_mu, std::try_to_lock);
+    std::unique_lock<std::mutex> ul(srv->dev->upload_mu, std::try_to_lock);
     if (ul.owns_lock()) {
       // nobody else is uploading: in pieces, so that the DMA of one piece runs while the next ones are being copied into the pinned
       // block -- by this thread and, when they are free, by the staging helpers; the pieces are uploaded in order as they complete
@@ -761,7 +802,7 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
     const double t_gate = tr ? now_seconds() : 0;
     hipError_t e = hipSuccess;
     if (st == CPIR_OK) {
-      std::lock_guard<std::mutex> ll(srv->launch_mu);  // the launch sequences of two arenas must not interleave on the run stream
+      std::lock_guard<std::mutex> ll(srv->dev->launch_mu);  // the launch sequences of two arenas must not interleave on the run stream
       for (uint32_t i = 0; i < k && e == hipSuccess; i++) e = hipStreamWaitEvent(srv->run_stream, a->seat_ev[i], 0);
       a->r0_zero = false;
       if (e == hipSuccess)

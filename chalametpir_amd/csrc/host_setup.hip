@@ -79,7 +79,7 @@ class PublicMatrixUpload {
         DeviceGuard g(t.dev->ordinal);
         for (hipEvent_t e : t.block_ev)
           if (e) (void)hipEventDestroy(e);
-        if (t.copy_stream) (void)hipStreamDestroy(t.copy_stream);
+        if (t.copy_stream) device_stream_release(t.dev, t.copy_stream);
         if (t.A_dev) (void)hipFree(t.A_dev);
       }
       device_release(t.dev);
@@ -98,7 +98,7 @@ class PublicMatrixUpload {
     for (Target& t : targets_) {
       DeviceGuard g(t.dev->ordinal);
       CPIR_HIP_TRY(hipMalloc(&t.A_dev, (size_t)rows * t.col_n * 4));
-      CPIR_HIP_TRY(hipStreamCreateWithFlags(&t.copy_stream, hipStreamNonBlocking));
+      if (!(t.copy_stream = device_stream_acquire(t.dev))) return CPIR_ERR_HIP;
       t.block_ev.assign(nblocks, nullptr);
       for (hipEvent_t& e : t.block_ev) CPIR_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       if (A_host) {  // caller supplied A: plain upload, no XOF

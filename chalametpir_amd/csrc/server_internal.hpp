@@ -108,13 +108,10 @@ struct Server {
   std::mutex mu;
   std::condition_variable cv;
   RespondArena arena[kArenas];  // each allocated on first use (a lone caller only ever needs the first)
-  bool streams_ready = false;
-  hipStream_t up_stream = nullptr;   // every query upload, FIFO
-  hipStream_t run_stream = nullptr;  // every batched respond + response download, FIFO
+  hipStream_t up_stream = nullptr;   // the device's host-path streams (Device::up_stream / run_stream), looked up when the first arena is
+  hipStream_t run_stream = nullptr;  // created; owned by the device handle, not by this server
   std::atomic<uint32_t> fill_aborts{0};  // lone queries whose polled launch gave up waiting for the copy (3: stop polling)
   std::atomic<uint64_t> fill_polled{0};  // lone pageable queries answered by one launch polling the copy's progress
-  std::mutex upload_mu;              // one query's upload is enqueued at a time (whole queries, not interleaved pieces)
-  std::mutex launch_mu;              // one arena's launch sequence is enqueued at a time
 
   // ---- group handle (cpir_server_setup_multi): the database is split along the filter slots over several devices of this
   // process; `shards` then holds one ordinary server per device and this handle owns no packed database itself.  A host query is
