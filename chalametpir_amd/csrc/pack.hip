@@ -524,11 +524,17 @@ __global__ void __launch_bounds__(kThreads) planar_pack_stream_kernel(const Pack
 // slot group (g outer, the 8 k-blocks inner), so that the bit planes of a (column, slot group) -- which span all 8 k-blocks -- still
 // accumulate in four registers per column and plane.  What a batch produces for a column tile is the QUARTER of an operand piece that
 // belongs to slot group g: 16 lanes x 16 bytes = 256 contiguous bytes, so every store instruction writes four 256-byte runs (the
-// streaming kernel writes 1 KiB runs; reads outnumber writes 3.5 to 1).
+// streaming kernel writes 1 KiB runs; reads outnumber writes 3.5 to 1).  The stores are non-temporal: the image is not read again by this
+// pass and should not displace D's lines on their way through the caches (about 2 % at 2^20 keys and with 8 kB values).
 // position of fragment p = 4 * lane + i (written) / 64 * k + lane (read back) in the wave's staging window: the low two bits are XOR-ed with
 // bits 4..5, so that the 8 lanes a ds_write_b128 serves together -- 64 bytes apart -- fall into 8 different 16-byte bank groups; a
 // permutation inside aligned groups of 4 fragments, so the linear read-back stays conflict-free
 __device__ __forceinline__ uint32_t rows_swz(uint32_t p) { return p ^ ((p >> 4) & 3u); }
+
+typedef uint32_t pack_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_nt(uint4* p, const uint4& x) {
+  __builtin_nontemporal_store(pack_u32x4{x.x, x.y, x.z, x.w}, reinterpret_cast<pack_u32x4*>(p));
+}
 
 template <int HB, bool VEC, bool GUARD>
 __device__ __forceinline__ void pack_rows_unit(const PackStreamArgs& a, uint4* my_stage, uint32_t lane, uint32_t wstripe, uint32_t ks) {
@@ -612,7 +618,7 @@ __device__ __forceinline__ void pack_rows_unit(const PackStreamArgs& a, uint4* m
     for (int k = 0; k < 4; k++) {
       const uint4 x = my_stage[rows_swz(64 * k + lane)];
       const uint32_t T = T0 + 4 * k + (lane >> 4);
-      if (T < a.col_tiles) a.tiles[((uint64_t)T * a.ks_total + ks) * ST16 + kb * 64 + 16 * g + (lane & 15)] = x;
+      if (T < a.col_tiles) store16_nt(a.tiles + ((uint64_t)T * a.ks_total + ks) * ST16 + kb * 64 + 16 * g + (lane & 15), x);
     }
     __builtin_amdgcn_wave_barrier();
     if (HB > 1 && a.hi_plane) {  // wave-uniform: the same fragments of the high-byte plane, through the same window (one bit plane: no such plane)
@@ -624,7 +630,7 @@ __device__ __forceinline__ void pack_rows_unit(const PackStreamArgs& a, uint4* m
       for (int k = 0; k < 4; k++) {
         const uint4 x = my_stage[rows_swz(64 * k + lane)];
         const uint32_t T = T0 + 4 * k + (lane >> 4);
-        if (T < a.col_tiles && kbg < a.kb_total) a.hi_plane[((uint64_t)T * a.kb_total + kbg) * 64 + 16 * g + (lane & 15)] = x;
+        if (T < a.col_tiles && kbg < a.kb_total) store16_nt(a.hi_plane + ((uint64_t)T * a.kb_total + kbg) * 64 + 16 * g + (lane & 15), x);
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -660,7 +666,7 @@ __device__ __forceinline__ void pack_rows_unit(const PackStreamArgs& a, uint4* m
       for (int k = 0; k < 4; k++) {
         const uint4 x = my_stage[rows_swz(64 * k + lane)];
         const uint32_t T = T0 + 4 * k + (lane >> 4);
-        if (T < a.col_tiles) a.tiles[((uint64_t)T * a.ks_total + ks) * ST16 + 512 + p * 64 + 16 * g + (lane & 15)] = x;
+        if (T < a.col_tiles) store16_nt(a.tiles + ((uint64_t)T * a.ks_total + ks) * ST16 + 512 + p * 64 + 16 * g + (lane & 15), x);
       }
       __builtin_amdgcn_wave_barrier();
     }
