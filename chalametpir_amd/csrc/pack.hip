@@ -350,6 +350,12 @@ __global__ void __launch_bounds__(kThreads) planar_pack_kernel(const uint32_t* _
 // k-blocks of the step and are accumulated in registers across them.  Pieces leave through a wave-private, swizzled 4 KiB LDS window that
 // only re-orders them so that every global store instruction writes 1 KiB contiguous.
 // Per-column field sums (correction term of the signed-byte arithmetic): v_sad_u8 over the packed low bytes + popcounts of the planes.
+// the packed image is written once and not read again by the pass that writes it: non-temporal stores keep it from displacing D's lines
+typedef uint32_t pack_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_nt(uint4* p, const uint4& x) {
+  __builtin_nontemporal_store(pack_u32x4{x.x, x.y, x.z, x.w}, reinterpret_cast<pack_u32x4*>(p));
+}
+
 struct PackStreamArgs {
   const uint32_t* D;
   uint64_t ld, N;
@@ -453,7 +459,7 @@ __device__ __forceinline__ void pack_stream_unit(const PackStreamArgs& a, uint4*
     for (int k = 0; k < 4; k++) {
       const uint4 x = my_stage[stage_swz(64 * k + lane)];
       const uint32_t T = stripe * 4 + k;
-      if (T < a.col_tiles) a.tiles[((uint64_t)T * a.ks_total + ks) * ST16 + kb * 64 + lane] = x;
+      if (T < a.col_tiles) store16_nt(a.tiles + ((uint64_t)T * a.ks_total + ks) * ST16 + kb * 64 + lane, x);
     }
     __builtin_amdgcn_wave_barrier();
     if (HB > 0 && a.hi_plane) {  // wave-uniform: the same four pieces of the high-byte plane, through the same window
@@ -465,7 +471,7 @@ __device__ __forceinline__ void pack_stream_unit(const PackStreamArgs& a, uint4*
       for (int k = 0; k < 4; k++) {
         const uint4 x = my_stage[stage_swz(64 * k + lane)];
         const uint32_t T = stripe * 4 + k;
-        if (T < a.col_tiles && kbg < a.kb_total) a.hi_plane[((uint64_t)T * a.kb_total + kbg) * 64 + lane] = x;
+        if (T < a.col_tiles && kbg < a.kb_total) store16_nt(a.hi_plane + ((uint64_t)T * a.kb_total + kbg) * 64 + lane, x);
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -481,7 +487,7 @@ __device__ __forceinline__ void pack_stream_unit(const PackStreamArgs& a, uint4*
     for (int k = 0; k < 4; k++) {
       const uint4 x = my_stage[stage_swz(64 * k + lane)];
       const uint32_t T = stripe * 4 + k;
-      if (T < a.col_tiles) a.tiles[((uint64_t)T * a.ks_total + ks) * ST16 + 512 + p * 64 + lane] = x;
+      if (T < a.col_tiles) store16_nt(a.tiles + ((uint64_t)T * a.ks_total + ks) * ST16 + 512 + p * 64 + lane, x);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -531,10 +537,6 @@ __global__ void __launch_bounds__(kThreads) planar_pack_stream_kernel(const Pack
 // permutation inside aligned groups of 4 fragments, so the linear read-back stays conflict-free
 __device__ __forceinline__ uint32_t rows_swz(uint32_t p) { return p ^ ((p >> 4) & 3u); }
 
-typedef uint32_t pack_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store16_nt(uint4* p, const uint4& x) {
-  __builtin_nontemporal_store(pack_u32x4{x.x, x.y, x.z, x.w}, reinterpret_cast<pack_u32x4*>(p));
-}
 
 template <int HB, bool VEC, bool GUARD>
 __device__ __forceinline__ void pack_rows_unit(const PackStreamArgs& a, uint4* my_stage, uint32_t lane, uint32_t wstripe, uint32_t ks) {
