@@ -11,8 +11,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="$ROOT/bench.py --no-setup --no-cpu-baseline --no-host-path --no-read-ceiling --steps 10 --warmup 2 $*"
-SETUP_BENCH="$ROOT/bench.py --no-cpu-baseline --no-host-path --no-read-ceiling --steps 2 --warmup 1 $*"
+BENCH="$ROOT/bench.py --no-setup --no-cpu-baseline --no-host-path --no-read-ceiling --no-live-traffic --steps 10 --warmup 2 $*"
+SETUP_BENCH="$ROOT/bench.py --no-cpu-baseline --no-host-path --no-read-ceiling --no-live-traffic --steps 2 --warmup 1 $*"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- python3 $BENCH > "$OUT/trace_bench.json" 2> "$OUT/trace.err"
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o fetch -- python3 $BENCH > "$OUT/fetch_bench.json" 2> "$OUT/fetch.err"
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o write -- python3 $BENCH > "$OUT/write_bench.json" 2> "$OUT/write.err"
