@@ -595,10 +595,14 @@ def live_traffic(args, passes_per_launch: int):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     fetch, write = means["FETCH_SIZE"], means["WRITE_SIZE"]
+    import re
+
+    m = re.search(r"respond_\w+(<[^>]*>)?", fetch[0])
+    short = m.group(0) if m else fetch[0][:60]
     return {
         "bytes_per_launch": (2 * fetch[1] + write[1]) * 1024,
         "source": (f"measured in this run: the timed loop alone in two child processes under rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE "
-                   f"(separate passes), mean over {fetch[2]} / {write[2]} dispatches of {fetch[0].split('(')[0].split('::')[-1]}; FETCH_SIZE x2 (gfx950: 64 B "
+                   f"(separate passes), mean over {fetch[2]} / {write[2]} dispatches of {short}; FETCH_SIZE x2 (gfx950: 64 B "
                    f"counted per 128 B request of a 16 B/lane stream) + WRITE_SIZE, units of 1024 B; one launch = {passes_per_launch} passes"),
     }
 
