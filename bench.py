@@ -13,6 +13,9 @@ sharded along the filter-slot axis, every rank streams its shard, and the per-sh
 queries are sum-reduced with ONE RCCL all-reduce per step (u32 wrap-around, bit-exact for any order).  Total work is
 fixed as N grows => "scaling": "strong".
 
+`roofline.traffic` (HBM bytes per launch from the PMC counters) is measured in the run itself: the timed loop alone, twice, as a child
+process under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (live_traffic() below).
+
 Rank 0 prints ONE JSON line -- in a multi-rank run with the server_setup extra, that line twice: first as soon as the timed respond
 region and its reduction are done ("server_setup_pending": true), then again enriched with the sharded setup's timing, which runs
 under a deadline (--setup-deadline) so that an optional extra can never cost the headline; take the LAST line.  `roofline` describes the respond kernel against the HBM roof (8 TB/s,
