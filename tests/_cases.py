@@ -40,3 +40,27 @@ def synth_u32_at(indices, seed, mask=0xFFFFFFFF):
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         z = z ^ (z >> np.uint64(31))
     return ((z >> np.uint64(32)).astype(np.uint32)) & np.uint32(mask)
+
+
+class OwnMapping:
+    """A u32 buffer in a private anonymous mapping of its own (mmap), page-aligned, for tests that hipHostRegister caller memory.
+    NEVER register glibc heap memory (a numpy array) in this suite: on the GPU boxes a hipHostRegister / hipHostUnregister cycle over heap
+    pages is followed, some allocations later, by "Memory access fault by GPU node-N on address <heap address>" -- with the HIP runtime and
+    torch alone, no code of this repository involved (scripts/probes/register_then_copy_probe.py).  Dedicated mappings, unmapped
+    after unregistering, do not show it (scripts/probes/register_mmap_probe.py)."""
+
+    def __init__(self, count):
+        import mmap
+
+        self.nbytes = (4 * count + 4095) // 4096 * 4096
+        self._mm = mmap.mmap(-1, self.nbytes)
+        self.array = np.frombuffer(self._mm, dtype=np.uint32, count=count)
+        self.address = self.array.ctypes.data
+        assert self.address % 4096 == 0
+
+    def close(self):
+        self.array = None
+        try:
+            self._mm.close()
+        except BufferError:  # a view is still alive somewhere: leave the mapping to the garbage collector rather than fail the test
+            pass

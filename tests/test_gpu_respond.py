@@ -8,7 +8,7 @@ import threading
 import numpy as np
 import pytest
 
-from _cases import ALL_BITS, cf_of, random_db_matrix, random_query, unwire, wire
+from _cases import ALL_BITS, OwnMapping, cf_of, random_db_matrix, random_query, unwire, wire
 
 pytestmark = pytest.mark.gpu
 
@@ -376,22 +376,25 @@ def test_partly_registered_query_buffer_is_not_read_in_place(orc, device):
     rng = np.random.default_rng(99)
     N, C, b = 6 * 4096 + 512, 11, 9
     srv, dtc = make_server(cp, orc, device, rng, N, C, b)
-    raw = np.zeros(N + 2048, dtype=np.uint32)
-    off = (-raw.ctypes.data % 4096) // 4  # page-aligned start, so that the registered half ends on a page boundary
-    q = raw[off:off + N]
+    own = OwnMapping(N)  # a mapping of its own, never heap memory (see OwnMapping)
+    q = own.array
     q[:] = random_query(rng, N)
     want = orc.row_vector_x_compressed_transposed_matrix(q, dtc, N, b)[0]
     half_bytes = (N // 2 * 4) // 4096 * 4096
-    for nbytes in (half_bytes, (N * 4 + 4095) // 4096 * 4096):
-        err = rt.cudaHostRegister(q.ctypes.data, nbytes, 0)
+    for nbytes in (half_bytes, own.nbytes):
+        err = rt.cudaHostRegister(own.address, nbytes, 0)
         assert int(err) == 0, err
         try:
             for _ in range(2):
                 assert np.array_equal(srv.respond_array(q), want), nbytes
         finally:
-            rt.cudaHostUnregister(q.ctypes.data)
+            err = rt.cudaHostUnregister(own.address)
+        assert int(err) == 0, err
         # unregistered again: the same address must not be taken for page-locked any more
         assert np.array_equal(srv.respond_array(q), want)
+    srv.close()
+    del q
+    own.close()
 
 
 def test_lone_pageable_query_polled_launch_and_its_fallbacks(orc, device):

@@ -4,7 +4,8 @@ do for minutes, here for a bounded number of rounds): servers of three shapes ar
   * a lone caller with a PAGEABLE query (2^19+ words: one launch polling the copy's progress; below: staged, read in place from the
     arena's pinned block),
   * a lone caller whose query lies in page-locked memory (cpir_host_alloc: read in place from the caller's buffer),
-  * a lone caller whose buffer is hipHostRegister'ed, asked, unregistered and asked again at the SAME address (must be staged then),
+  * a lone caller whose buffer (a mapping of its own, never heap memory) is hipHostRegister'ed, asked, unregistered and asked again at
+    the SAME address (must be staged then),
   * bursts of concurrent callers mixing pageable and page-locked buffers (arenas coalesce and pipeline them),
 
 cloned, closed while the clone keeps answering, and destroyed -- interleaved, so that arenas, streams, pinned blocks and registrations are
@@ -16,20 +17,11 @@ import time
 import numpy as np
 import pytest
 
-from _cases import random_db_matrix, random_query
+from _cases import OwnMapping, random_db_matrix, random_query
 
 pytestmark = pytest.mark.gpu
 
 SHAPES = [((1 << 19) + 4096 * 3 + 5, 24, 9), (77_824, 130, 10), (600_000, 7, 12), (3 * 1536 + 1, 19, 6)]
-
-
-def _register(rt, arr):
-    """hipHostRegister over the pages that hold `arr` (torch's binding of the runtime call); returns the registered base address"""
-    base = arr.ctypes.data // 4096 * 4096
-    end = (arr.ctypes.data + arr.nbytes + 4095) // 4096 * 4096
-    err = rt.cudaHostRegister(base, end - base, 0)
-    assert int(err) == 0, err
-    return base
 
 
 @pytest.mark.parametrize("order", ["forward", "reversed"])
@@ -68,16 +60,19 @@ def test_server_lifecycle_under_mixed_callers(order, orc, device):
             pin.array[:] = q
             ask(srv, pin.array, q, "page-locked")
             if can_register:
-                raw = np.zeros(N + 2048, dtype=np.uint32)
-                off = (-raw.ctypes.data % 4096) // 4
-                qr = raw[off:off + N]
+                own = OwnMapping(N)  # a mapping of its own: heap memory is never registered in this suite (see OwnMapping)
+                qr = own.array
                 qr[:] = random_query(rng, N)
-                _register(rt, qr)
+                err = rt.cudaHostRegister(own.address, own.nbytes, 0)
+                assert int(err) == 0, err
                 try:
                     ask(srv, qr, qr.copy(), "registered")
                 finally:
-                    rt.cudaHostUnregister(qr.ctypes.data // 4096 * 4096)
+                    err = rt.cudaHostUnregister(own.address)
+                assert int(err) == 0, err
                 ask(srv, qr, qr.copy(), "unregistered-again")
+                del qr
+                own.close()
             # a burst of concurrent callers on the one handle, pageable and page-locked buffers mixed
             qs = [random_query(rng, N) for _ in range(6)]
             pins = [cp.PinnedArray(N) for _ in range(2)]
