@@ -59,7 +59,7 @@ def test_server_lifecycle_under_mixed_callers(order, orc, device):
             pin = cp.PinnedArray(N)
             pin.array[:] = q
             ask(srv, pin.array, q, "page-locked")
-            if can_register:
+            if can_register and rnd == 0:  # (once per shape and order: 8 register / unregister cycles per run are enough)
                 own = OwnMapping(N)  # a mapping of its own: heap memory is never registered in this suite (see OwnMapping)
                 qr = own.array
                 qr[:] = random_query(rng, N)
@@ -92,7 +92,7 @@ def test_server_lifecycle_under_mixed_callers(order, orc, device):
                 pa.close()
             pin.close()
             assert not bad, bad
-            responses += 12 if can_register else 10
+            responses += 12 if (can_register and rnd == 0) else 10
     assert responses >= 10 * len(SHAPES)  # at least one full round fitted the bound
 
 
