@@ -223,3 +223,19 @@ def test_every_documented_tuning_key_is_accepted_and_bounded():
                      ("respond.host_fill_timeout_us", 2_000_000), ("respond.no_such_key", 1)):
         with pytest.raises(ChalametPIRError):
             cp.tuning_set(key, bad)
+
+
+def test_the_suite_registers_only_mappings_of_its_own():
+    """regression guard for the abort of the GPU suite: hipHostRegister over glibc HEAP memory (a numpy array) is followed,
+    on the GPU boxes, by a GPU memory fault some allocations later -- with the runtime alone.  Every hipHostRegister of this suite must
+    therefore go through tests/_cases.py::OwnMapping (a private mapping, registered, unregistered with the return code checked, unmapped)."""
+    import re
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name in sorted(os.listdir(here)):
+        if not name.endswith(".py") or name == os.path.basename(__file__):
+            continue
+        text = open(os.path.join(here, name)).read()
+        for m in re.finditer(r"cudaHost(?:Un)?[Rr]egister\(([^,)]*)", text):
+            assert m.group(1).strip() == "own.address", (name, m.group(0))
+        assert "hipHostRegister(" not in text or name == "_cases.py" or "OwnMapping" in text, name
