@@ -585,7 +585,7 @@ def live_traffic(args, passes_per_launch: int):
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
                         name = row.get("Kernel_Name") or ""
-                        if (row.get("Counter_Name") or "") == counter and ("respond_planar_kernel" in name or "respond_kernel" in name):
+                        if (row.get("Counter_Name") or "") == counter and ("respond_planar" in name or "respond_kernel" in name):
                             per_kernel.setdefault(name, []).append(float(row.get("Counter_Value") or 0))
             if not per_kernel:
                 log(f"live traffic: no respond kernel in the {counter} pass")
