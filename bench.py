@@ -565,6 +565,10 @@ def live_traffic(args, passes_per_launch: int):
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
         return None
+    # not from inside a profiled run (the profiler's preloaded tool library and its environment would be inherited by the children)
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "") or os.environ.get("HSA_TOOLS_LIB"):
+        log("live traffic: this process is being profiled itself; quoting the committed counter pass instead")
+        return None
     child = [sys.executable, os.path.abspath(__file__), "--headline-only", "--no-setup", "--no-cpu-baseline", "--no-host-path", "--no-read-ceiling",
              "--no-live-traffic", "--config", args.config, "--steps", "3", "--warmup", "1", "--queries-per-step", str(args.queries_per_step),
              "--query-pool", str(args.query_pool), "--enqueue", args.enqueue]
