@@ -152,12 +152,12 @@ int cpir_host_alloc(size_t bytes, void** out) {
   if (!out || bytes == 0) return CPIR_ERR_INVALID_ARGUMENT;
   *out = nullptr;
   if (!has_device(nullptr)) return CPIR_ERR_NO_DEVICE;
-  CPIR_HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocPortable));
+  CPIR_HIP_TRY(CPIR_HIP_HOST_MALLOC(out, bytes, hipHostMallocPortable));
   return CPIR_OK;
 }
 
 void cpir_host_free(void* p) {
-  if (p) (void)hipHostFree(p);
+  if (p) (void)CPIR_HIP_HOST_FREE(p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -361,7 +361,7 @@ int cpir_server_export_compressed(const cpir_server* srv, uint32_t* compressed_o
   }
   DeviceGuard g(srv->dev->ordinal);
   DevBuf tmp;
-  CPIR_HIP_TRY(hipMalloc(&tmp.p, (size_t)words * 4));
+  CPIR_HIP_TRY(CPIR_HIP_MALLOC(&tmp.p, (size_t)words * 4));
   CPIR_TRY(launch_dtc_export(srv->dev, srv->dtc, L, (uint32_t*)tmp.p, srv->dev->stream));
   CPIR_HIP_TRY(hipMemcpyAsync(compressed_out, tmp.p, (size_t)words * 4, hipMemcpyDeviceToHost, srv->dev->stream));
   CPIR_HIP_TRY(hipStreamSynchronize(srv->dev->stream));

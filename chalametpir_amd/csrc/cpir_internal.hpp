@@ -36,7 +36,7 @@ void set_last_hip_error(hipError_t e, const char* what, const char* file, int li
   } while (0)
 
 // ---- allocation journal (diagnosis) ------------------------------------------------------------
-// Every device / page-locked allocation and release of the library is noted in a small ring (what, address, bytes, where, thread); the
+// Every device / page-locked allocation and release of the library goes through CPIR_HIP_MALLOC / _FREE / _HOST_MALLOC / _HOST_FREE and is noted in a small ring (what, address, bytes, where, thread); the
 // fatal-signal handler (capi.hip, CPIR_ABORT_BACKTRACE=1) prints the tail of it, so that the address in a "Memory access fault by GPU"
 // line of the runtime can be matched to the block it fell into -- or used to fall into.  A few nanoseconds per call.
 void journal_note(const char* what, const void* p, size_t bytes, const char* file, int line);
@@ -60,10 +60,10 @@ inline hipError_t traced_hipHostFree(void* p, const char* f, int l) {
   journal_note("hipHostFree", p, 0, f, l);
   return hipHostFree(p);
 }
-#define hipMalloc(p, n) ::cpir::traced_hipMalloc(reinterpret_cast<void**>(p), (n), __FILE__, __LINE__)
-#define hipHostMalloc(p, n, flags) ::cpir::traced_hipHostMalloc(reinterpret_cast<void**>(p), (n), (flags), __FILE__, __LINE__)
-#define hipFree(p) ::cpir::traced_hipFree((p), __FILE__, __LINE__)
-#define hipHostFree(p) ::cpir::traced_hipHostFree((p), __FILE__, __LINE__)
+#define CPIR_HIP_MALLOC(p, n) ::cpir::traced_hipMalloc(reinterpret_cast<void**>(p), (n), __FILE__, __LINE__)
+#define CPIR_HIP_HOST_MALLOC(p, n, flags) ::cpir::traced_hipHostMalloc(reinterpret_cast<void**>(p), (n), (flags), __FILE__, __LINE__)
+#define CPIR_HIP_FREE(p) ::cpir::traced_hipFree((p), __FILE__, __LINE__)
+#define CPIR_HIP_HOST_FREE(p) ::cpir::traced_hipHostFree((p), __FILE__, __LINE__)
 
 // ---- device context ---------------------------------------------------------------------------
 struct Device {

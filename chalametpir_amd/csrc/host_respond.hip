@@ -207,8 +207,8 @@ static void arena_free(RespondArena& a) {
   for (hipEvent_t e : a.seat_ev)
     if (e) (void)hipEventDestroy(e);
   if (a.done_ev) (void)hipEventDestroy(a.done_ev);
-  if (a.q_dev) (void)hipFree(a.q_dev);
-  if (a.q_pinned) (void)hipHostFree(a.q_pinned);
+  if (a.q_dev) (void)CPIR_HIP_FREE(a.q_dev);
+  if (a.q_pinned) (void)CPIR_HIP_HOST_FREE(a.q_pinned);
   a = RespondArena{};
 }
 
@@ -244,10 +244,10 @@ static int arena_create(Server* srv, RespondArena& a) {
     CPIR_TRY(device_host_streams(srv->dev));
     srv->up_stream = srv->dev->up_stream, srv->run_stream = srv->dev->run_stream;
   }
-  if ((e = hipMalloc(&a.q_dev, (qw + rw) * 4)) != hipSuccess) return fail(e, "hipMalloc(respond arena)");
+  if ((e = CPIR_HIP_MALLOC(&a.q_dev, (qw + rw) * 4)) != hipSuccess) return fail(e, "hipMalloc(respond arena)");
   // COHERENT (fine-grained) on purpose, whatever HIP_HOST_COHERENT says: a polled launch reads the fill progress and the query words
   // while the host is still writing them (respond_alone), which only works on memory the device does not cache
-  if ((e = hipHostMalloc(&a.q_pinned, (qw + rw) * 4, hipHostMallocCoherent)) != hipSuccess) return fail(e, "hipHostMalloc(respond arena)");
+  if ((e = CPIR_HIP_HOST_MALLOC(&a.q_pinned, (qw + rw) * 4, hipHostMallocCoherent)) != hipSuccess) return fail(e, "hipHostMalloc(respond arena)");
   a.r_dev = a.q_dev + qw, a.r_pinned = a.q_pinned + qw;
   {
     void* dp = nullptr;
@@ -281,8 +281,8 @@ static void group_ctx_destroy(Server* srv) {
       Server::GroupLane& l = c.lanes[g];
       DeviceGuard dg(srv->shards[g]->dev->ordinal);
       if (l.stream) device_stream_release(srv->shards[g]->dev, l.stream);
-      if (l.q_dev) (void)hipFree(l.q_dev);  // q_dev and r_dev are one block
-      if (l.q_pinned) (void)hipHostFree(l.q_pinned);  // q_pinned and r_pinned are one block
+      if (l.q_dev) (void)CPIR_HIP_FREE(l.q_dev);  // q_dev and r_dev are one block
+      if (l.q_pinned) (void)CPIR_HIP_HOST_FREE(l.q_pinned);  // q_pinned and r_pinned are one block
     }
     c.lanes.clear();
   }
@@ -311,7 +311,7 @@ void server_destroy(Server* srv) {
   {
     DeviceGuard g(srv->dev->ordinal);
     arenas_destroy(srv);
-    if (srv->dtc) (void)hipFree(srv->dtc);
+    if (srv->dtc) (void)CPIR_HIP_FREE(srv->dtc);
   }
   device_release(srv->dev);
   delete srv;
@@ -383,8 +383,8 @@ static int group_ctx_create(Server* srv) {
         group_ctx_destroy(srv);
         return CPIR_ERR_HIP;
       }
-      TRY_(hipMalloc(&l.q_dev, words * 4));
-      TRY_(hipHostMalloc(&l.q_pinned, words * 4, hipHostMallocDefault));
+      TRY_(CPIR_HIP_MALLOC(&l.q_dev, words * 4));
+      TRY_(CPIR_HIP_HOST_MALLOC(&l.q_pinned, words * 4, hipHostMallocDefault));
 #undef TRY_
       l.r_dev = l.q_dev + qw;
       l.r_pinned = l.q_pinned + qw;

@@ -80,12 +80,12 @@ class PublicMatrixUpload {
         for (hipEvent_t e : t.block_ev)
           if (e) (void)hipEventDestroy(e);
         if (t.copy_stream) device_stream_release(t.dev, t.copy_stream);
-        if (t.A_dev) (void)hipFree(t.A_dev);
+        if (t.A_dev) (void)CPIR_HIP_FREE(t.A_dev);
       }
       device_release(t.dev);
     }
     for (int i = 0; i < 2; i++)
-      if (pinned_[i]) (void)hipHostFree(pinned_[i]);
+      if (pinned_[i]) (void)CPIR_HIP_HOST_FREE(pinned_[i]);
   }
 
   int start(const uint8_t seed[32], const uint32_t* A_host) {
@@ -97,7 +97,7 @@ class PublicMatrixUpload {
     const uint64_t nblocks = (rows + rows_per_block_ - 1) / rows_per_block_;
     for (Target& t : targets_) {
       DeviceGuard g(t.dev->ordinal);
-      CPIR_HIP_TRY(hipMalloc(&t.A_dev, (size_t)rows * t.col_n * 4));
+      CPIR_HIP_TRY(CPIR_HIP_MALLOC(&t.A_dev, (size_t)rows * t.col_n * 4));
       if (!(t.copy_stream = device_stream_acquire(t.dev))) return CPIR_ERR_HIP;
       t.block_ev.assign(nblocks, nullptr);
       for (hipEvent_t& e : t.block_ev) CPIR_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -112,7 +112,7 @@ class PublicMatrixUpload {
       return CPIR_OK;
     }
     // portable: the same staging block is the source of copies to every target device
-    for (int i = 0; i < 2; i++) CPIR_HIP_TRY(hipHostMalloc(&pinned_[i], (size_t)rows_per_block_ * N_ * 4, hipHostMallocPortable));
+    for (int i = 0; i < 2; i++) CPIR_HIP_TRY(CPIR_HIP_HOST_MALLOC(&pinned_[i], (size_t)rows_per_block_ * N_ * 4, hipHostMallocPortable));
     memcpy(seed_, seed, 32);
     worker_ = std::thread([this] {
       (void)pthread_setname_np(pthread_self(), "cpir-xof");
@@ -216,7 +216,7 @@ void DevBuf::dispose_async(int ordinal) {
   if (q)
     g_disposer.run([q, ordinal] {
       DeviceGuard g(ordinal);
-      (void)hipFree(q);
+      (void)CPIR_HIP_FREE(q);
     });
 }
 
@@ -228,14 +228,14 @@ static int setup_from_host_matrix(Device* dev, PublicMatrixUpload& upA, const ui
   DeviceGuard g(dev->ordinal);
   hipStream_t stream = dev->stream;
   DevBuf D_dev, flag, M_dev;
-  CPIR_HIP_TRY(hipMalloc(&D_dev.p, (size_t)N * C * 4));
-  CPIR_HIP_TRY(hipMalloc(&flag.p, 4));
-  CPIR_HIP_TRY(hipMalloc(&M_dev.p, (size_t)CPIR_LWE_DIMENSION * C * 4));
+  CPIR_HIP_TRY(CPIR_HIP_MALLOC(&D_dev.p, (size_t)N * C * 4));
+  CPIR_HIP_TRY(CPIR_HIP_MALLOC(&flag.p, 4));
+  CPIR_HIP_TRY(CPIR_HIP_MALLOC(&M_dev.p, (size_t)CPIR_LWE_DIMENSION * C * 4));
   Server* srv = server_new(dev, L, 0, N);
   auto fail = [&](int st) { server_destroy(srv); return st; };
 #define TRY_(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_last_hip_error(_e, #e, __FILE__, __LINE__); \
     return fail(_e == hipErrorOutOfMemory ? CPIR_ERR_OUT_OF_DEVICE_MEMORY : CPIR_ERR_HIP); } } while (0)
-  TRY_(hipMalloc(&srv->dtc, (size_t)L.total_words * 4));
+  TRY_(CPIR_HIP_MALLOC(&srv->dtc, (size_t)L.total_words * 4));
   double t0 = now_seconds();
   TRY_(hipMemcpyAsync(D_dev.p, D, (size_t)N * C * 4, hipMemcpyHostToDevice, stream));
   TRY_(hipStreamSynchronize(stream));
@@ -250,8 +250,8 @@ static int setup_from_host_matrix(Device* dev, PublicMatrixUpload& upA, const ui
   const uint64_t hi_bytes = planar_hi_plane_bytes(L);  // 0 with one bit plane (b = 9): the matmul expands it from the image itself
   bool planar_rhs = mfma_matmul_enabled() && mfma_planar_rhs_applicable(A_dev, N, L);
   if (planar_rhs) {
-    if (hi_bytes) TRY_(hipMalloc(&hi_plane.p, (size_t)hi_bytes));
-    TRY_(hipMalloc(&rowsum_ws.p, 4 * 128));
+    if (hi_bytes) TRY_(CPIR_HIP_MALLOC(&hi_plane.p, (size_t)hi_bytes));
+    TRY_(CPIR_HIP_MALLOC(&rowsum_ws.p, 4 * 128));
   }
   int st = launch_transpose_compress(dev, (const uint32_t*)D_dev.p, C, L, srv->dtc, (uint32_t*)flag.p, stream, hi_plane.p);
   if (st != CPIR_OK) return fail(st);
@@ -275,7 +275,7 @@ static int setup_from_host_matrix(Device* dev, PublicMatrixUpload& upA, const ui
   DevBuf rhs;
   const bool mfma = !planar_rhs && mfma_matmul_enabled() && mfma_matmul_applicable(A_dev, N, N, C, rhs_bits);
   if (mfma) {
-    TRY_(hipMalloc(&rhs.p, (size_t)mfma_rhs_workspace_bytes(N, C, chunk)));
+    TRY_(CPIR_HIP_MALLOC(&rhs.p, (size_t)mfma_rhs_workspace_bytes(N, C, chunk)));
     st = launch_rhs_split(dev, (const uint32_t*)D_dev.p, C, N, C, rhs.p, stream);
     if (st != CPIR_OK) return fail(st);
   }
@@ -361,10 +361,10 @@ static int setup_group_from_host_matrix(const std::vector<Device*>& devs, Public
     DeviceGuard dg(devs[g]->ordinal);
     Server* child = server_new(devs[g], L, lo, N);
     grp->shards.push_back(child);
-    TRY_(hipMalloc(&child->dtc, (size_t)L.total_words * 4));
-    TRY_(hipMalloc(&work[g].D_dev.p, (size_t)(hi - lo) * C * 4));
-    TRY_(hipMalloc(&work[g].flag.p, 4));
-    TRY_(hipMalloc(&work[g].M_dev.p, (size_t)CPIR_LWE_DIMENSION * C * 4));
+    TRY_(CPIR_HIP_MALLOC(&child->dtc, (size_t)L.total_words * 4));
+    TRY_(CPIR_HIP_MALLOC(&work[g].D_dev.p, (size_t)(hi - lo) * C * 4));
+    TRY_(CPIR_HIP_MALLOC(&work[g].flag.p, 4));
+    TRY_(CPIR_HIP_MALLOC(&work[g].M_dev.p, (size_t)CPIR_LWE_DIMENSION * C * 4));
     hipStream_t stream = devs[g]->stream;
     TRY_(hipMemcpyAsync(work[g].D_dev.p, D + lo * C, (size_t)(hi - lo) * C * 4, hipMemcpyHostToDevice, stream));
     TRY_(hipMemsetAsync(work[g].flag.p, 0, 4, stream));
@@ -372,8 +372,8 @@ static int setup_group_from_host_matrix(const std::vector<Device*>& devs, Public
     // for this shard is allocated 16-byte aligned with leading dimension hi - lo)
     const uint64_t hi_bytes = planar_hi_plane_bytes(L);
     if (mfma_matmul_enabled() && L.packing == CPIR_PACK_PLANAR && L.mat_elem_bit_len >= 9 && (hi - lo) % 4 == 0 && mfma_pipeline() != 0) {
-      if (hi_bytes) TRY_(hipMalloc(&work[g].hi_plane.p, (size_t)hi_bytes));  // (one bit plane: none, the matmul expands it from the image)
-      TRY_(hipMalloc(&work[g].rowsum_ws.p, 4 * ((CPIR_LWE_DIMENSION + 127) / 128 * 128)));
+      if (hi_bytes) TRY_(CPIR_HIP_MALLOC(&work[g].hi_plane.p, (size_t)hi_bytes));  // (one bit plane: none, the matmul expands it from the image)
+      TRY_(CPIR_HIP_MALLOC(&work[g].rowsum_ws.p, 4 * ((CPIR_LWE_DIMENSION + 127) / 128 * 128)));
     }
     st = launch_transpose_compress(devs[g], (const uint32_t*)work[g].D_dev.p, C, L, child->dtc, (uint32_t*)work[g].flag.p, stream,
                                    work[g].hi_plane.p);
@@ -647,7 +647,7 @@ int cpir_server_from_device_matrix(cpir_device* dev, const uint32_t* D_dev, uint
   if (slot_offset + N_shard > total_slots) return CPIR_ERR_SHARD_RANGE;
   DeviceGuard g(dev->ordinal);
   Server* srv = server_new(dev, L, slot_offset, total_slots);
-  hipError_t e = hipMalloc(&srv->dtc, (size_t)L.total_words * 4);
+  hipError_t e = CPIR_HIP_MALLOC(&srv->dtc, (size_t)L.total_words * 4);
   if (e != hipSuccess) {
     set_last_hip_error(e, "hipMalloc(dtc)", __FILE__, __LINE__);
     server_destroy(srv);
@@ -675,10 +675,10 @@ int cpir_server_from_compressed(cpir_device* dev, const uint32_t* compressed, ui
   DeviceGuard g(dev->ordinal);
   DevBuf src;
   const size_t src_bytes = (size_t)C * L.words_per_row * 4;
-  CPIR_HIP_TRY(hipMalloc(&src.p, src_bytes));
+  CPIR_HIP_TRY(CPIR_HIP_MALLOC(&src.p, src_bytes));
   Server* srv = server_new(dev, L, 0, N);
   auto fail = [&](int st) { server_destroy(srv); return st; };
-  hipError_t e = hipMalloc(&srv->dtc, (size_t)L.total_words * 4);
+  hipError_t e = CPIR_HIP_MALLOC(&srv->dtc, (size_t)L.total_words * 4);
   if (e != hipSuccess) { set_last_hip_error(e, "hipMalloc(dtc)", __FILE__, __LINE__); return fail(CPIR_ERR_OUT_OF_DEVICE_MEMORY); }
   e = hipMemcpyAsync(src.p, compressed, src_bytes, hipMemcpyHostToDevice, dev->stream);
   if (e != hipSuccess) { set_last_hip_error(e, "hipMemcpyAsync", __FILE__, __LINE__); return fail(CPIR_ERR_HIP); }

@@ -173,7 +173,7 @@ uint64_t shard_unit(const cpir_dtc_layout& L);
 struct DevBuf {  // scoped device allocation
   void* p = nullptr;
   ~DevBuf() {
-    if (p) (void)hipFree(p);
+    if (p) (void)CPIR_HIP_FREE(p);
   }
   void dispose_async(int ordinal);  // free in the background (on device `ordinal`) instead of at scope exit
 };
