@@ -499,3 +499,37 @@ def test_wide_database_fused_batches_go_window_by_window(orc, device):
         cp.tuning_set("respond.ks_major", 1)
         assert np.array_equal(srv.respond_array(Q[0]), want[0])  # the host entry point (one query: one window)
         srv.close()
+
+
+def test_more_columns_than_one_query_fits_in_the_accumulators(orc, device):
+    """beyond 12 288 columns even ONE query's responses exceed the step-major kernel's 48 KiB of LDS accumulators: a lone device launch goes
+    over two column windows, the host entry point stages the query instead of reading it in place (a query behind the host link must be
+    read once), and everything agrees with the tile-major kernel and the oracle"""
+    import torch
+
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(12400)
+    stream = torch.cuda.current_stream()
+    b, N, C = 9, 600, 12400
+    D = random_db_matrix(rng, N, C, b)
+    dtc = orc.row_wise_compress(orc.transpose(D), b)
+    srv = cp.Server.from_compressed(dtc, N, b, device=device)
+    Q = np.stack([random_query(rng, N) for _ in range(3)])
+    want = np.stack([orc.row_vector_x_compressed_transposed_matrix(Q[i], dtc, N, b)[0] for i in range(3)])
+    Q_dev = torch.from_numpy(Q.view(np.int32)).cuda()
+    for ks_major in (1, 2, 0):
+        cp.tuning_set("respond.ks_major", ks_major)
+        r = torch.full((C,), -1, dtype=torch.int32, device="cuda")
+        srv.respond_device(Q_dev[0], r, stream=stream)
+        R = torch.full((3, C), -1, dtype=torch.int32, device="cuda")
+        srv.respond_batch_device(Q_dev, 3, R, stream=stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(r.cpu().numpy().view(np.uint32), want[0]), ks_major
+        assert np.array_equal(R.cpu().numpy().view(np.uint32), want), ks_major
+    cp.tuning_set("respond.ks_major", 1)
+    pin = cp.PinnedArray(N)
+    pin.array[:] = Q[1]
+    assert np.array_equal(srv.respond_array(Q[1]), want[1]) and np.array_equal(srv.respond_array(pin.array), want[1])
+    pin.close()
+    srv.close()
