@@ -6,7 +6,7 @@ N = 1 179 648 slots, C = 940 columns, b = 9 bits, 3 fields per packed u32), and 
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one batch of `--queries-per-step` distinct synthetic queries; every query is an independent
+A "step" is one batch of `--queries-per-step` (default: 32 per GPU) distinct synthetic queries; every query is an independent
 Server::respond: one full pass of the respond kernel over the packed database resident in HBM (inputs already in HBM
 when the timed region starts).  For N > 1 (one process per GPU, launched by torch.distributed.run) the database is
 sharded along the filter-slot axis, every rank streams its shard, and the per-shard partial responses of the step's
@@ -67,8 +67,11 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
-    ap.add_argument("--queries-per-step", type=int, default=32)
-    ap.add_argument("--query-pool", type=int, default=64, help="distinct queries cycled through (no query-side caching)")
+    ap.add_argument("--queries-per-step", type=int, default=0,
+                    help="queries in a step's batch; 0 (default) = 32 per GPU: the database is fixed, so a rank's share of a step shrinks with the "
+                         "number of GPUs (0.37 ms for 32 queries on an eighth of the headline database) and a step of a fixed 32 queries would "
+                         "be timed against the latency of its own barrier")
+    ap.add_argument("--query-pool", type=int, default=0, help="distinct queries cycled through (no query-side caching); 0 = twice the step's batch")
     ap.add_argument("--no-setup", action="store_true", help="skip the server_setup timing (needs A: 8.4 GB at cfg2, ~10 s of host XOF)")
     ap.add_argument("--setup-kv", action="store_true",
                     help="also time the FULL Server::setup(seed, kv database) incl. filter construction and row encoding "
@@ -111,6 +114,10 @@ def main() -> int:
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if args.queries_per_step <= 0:
+        args.queries_per_step = 32 * max(1, world)
+    if args.query_pool <= 0:
+        args.query_pool = 2 * args.queries_per_step
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
