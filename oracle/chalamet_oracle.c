@@ -805,7 +805,7 @@ int or_recover_value(const uint32_t* mat, uint64_t mat_rows, uint64_t mat_cols, 
     uint8_t hkb[32];
     for (unsigned i = 0; i < 4; i++) put_le64(hkb + 8 * i, hk[i]);
     uint8_t acc = 0;
-    for (unsigned i = 0; i < 32; i++) acc |= (uint8_t)(kv[i] ^ hkb[i]);
+    for (unsigned i = 0; i < 32; i++) acc ^= (uint8_t)(kv[i] ^ hkb[i]); /* client.rs:252: an XOR fold, as the reference has it */
     if (acc != 0) rc = OR_ERR_DECODED_ROW_NOT_PREPENDED_WITH_DIGEST;
     else if (kv_len - 32 > value_cap) rc = OR_ERR_BUFFER_TOO_SMALL;
     else { memcpy(value, kv + 32, kv_len - 32); *value_len = kv_len - 32; }
@@ -977,7 +977,7 @@ int or_client_process_response(const or_bff* filter, const uint8_t* key, size_t 
     uint8_t hkb[32];
     for (unsigned i = 0; i < 4; i++) put_le64(hkb + 8 * i, hk[i]);
     uint8_t acc = 0;
-    for (unsigned i = 0; i < 32; i++) acc |= (uint8_t)(kv[i] ^ hkb[i]);
+    for (unsigned i = 0; i < 32; i++) acc ^= (uint8_t)(kv[i] ^ hkb[i]); /* client.rs:252: an XOR fold, as the reference has it */
     if (acc != 0) rc = OR_ERR_DECODED_ROW_NOT_PREPENDED_WITH_DIGEST;
     else if (kv_len - 32 > value_cap) rc = OR_ERR_BUFFER_TOO_SMALL;
     else { memcpy(value, kv + 32, kv_len - 32); *value_len = kv_len - 32; }

@@ -402,6 +402,21 @@ def ternary_vector(n: int, rng: np.random.Generator) -> np.ndarray:
     return out
 
 
+def ternary_vector_np(n: int, rng: np.random.Generator) -> np.ndarray:
+    """ternary_vector for long vectors (the error vector e has N entries): the same rejection sampling and interval map as
+    matrix.rs:577-612, stated in numpy; tests/test_oracle_properties.py pins it to or_ternary_from_u32 draw by draw"""
+    interval = (0xFFFFFFFF - 2) // 3
+    out = np.empty(n, dtype=np.uint32)
+    i = 0
+    while i < n:
+        d = rng.integers(0, 1 << 32, size=n - i, dtype=np.uint64)
+        d = d[d <= 3 * interval]
+        t = np.where(d <= interval, 0, np.where(d <= 2 * interval, 1, 0xFFFFFFFF)).astype(np.uint32)
+        out[i:i + t.size] = t
+        i += t.size
+    return out
+
+
 def client_query(A: np.ndarray, hint: np.ndarray, filt: Filter, key: bytes, secret_s: np.ndarray, error_e: np.ndarray):
     A, hint, secret_s, error_e = _u32(A), _u32(hint), _u32(secret_s), _u32(error_e)
     N, Cc = A.shape[1], hint.shape[1]
@@ -424,6 +439,27 @@ def client_process_response(filt: Filter, key: bytes, secret_c: np.ndarray, resp
     _chk(lib().or_client_process_response(C.byref(c), k, C.c_size_t(len(key)), _p(secret_c), _p(response), C.c_uint64(response.size),
                                           out, C.c_size_t(cap), C.byref(n)))
     return bytes(out[: n.value])
+
+
+def filter_slots(filt: Filter, key: bytes):
+    """the `arity` filter slots a key hashes to, as the client derives them (client.rs:109-113 / 158-163: hash_of_key -> mix256 with
+    the filter's seed -> hash_batch_for_{3,4}_wise_xor_filter): the rows of D whose masked sum carries the key's value"""
+    L = lib()
+    hk = (C.c_uint64 * 4)()
+    k = (C.c_uint8 * max(len(key), 1)).from_buffer_copy(key if key else b"\0")
+    L.or_hash_of_key(k, C.c_size_t(len(key)), hk)
+    seed = (C.c_uint8 * 32).from_buffer_copy(filt.seed)
+    L.or_mix256.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint8)]
+    h64 = L.or_mix256(hk, seed)
+    h = (C.c_uint32 * 4)()
+    fn = L.or_hash_batch_3 if filt.arity == 3 else L.or_hash_batch_4
+    fn(C.c_uint64(h64), C.c_uint32(filt.segment_length), C.c_uint32(filt.segment_count_length), h)
+    return [int(h[j]) for j in range(filt.arity)]
+
+
+def query_indicator(b: int) -> int:
+    """client.rs:277-282: 2^32 / 2^b"""
+    return (1 << 32) >> b
 
 
 def first_touch_copy(m: np.ndarray) -> np.ndarray:

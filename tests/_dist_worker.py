@@ -59,16 +59,17 @@ def main():
     seed = bytes(range(32))
     for rows, N, C, unit, block_bytes in ((50, 3 * 1024 * 4 + 5, 6, 3 * 1024, 4 * (3 * 1024 * 4 + 5) * 7), (1774, 2000, 3, 512, 64 << 20),
                                           (9, 700, 2, 1024, 1)):
-        slab, lo, hi = scatter_public_matrix(seed, N, unit, rows=rows, block_bytes=block_bytes)
-        assert (lo, hi) == shard_range(N, unit, rank, world)
-        A = orc.generate_from_seed(rows, N, seed)
-        assert np.array_equal(slab.numpy().view(np.uint32), A[:, lo:hi]), (rows, N, rank)
-        D = random_db_matrix(np.random.default_rng(7), N, C, 9)
-        part = orc.mul(np.ascontiguousarray(A[:, lo:hi]), D[lo:hi]) if hi > lo else np.zeros((rows, C), dtype=np.uint32)
-        m = torch.from_numpy(part.view(np.int32).copy())
-        reduce_u32_(m, dst=0)
-        if rank == 0:
-            assert np.array_equal(m.numpy().view(np.uint32), orc.mul(A, D)), (rows, N)
+        for via in ("p2p", "broadcast", None):  # both transports (None = the backend's default: p2p under gloo)
+            slab, lo, hi = scatter_public_matrix(seed, N, unit, rows=rows, block_bytes=block_bytes, via=via)
+            assert (lo, hi) == shard_range(N, unit, rank, world)
+            A = orc.generate_from_seed(rows, N, seed)
+            assert np.array_equal(slab.numpy().view(np.uint32), A[:, lo:hi]), (rows, N, rank)
+            D = random_db_matrix(np.random.default_rng(7), N, C, 9)
+            part = orc.mul(np.ascontiguousarray(A[:, lo:hi]), D[lo:hi]) if hi > lo else np.zeros((rows, C), dtype=np.uint32)
+            m = torch.from_numpy(part.view(np.int32).copy())
+            reduce_u32_(m, dst=0)
+            if rank == 0:
+                assert np.array_equal(m.numpy().view(np.uint32), orc.mul(A, D)), (rows, N)
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank} ok")

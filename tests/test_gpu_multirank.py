@@ -22,8 +22,12 @@ def test_bench_multirank_on_one_gpu(world, config):
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == world and out["verified_vs_oracle"] is True and out["scaling"] == "strong"
+    assert out["n_gpus"] == world and out["verified_vs_oracle"] is True and out["scaling"] == "weak"
     assert out["value"] > 0
+    # the default-on proof every N > 1 line carries (no oracle involved): unit / dense / all-ones queries, both dispatch modes
+    assert out["multirank_bit_exact"] is True and out["ranks_seen"] == list(range(world))
+    chk = out["multirank_check"]
+    assert chk["unit_queries_ok"] and chk["dense_and_all_ones_ok"] and chk["same_response_on_every_rank"] and sum(chk["shard_slots"]) > 0
     # the sharded setup (partial hints reduced to rank 0) gives the same hint as the single-process setup of the same DB
     single = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "1", "--warmup", "0",
                              "--no-cpu-baseline", "--no-live-traffic", "--queries-per-step", "8", "--query-pool", "16"], capture_output=True, text=True,
@@ -47,6 +51,37 @@ def test_bench_gpus_n_launches_its_own_ranks():
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["backend"] == "gloo" and out["verified_vs_oracle"] is True
+
+
+def test_driver_command_rehearsal_four_ranks():
+    """the driver's exact scaling command shape (`bench.py --gpus N --steps 20 --warmup 5`, its own default batch: 32 queries per GPU)
+    with 4 ranks on the one GPU under the gloo hook (the pool allows 6 processes on a card; this one holds it too): the line must carry
+    its own proof of bit-exactness, all ranks seen, and the sharded setup's hint checksum"""
+    env = dict(os.environ, CPIR_BENCH_BACKEND="gloo", CPIR_BENCH_SHARE_DEVICE="1", OMP_NUM_THREADS="4")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "20", "--warmup", "5", "--config", "cfg1"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    first, out = json.loads(lines[0]), json.loads(lines[-1])
+    assert first["server_setup_pending"] is True and first["multirank_bit_exact"] is True  # the proof is in the line that is printed FIRST
+    assert out["n_gpus"] == 4 and out["ranks"] == 4 and out["config"]["queries_per_step"] == 128 and out["steps"] == 20
+    assert out["multirank_bit_exact"] is True and out["ranks_seen"] == [0, 1, 2, 3]
+    assert out["server_setup_wall_sec"] > 0 and "server_setup_timed_out" not in out and out["hint_checksum"] > 0
+
+
+def test_setup_deadline_is_not_a_success():
+    """a sharded setup whose collectives never come back: the respond line is out first, the LAST line says so, the exit code is not 0"""
+    env = dict(os.environ, CPIR_BENCH_BACKEND="gloo", CPIR_BENCH_SHARE_DEVICE="1", OMP_NUM_THREADS="4", CPIR_BENCH_TEST_HANG_SETUP="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "tiny", "--setup-deadline", "5"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0, p.stdout[-2000:]
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert lines[0]["server_setup_pending"] is True and lines[0]["value"] > 0
+    assert lines[-1]["server_setup_timed_out"] is True and "deadline" in lines[-1]["server_setup_error"] and lines[-1]["value"] == lines[0]["value"]
 
 
 def test_bench_single_rank_verify():

@@ -269,3 +269,46 @@ def test_keyword_pir_oracle_end_to_end(arity, orc):
     resp = unwire(orc.server_respond(dtc, N, b, wire(qb)))
     with pytest.raises(orc.OracleError):
         orc.client_process_response(filt, b"definitely-not-a-key", sc, resp)
+
+
+def test_vectorised_ternary_sampler_equals_the_scalar_restatement(orc):
+    """oracle.ternary_vector_np (used for the N-long error vectors of the full-size end-to-end test) draws the same u32 stream and maps
+    it like or_ternary_from_u32 (matrix.rs:577-612), rejections included"""
+    a = orc.ternary_vector(5000, np.random.default_rng(11))
+    b = orc.ternary_vector_np(5000, np.random.default_rng(11))
+    assert np.array_equal(a, b) and set(np.unique(a).tolist()) == {0, 1, 0xFFFFFFFF}
+    # the rejection branch itself: values just around the boundaries
+    import ctypes as C
+
+    interval = (0xFFFFFFFF - 2) // 3
+    for v, want in ((0, 0), (interval, 0), (interval + 1, 1), (2 * interval, 1), (2 * interval + 1, 0xFFFFFFFF), (3 * interval, 0xFFFFFFFF),
+                    (3 * interval + 1, None), (0xFFFFFFFF, None)):
+        t = C.c_uint32()
+        ok = orc.lib().or_ternary_from_u32(C.c_uint32(v), C.byref(t))
+        assert (t.value if ok else None) == want
+
+
+def test_filter_slots_are_where_the_query_indicator_lands(orc):
+    """oracle.filter_slots restates the slot derivation of Client::query (client.rs:109-113): a query for a key differs from s*A + e in
+    exactly those slots, by 2^32 / 2^b"""
+    rng = np.random.default_rng(21)
+    for arity in (3, 4):
+        keys = [rng.bytes(20) for _ in range(300)]
+        vals = [rng.bytes(10) for _ in keys]
+        b = orc.find_encoded_db_matrix_element_bit_length(len(keys))
+        D, filt, _ = orc.from_kv_database(arity, keys, vals, b, rng.bytes(32 * 100))
+        N = filt.num_fingerprints
+        seed = rng.bytes(32)
+        A = orc.generate_from_seed(1774, N, seed)
+        hint = orc.mul(A, D)
+        for key in keys[:5]:
+            s, e = orc.ternary_vector(1774, rng), orc.ternary_vector_np(N, rng)
+            try:
+                q, _ = orc.client_query(A, hint, filt, key, s, e)
+            except orc.OracleError:
+                continue
+            base = (orc.mul(s.reshape(1, -1), A)[0] + e).astype(np.uint32)
+            diff = (q - base).astype(np.uint32)
+            slots = orc.filter_slots(filt, key)
+            assert len(set(slots)) == arity and sorted(np.nonzero(diff)[0].tolist()) == sorted(slots)
+            assert all(int(diff[h]) == orc.query_indicator(b) for h in slots)
