@@ -124,6 +124,11 @@ SIGNATURES = {
     "cpir_server_release": (None, [vp]),
     "cpir_server_layout": (C.c_int, [vp, C.POINTER(DtcLayout)]),
     "cpir_server_shard": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "cpir_server_physical_layout": (C.c_int, [vp, C.POINTER(DtcLayout)]),
+    "cpir_server_slots_served": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "cpir_server_kept_slots": (C.c_int, [vp, u32p, C.c_uint64]),
+    "cpir_host_gather_variant": (C.c_char_p, []),
+    "cpir_host_gather_words": (C.c_int, [u32p, u32p, u32p, C.c_uint64]),
     "cpir_server_dtc_device_ptr": (vp, [vp]),
     "cpir_server_respond_bytes": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "cpir_server_respond": (C.c_int, [vp, u32p, C.c_uint32, C.c_uint64, u32p]),

@@ -362,6 +362,19 @@ int cpir_server_export_compressed(const cpir_server* srv, uint32_t* compressed_o
   DeviceGuard g(srv->dev->ordinal);
   DevBuf tmp;
   CPIR_HIP_TRY(CPIR_HIP_MALLOC(&tmp.p, (size_t)words * 4));
+  if (srv->map.active()) {
+    // only the slots with a non-zero row are resident: export those in the reference's representation, then spread them over all N slots
+    // (a dropped slot's fields are zero -- that is why it was dropped)
+    const cpir_dtc_layout& P = srv->phys;
+    DevBuf part;
+    CPIR_HIP_TRY(CPIR_HIP_MALLOC(&part.p, (size_t)P.num_cols * P.words_per_row * 4));
+    CPIR_TRY(launch_dtc_export(srv->dev, srv->dtc, P, (uint32_t*)part.p, srv->dev->stream));
+    CPIR_TRY(launch_expand_ref(srv->dev, (const uint32_t*)part.p, P.words_per_row, srv->map, L.words_per_row, L.num_cols, L.compression_factor,
+                               (uint32_t*)tmp.p, srv->dev->stream));
+    CPIR_HIP_TRY(hipMemcpyAsync(compressed_out, tmp.p, (size_t)words * 4, hipMemcpyDeviceToHost, srv->dev->stream));
+    CPIR_HIP_TRY(hipStreamSynchronize(srv->dev->stream));
+    return CPIR_OK;
+  }
   CPIR_TRY(launch_dtc_export(srv->dev, srv->dtc, L, (uint32_t*)tmp.p, srv->dev->stream));
   CPIR_HIP_TRY(hipMemcpyAsync(compressed_out, tmp.p, (size_t)words * 4, hipMemcpyDeviceToHost, srv->dev->stream));
   CPIR_HIP_TRY(hipStreamSynchronize(srv->dev->stream));
@@ -386,6 +399,41 @@ void cpir_server_release(cpir_server* srv) {
 int cpir_server_layout(const cpir_server* srv, cpir_dtc_layout* out) {
   if (!srv || !out) return CPIR_ERR_INVALID_ARGUMENT;
   *out = srv->layout;
+  return CPIR_OK;
+}
+
+int cpir_server_physical_layout(const cpir_server* srv, cpir_dtc_layout* out) {
+  if (!srv || !out) return CPIR_ERR_INVALID_ARGUMENT;
+  *out = srv->phys;
+  return CPIR_OK;
+}
+
+int cpir_server_slots_served(const cpir_server* srv, uint64_t* served, uint64_t* of_slots) {
+  if (!srv) return CPIR_ERR_INVALID_ARGUMENT;
+  uint64_t kept = 0;
+  if (!srv->shards.empty()) {
+    for (const Server* c : srv->shards) kept += c->map.active() ? c->map.n_kept : c->layout.num_slots;
+  } else {
+    kept = srv->map.active() ? srv->map.n_kept : srv->layout.num_slots;
+  }
+  if (served) *served = kept;
+  if (of_slots) *of_slots = srv->layout.num_slots;
+  return CPIR_OK;
+}
+
+int cpir_server_kept_slots(const cpir_server* srv, uint32_t* out, uint64_t cap) {
+  if (!srv || !out || !srv->shards.empty()) return CPIR_ERR_INVALID_ARGUMENT;
+  if (!srv->map.active()) return CPIR_ERR_INVALID_ARGUMENT;
+  if (cap < srv->map.n_kept) return CPIR_ERR_BUFFER_TOO_SMALL;
+  memcpy(out, srv->map.keep_host.data(), (size_t)srv->map.n_kept * 4);
+  return CPIR_OK;
+}
+
+const char* cpir_host_gather_variant(void) { return gather_words_variant(); }
+
+int cpir_host_gather_words(uint32_t* dst, const uint32_t* src, const uint32_t* idx, uint64_t count) {
+  if ((!dst || !src || !idx) && count) return CPIR_ERR_INVALID_ARGUMENT;
+  gather_words(dst, src, idx, (size_t)count);
   return CPIR_OK;
 }
 

@@ -155,6 +155,30 @@ void set_pack_rows_mode(int m);
 int launch_dtc_import(const Device* dev, const uint32_t* compressed, const cpir_dtc_layout& L, uint32_t* dtc, hipStream_t stream);
 int launch_dtc_export(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, uint32_t* compressed, hipStream_t stream);
 
+// compact.hip: serving only the slots whose row of D has a non-zero field (a real encoded database leaves N - n rows all zero)
+struct SlotMap {
+  uint32_t* keep_dev = nullptr;     // device: compact index -> slot (relative to the first slot of this database / shard), increasing;
+                                    // n_pad entries, the padding holds 0xFFFFFFFF
+  std::vector<uint32_t> keep_host;  // the same, n_kept entries (a lone host query is compacted on the host while it is staged)
+  uint64_t n_kept = 0;              // 0: no map, every slot is served
+  uint64_t n_pad = 0;               // stride and length of a compact query: n_kept rounded up to 128 words
+  uint64_t n_orig = 0;              // slots the map selects from
+  bool active() const { return n_kept != 0; }
+  void reset();
+};
+int compact_slots_mode();  // tuning "layout.compact_slots": 0 never, 1 (default) where at least 1/32 of the rows are zero, 2 whenever a row is
+void set_compact_slots_mode(int m);
+int build_slot_map(const Device* dev, const uint32_t* D_dev, uint64_t ldd, uint64_t N, uint32_t C, uint32_t b, hipStream_t stream, SlotMap* map,
+                   uint32_t* or_of_entries_host);
+int launch_gather_rows(const Device* dev, const uint32_t* D_dev, uint64_t ldd, const SlotMap& map, uint32_t C, uint32_t* out, hipStream_t stream);
+int launch_gather_query(const Device* dev, const uint32_t* q, uint64_t q_len, uint64_t q_slot_offset, const SlotMap& map, uint32_t batch,
+                        uint32_t* out, hipStream_t stream);
+int launch_expand_ref(const Device* dev, const uint32_t* compact_ref, uint64_t Wc, const SlotMap& map, uint64_t W, uint32_t C, uint32_t cf,
+                      uint32_t* out, hipStream_t stream);
+// host_gather.cpp: dst[i] = src[idx[i]] on the host (AVX-512 / AVX2 gathers where the CPU has them)
+void gather_words(uint32_t* dst, const uint32_t* src, const uint32_t* idx, size_t count);
+const char* gather_words_variant();
+
 // matmul.hip
 int launch_mat_x_mat(const Device* dev, const uint32_t* A, uint64_t lda, const uint32_t* D, uint64_t ldd, uint32_t* M,
                      uint64_t ldm, uint64_t rows, uint64_t inner, uint64_t cols, uint32_t rhs_max_bits, int accumulate,

@@ -18,7 +18,13 @@ class StagingHelpers {
     const void* src;
     size_t bytes;
     std::atomic<int>* done;  // set to 1 when copied
+    const uint32_t* idx = nullptr;  // NULL: dst <- src, `bytes` bytes; else dst[i] = src[idx[i]] for bytes / 4 words (a query compacted
+                                    // onto the slots the server holds, compact.hip)
   };
+  static void copy(const Job& j) {
+    if (j.idx) gather_words(static_cast<uint32_t*>(j.dst), static_cast<const uint32_t*>(j.src), j.idx, j.bytes / 4);
+    else memcpy(j.dst, j.src, j.bytes);
+  }
   ~StagingHelpers() {
     {
       std::lock_guard<std::mutex> lk(mu_);
@@ -53,7 +59,7 @@ class StagingHelpers {
       j = jobs_.front();
       jobs_.pop_front();
     }
-    memcpy(j.dst, j.src, j.bytes);
+    copy(j);
     j.done->store(1, std::memory_order_release);
     return true;
   }
@@ -70,7 +76,7 @@ class StagingHelpers {
         j = jobs_.front();
         jobs_.pop_front();
       }
-      memcpy(j.dst, j.src, j.bytes);
+      copy(j);
       j.done->store(1, std::memory_order_release);
     }
   }
@@ -234,6 +240,7 @@ static int arena_create(Server* srv, RespondArena& a) {
   // (+ 16 words behind the responses: the device block's spare words follow seat 0's response when a lone caller has only one seat
   // to fill -- the abort flag of a polled launch; the pinned block's hold the fill progress the kernel polls)
   const size_t qw = (size_t)srv->total_slots * Server::kSeats, rw = ((size_t)srv->layout.num_cols * Server::kSeats + 3) / 4 * 4 + kArenaSpareWords;
+  const size_t qcw = (size_t)srv->map.n_pad * Server::kSeats;  // (slot map: the seats' queries gathered onto the kept slots; device block only)
   auto fail = [&](hipError_t e, const char* what) {
     set_last_hip_error(e, what, __FILE__, __LINE__);
     arena_free(a);
@@ -244,7 +251,8 @@ static int arena_create(Server* srv, RespondArena& a) {
     CPIR_TRY(device_host_streams(srv->dev));
     srv->up_stream = srv->dev->up_stream, srv->run_stream = srv->dev->run_stream;
   }
-  if ((e = CPIR_HIP_MALLOC(&a.q_dev, (qw + rw) * 4)) != hipSuccess) return fail(e, "hipMalloc(respond arena)");
+  if ((e = CPIR_HIP_MALLOC(&a.q_dev, (qw + rw + qcw) * 4)) != hipSuccess) return fail(e, "hipMalloc(respond arena)");
+  a.q_compact = qcw ? a.q_dev + qw + rw : nullptr;  // behind the responses: q_dev and r_dev keep their places
   // COHERENT (fine-grained) on purpose, whatever HIP_HOST_COHERENT says: a polled launch reads the fill progress and the query words
   // while the host is still writing them (respond_alone), which only works on memory the device does not cache
   if ((e = CPIR_HIP_HOST_MALLOC(&a.q_pinned, (qw + rw) * 4, hipHostMallocCoherent)) != hipSuccess) return fail(e, "hipHostMalloc(respond arena)");
@@ -312,6 +320,7 @@ void server_destroy(Server* srv) {
     DeviceGuard g(srv->dev->ordinal);
     arenas_destroy(srv);
     if (srv->dtc) (void)CPIR_HIP_FREE(srv->dtc);
+    srv->map.reset();
   }
   device_release(srv->dev);
   delete srv;
@@ -329,7 +338,7 @@ static int group_shard_respond(const Server* child, Server::GroupLane& l, const 
   }
   int status = CPIR_OK;
   // a shard answered from ITS slice of the query is an unsharded respond on a database of its own slots
-  if (e == hipSuccess) status = launch_respond(child->dev, child->dtc, child->layout, l.q_dev, n, 0, 1, 1, l.r_dev, nullptr, l.stream);
+  if (e == hipSuccess) status = server_respond_on_device(child, l.q_dev, n, 0, 1, true, l.r_dev, nullptr, l.q_compact, l.stream);
   if (e == hipSuccess && status == CPIR_OK) e = hipMemcpyAsync(l.r_pinned, l.r_dev, (size_t)C * 4, hipMemcpyDeviceToHost, l.stream);
   const hipError_t e2 = hipStreamSynchronize(l.stream);  // drain whatever was enqueued
   if (e == hipSuccess) e = e2;
@@ -376,16 +385,18 @@ static int group_ctx_create(Server* srv) {
       Server::GroupLane& l = c.lanes[g];
       const Server* child = srv->shards[g];
       DeviceGuard dg(child->dev->ordinal);
-      const size_t qw = ((size_t)child->layout.num_slots + 3) / 4 * 4, words = qw + C;
+      const size_t qw = ((size_t)child->layout.num_slots + 3) / 4 * 4, words = qw + (C + 3) / 4 * 4;
+      const size_t qcw = (size_t)child->map.n_pad;  // (slot map) the slice gathered onto the kept slots: behind the response, device block only
 #define TRY_(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_last_hip_error(_e, #e, __FILE__, __LINE__); group_ctx_destroy(srv); \
     return _e == hipErrorOutOfMemory ? CPIR_ERR_OUT_OF_DEVICE_MEMORY : CPIR_ERR_HIP; } } while (0)
       if (!(l.stream = device_stream_acquire(child->dev))) {
         group_ctx_destroy(srv);
         return CPIR_ERR_HIP;
       }
-      TRY_(CPIR_HIP_MALLOC(&l.q_dev, words * 4));
+      TRY_(CPIR_HIP_MALLOC(&l.q_dev, (words + qcw) * 4));
       TRY_(CPIR_HIP_HOST_MALLOC(&l.q_pinned, words * 4, hipHostMallocDefault));
 #undef TRY_
+      l.q_compact = qcw ? l.q_dev + words : nullptr;
       l.r_dev = l.q_dev + qw;
       l.r_pinned = l.q_pinned + qw;
     }
@@ -455,6 +466,7 @@ Server* server_new(Device* dev, const cpir_dtc_layout& L, uint64_t slot_offset, 
   s->dev = dev;
   device_retain(dev);
   s->layout = L;
+  s->phys = L;
   s->slot_offset = slot_offset;
   s->total_slots = total_slots;
   const char* tr = getenv("CPIR_RESPOND_TRACE");
@@ -462,6 +474,45 @@ Server* server_new(Device* dev, const cpir_dtc_layout& L, uint64_t slot_offset, 
   return s;
 }
 
+
+void server_set_physical(Server* srv, const cpir_dtc_layout& phys, SlotMap* map) {
+  srv->phys = phys;
+  srv->map.reset();
+  if (map && map->active()) {
+    srv->map.keep_dev = map->keep_dev, map->keep_dev = nullptr;
+    srv->map.keep_host = std::move(map->keep_host);
+    srv->map.n_kept = map->n_kept, srv->map.n_pad = map->n_pad, srv->map.n_orig = map->n_orig;
+    map->reset();
+  }
+}
+
+int server_respond_on_device(const Server* srv, const uint32_t* q, uint64_t q_len, uint64_t q_slot_offset, uint32_t batch, bool lone, uint32_t* r,
+                             uint32_t* scratch, uint32_t* qc, hipStream_t stream) {
+  if (!srv->map.active()) {
+    if (lone) return launch_respond(srv->dev, srv->dtc, srv->phys, q, q_len, q_slot_offset, 1, 1, r, scratch, stream);
+    return respond_batched(srv->dev, srv->dtc, srv->phys, q, q_len, q_slot_offset, batch, r, scratch, stream);
+  }
+  // only the slots with a non-zero row are resident: gather the queries onto them, then an ordinary respond on the compact database
+  const SlotMap& m = srv->map;
+  if (q_slot_offset + m.n_orig > q_len) return CPIR_ERR_SHARD_RANGE;
+  uint32_t* own = nullptr;
+  if (!qc) {
+    CPIR_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&own), (size_t)batch * m.n_pad * 4, stream));
+    qc = own;
+  }
+  int st = launch_gather_query(srv->dev, q, q_len, q_slot_offset, m, batch, qc, stream);
+  if (st == CPIR_OK)
+    st = lone ? launch_respond(srv->dev, srv->dtc, srv->phys, qc, m.n_pad, 0, 1, 1, r, scratch, stream)
+              : respond_batched(srv->dev, srv->dtc, srv->phys, qc, m.n_pad, 0, batch, r, scratch, stream);
+  if (own) {
+    const hipError_t fe = hipFreeAsync(own, stream);
+    if (st == CPIR_OK && fe != hipSuccess) {
+      set_last_hip_error(fe, "hipFreeAsync(compact queries)", __FILE__, __LINE__);
+      st = CPIR_ERR_HIP;
+    }
+  }
+  return st;
+}
 
 // Any batch size.  With batch fusion every pass answers 4 queries from one stream of the database (remainder 2 / 1);
 // without it every query is its own pass.  Either way the passes of one kind go into ONE launch.
@@ -516,7 +567,14 @@ extern "C" {
 // words (see below; two plain launches, each when its half is in place, if polling is off).  r_dev is kept zeroed between uses.
 static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32_t* r_out) {
   const size_t C = srv->layout.num_cols;
-  const size_t q_lo = (size_t)srv->slot_offset, words = (size_t)srv->layout.num_slots;
+  // With a slot map (compact.hip) the kernel reads a COMPACT query -- the words of the kept slots only, q_len = map.n_pad, no offset --
+  // which exists nowhere yet: it is produced in the pinned block by the same copy jobs that otherwise just copy (dst[i] = q[q_lo +
+  // keep[i]]), so the polled launch applies unchanged and a page-locked caller buffer is no shortcut any more.
+  const bool mapped = srv->map.active();
+  const size_t q_lo = (size_t)srv->slot_offset;
+  const size_t words = mapped ? (size_t)srv->map.n_kept : (size_t)srv->layout.num_slots;  // words of q the kernel reads
+  const uint64_t kq_len = mapped ? srv->map.n_pad : srv->total_slots, kq_off = mapped ? 0 : srv->slot_offset;  // as the kernel addresses them
+  const cpir_dtc_layout& L = srv->phys;
   hipStream_t st = srv->run_stream;
   std::lock_guard<std::mutex> ll(srv->dev->launch_mu);
   hipError_t e = hipSuccess;
@@ -528,20 +586,28 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
   // the slots this server reads, q[q_lo, q_lo + words), as the device addresses them -- if the whole range is page-locked; the kernel
   // is handed the (possibly virtual) address of q[0] and adds the offset itself
   const uint32_t* in_place = nullptr;
-  if (e == hipSuccess && reinterpret_cast<uintptr_t>(q) % 16 == 0) {
+  if (e == hipSuccess && !mapped && reinterpret_cast<uintptr_t>(q) % 16 == 0) {
     const void* dp = pinned_range_device_pointer(q + q_lo, words * 4);
     if (dp && reinterpret_cast<uintptr_t>(dp) % 16 == (q_lo * 4) % 16) in_place = static_cast<const uint32_t*>(dp) - q_lo;
   }
   if (e == hipSuccess && in_place) {
     journal_note("respond: q read in place", q + q_lo, words * 4, __FILE__, __LINE__);
-    rc = launch_respond_read_once(srv->dev, srv->dtc, srv->layout, in_place, srv->total_slots, srv->slot_offset, a->r_dev, st);
+    rc = launch_respond_read_once(srv->dev, srv->dtc, L, in_place, kq_len, kq_off, a->r_dev, st);
   } else if (e == hipSuccess) {
-    uint32_t* const qp = a->q_pinned;  // seat 0; same offsets as the caller's buffer
+    // seat 0 of the pinned block: the same offsets as the caller's buffer, or (slot map) the compact query from word 0
+    uint32_t* const qp = mapped ? a->q_pinned : a->q_pinned + q_lo;
+    const uint32_t* const src = q + q_lo;
+    const uint32_t* const idx = mapped ? srv->map.keep_host.data() : nullptr;
     constexpr size_t kJob = (size_t)1 << 16;  // 256 KiB of u32, a multiple of the kernel's 512-slot step
     static_assert(kJob % CPIR_PLANAR_SLOTS_PER_TILE == 0, "a copy job must end on a step boundary: the kernel is told whole steps");
     constexpr size_t kStepsPerJob = kJob / CPIR_PLANAR_SLOTS_PER_TILE;
     constexpr size_t kMaxJobs = 512;
     const size_t n_jobs = (words + kJob - 1) / kJob;
+    // job i: words [i * kJob, ...) of what the kernel reads
+    auto job = [&](size_t i, std::atomic<int>* done) {
+      const size_t o = i * kJob, n = (words - o < kJob) ? words - o : kJob;
+      return mapped ? StagingHelpers::Job{qp + o, src, n * 4, done, idx + o} : StagingHelpers::Job{qp + o, src + o, n * 4, done, nullptr};
+    };
     // how long a wave waits for the words of a step (the tuning value, default 2 ms), but never less than the whole copy would take at
     // 5 GB/s -- a quarter of what ONE core copies: the last steps of a long query are legitimately waited for that long
     uint32_t fill_timeout_us = respond_host_fill_timeout_us();
@@ -555,20 +621,19 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
       // (synchronous launches under a debugger or a serialising profiler) costs that timeout once, and after three such launches the
       // server stops polling and launches each half of the query when it is in place.
       // (no 128-byte line of the pinned block may straddle two copy jobs -- a wave that has seen job i's count could otherwise fetch a
-      // line whose tail belongs to job i + 1: the shard must start on a line boundary, which every shard_unit() multiple does)
-      polled = fill_timeout_us > 0 && srv->fill_aborts.load(std::memory_order_relaxed) < 3 && (q_lo * 4) % 128 == 0;
+      // line whose tail belongs to job i + 1: the words the kernel reads must start on a line boundary, which every shard_unit() multiple
+      // does, and a compact query does by starting at word 0)
+      polled = fill_timeout_us > 0 && srv->fill_aborts.load(std::memory_order_relaxed) < 3 && (mapped || (q_lo * 4) % 128 == 0);
       if (polled) {
         journal_note("respond: polled launch", a->q_pinned, words * 4, __FILE__, __LINE__);
         publish_fill_progress(a->fill_progress, 0u);
         const PlanarHostFill fill{a->fill_progress_dev, a->r_dev + C, fill_timeout_us};
-        rc = launch_respond_read_once(srv->dev, srv->dtc, srv->layout, a->q_pinned_dev, srv->total_slots, srv->slot_offset, a->r_dev, st, 0, 0,
-                                      &fill);
+        rc = launch_respond_read_once(srv->dev, srv->dtc, L, a->q_pinned_dev, kq_len, kq_off, a->r_dev, st, 0, 0, &fill);
         if (rc != CPIR_OK) polled = false;  // nothing was launched
       }
       for (size_t i = 0; i < n_jobs; i++) {
         done[i].store(0, std::memory_order_relaxed);
-        const size_t o = q_lo + i * kJob, n = (words - i * kJob < kJob) ? words - i * kJob : kJob;
-        g_staging.submit(StagingHelpers::Job{qp + o, q + o, n * 4, &done[i]});
+        g_staging.submit(job(i, &done[i]));
       }
       auto wait_for_job = [&](size_t i) {
         while (!done[i].load(std::memory_order_acquire))
@@ -590,16 +655,15 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
           for (; next < (h ? n_jobs : j_half); next++) wait_for_job(next);
           const uint64_t s_lo = h ? j_half * kStepsPerJob : 0;
           const uint64_t s_hi = h ? (words + CPIR_PLANAR_SLOTS_PER_TILE - 1) / CPIR_PLANAR_SLOTS_PER_TILE : j_half * kStepsPerJob;
-          if (s_hi > s_lo)
-            rc = launch_respond_read_once(srv->dev, srv->dtc, srv->layout, a->q_pinned_dev, srv->total_slots, srv->slot_offset, a->r_dev, st,
-                                          s_lo, s_hi);
+          if (s_hi > s_lo) rc = launch_respond_read_once(srv->dev, srv->dtc, L, a->q_pinned_dev, kq_len, kq_off, a->r_dev, st, s_lo, s_hi);
         }
       }
       for (size_t i = 0; i < n_jobs; i++) wait_for_job(i);  // every job must have run before the stack array goes away, whatever happened
       g_staging.release();
     } else {
-      memcpy(qp + q_lo, q + q_lo, words * 4);
-      rc = launch_respond_read_once(srv->dev, srv->dtc, srv->layout, a->q_pinned_dev, srv->total_slots, srv->slot_offset, a->r_dev, st);
+      if (mapped) gather_words(qp, src, idx, words);
+      else memcpy(qp, src, words * 4);
+      rc = launch_respond_read_once(srv->dev, srv->dtc, L, a->q_pinned_dev, kq_len, kq_off, a->r_dev, st);
     }
   }
   for (int attempt = 0; attempt < 2; attempt++) {
@@ -620,8 +684,7 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
     srv->fill_aborts.fetch_add(1, std::memory_order_relaxed);
     if (!a->r0_zero) e = hipMemsetAsync(a->r_dev, 0, (C + 1) * 4, st);
     a->r0_zero = false;
-    if (e == hipSuccess)
-      rc = launch_respond_read_once(srv->dev, srv->dtc, srv->layout, a->q_pinned_dev, srv->total_slots, srv->slot_offset, a->r_dev, st);
+    if (e == hipSuccess) rc = launch_respond_read_once(srv->dev, srv->dtc, L, a->q_pinned_dev, kq_len, kq_off, a->r_dev, st);
   }
   if (polled) {
     srv->fill_polled.fetch_add(1, std::memory_order_relaxed);
@@ -651,7 +714,7 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
   // ---- take a seat ----------------------------------------------------------------------------------------------
   const bool tr = srv->trace_on;
   const double t_enter = tr ? now_seconds() : 0;
-  const bool read_once_ok = respond_read_once_applicable(srv->layout);
+  const bool read_once_ok = respond_read_once_applicable(srv->phys);
   std::unique_lock<std::mutex> lk(srv->mu);
   RespondArena* a = nullptr;
   bool solo = false;
@@ -806,7 +869,7 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
       for (uint32_t i = 0; i < k && e == hipSuccess; i++) e = hipStreamWaitEvent(srv->run_stream, a->seat_ev[i], 0);
       a->r0_zero = false;
       if (e == hipSuccess)
-        st = respond_batched(srv->dev, srv->dtc, srv->layout, a->q_dev, srv->total_slots, srv->slot_offset, k, a->r_dev, nullptr, srv->run_stream);
+        st = server_respond_on_device(srv, a->q_dev, srv->total_slots, srv->slot_offset, k, false, a->r_dev, nullptr, a->q_compact, srv->run_stream);
       if (e == hipSuccess && st == CPIR_OK) e = hipMemcpyAsync(a->r_pinned, a->r_dev, (size_t)k * C * 4, hipMemcpyDeviceToHost, srv->run_stream);
       if (e == hipSuccess) e = hipEventRecord(a->done_ev, srv->run_stream);
     }
@@ -884,16 +947,15 @@ int cpir_server_respond_bytes(const cpir_server* srv, const uint8_t* query, size
 int cpir_server_respond_device(const cpir_server* srv, const uint32_t* q_dev, uint32_t* r_dev, uint32_t* scratch_dev, void* stream) {
   if (!srv || !q_dev || !r_dev || !srv->shards.empty()) return CPIR_ERR_INVALID_ARGUMENT;  // device pointers belong to ONE device
   DeviceGuard g(srv->dev->ordinal);
-  return launch_respond(srv->dev, srv->dtc, srv->layout, q_dev, srv->total_slots, srv->slot_offset, 1, 1, r_dev, scratch_dev,
-                        pick_stream(srv->dev, stream));
+  return server_respond_on_device(srv, q_dev, srv->total_slots, srv->slot_offset, 1, true, r_dev, scratch_dev, nullptr, pick_stream(srv->dev, stream));
 }
 
 int cpir_server_respond_batch_device(const cpir_server* srv, const uint32_t* q_dev, uint32_t batch, uint32_t* r_dev, uint32_t* scratch_dev,
                                      void* stream) {
   if (!srv || !q_dev || !r_dev || batch == 0 || !srv->shards.empty()) return CPIR_ERR_INVALID_ARGUMENT;
   DeviceGuard g(srv->dev->ordinal);
-  return respond_batched(srv->dev, srv->dtc, srv->layout, q_dev, srv->total_slots, srv->slot_offset, batch, r_dev, scratch_dev,
-                         pick_stream(srv->dev, stream));
+  return server_respond_on_device(srv, q_dev, srv->total_slots, srv->slot_offset, batch, false, r_dev, scratch_dev, nullptr,
+                                  pick_stream(srv->dev, stream));
 }
 
 

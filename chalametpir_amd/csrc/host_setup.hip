@@ -220,6 +220,36 @@ void DevBuf::dispose_async(int ordinal) {
     });
 }
 
+// Packs D (L.num_slots x C on the device, leading dimension ldd) into srv->dtc (allocated here).  With an active `map` (the rows of D that
+// have a non-zero field: build_slot_map, compact.hip) only those rows are packed -- gathered into a stream-ordered temporary first -- and the
+// server adopts the map and the compact layout; hi_plane (the hint matmul's second operand plane, written by the pack pass) only goes with an
+// uncompacted image.  Enqueues on `stream`; the caller synchronises.
+static int pack_into_server(Device* dev, Server* srv, const uint32_t* D_dev, uint64_t ldd, const cpir_dtc_layout& L, SlotMap* map, uint32_t* flag_dev,
+                            void* hi_plane, hipStream_t stream) {
+  cpir_dtc_layout P = L;
+  if (map->active()) {
+    if (hi_plane) return CPIR_ERR_INVALID_ARGUMENT;
+    CPIR_TRY(dtc_layout_for_packing(map->n_kept, L.num_cols, L.mat_elem_bit_len, L.packing, &P));
+  }
+  CPIR_HIP_TRY(CPIR_HIP_MALLOC(&srv->dtc, (size_t)P.total_words * 4));
+  int st;
+  if (map->active()) {
+    uint32_t* Dc = nullptr;
+    CPIR_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&Dc), (size_t)map->n_kept * L.num_cols * 4, stream));
+    st = launch_gather_rows(dev, D_dev, ldd, *map, L.num_cols, Dc, stream);
+    if (st == CPIR_OK) st = launch_transpose_compress(dev, Dc, L.num_cols, P, srv->dtc, flag_dev, stream, nullptr);
+    const hipError_t fe = hipFreeAsync(Dc, stream);
+    if (st == CPIR_OK && fe != hipSuccess) {
+      set_last_hip_error(fe, "hipFreeAsync(compact D)", __FILE__, __LINE__);
+      st = CPIR_ERR_HIP;
+    }
+  } else {
+    st = launch_transpose_compress(dev, D_dev, ldd, L, srv->dtc, flag_dev, stream, hi_plane);
+  }
+  if (st == CPIR_OK) server_set_physical(srv, P, map);
+  return st;
+}
+
 // The matrix half of setup once D sits on the host: upload D, pack it, wait for A, one matmul, hint back.
 static int setup_from_host_matrix(Device* dev, PublicMatrixUpload& upA, const uint32_t* D, uint64_t N, uint32_t C, uint32_t b,
                                   uint32_t* hint_out, Server** out) {
@@ -235,7 +265,6 @@ static int setup_from_host_matrix(Device* dev, PublicMatrixUpload& upA, const ui
   auto fail = [&](int st) { server_destroy(srv); return st; };
 #define TRY_(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_last_hip_error(_e, #e, __FILE__, __LINE__); \
     return fail(_e == hipErrorOutOfMemory ? CPIR_ERR_OUT_OF_DEVICE_MEMORY : CPIR_ERR_HIP); } } while (0)
-  TRY_(CPIR_HIP_MALLOC(&srv->dtc, (size_t)L.total_words * 4));
   double t0 = now_seconds();
   TRY_(hipMemcpyAsync(D_dev.p, D, (size_t)N * C * 4, hipMemcpyHostToDevice, stream));
   TRY_(hipStreamSynchronize(stream));
@@ -248,16 +277,27 @@ static int setup_from_host_matrix(Device* dev, PublicMatrixUpload& upA, const ui
   const uint32_t* A_dev = upA.device_ptr();
   DevBuf hi_plane, rowsum_ws;
   const uint64_t hi_bytes = planar_hi_plane_bytes(L);  // 0 with one bit plane (b = 9): the matmul expands it from the image itself
-  bool planar_rhs = mfma_matmul_enabled() && mfma_planar_rhs_applicable(A_dev, N, L);
+  // Rows of D without a non-zero field (the slots of a real encoded database that no key owns: 11 % of them at arity 3) are left out of
+  // the resident image where that pays (compact.hip); the hint is still computed from D as it is, all rows and unmasked (server.rs:61),
+  // through the byte-plane split of the whole matrix -- an image that lacks rows cannot serve as the matmul's right-hand side.
+  SlotMap map;
+  uint32_t ored_rows = 0;
+  int st = CPIR_OK;
+  if (compact_slots_mode() != 0) {
+    st = build_slot_map(dev, (const uint32_t*)D_dev.p, C, N, C, b, stream, &map, &ored_rows);
+    if (st != CPIR_OK) return fail(st);
+  }
+  bool planar_rhs = !map.active() && mfma_matmul_enabled() && mfma_planar_rhs_applicable(A_dev, N, L);
   if (planar_rhs) {
     if (hi_bytes) TRY_(CPIR_HIP_MALLOC(&hi_plane.p, (size_t)hi_bytes));
     TRY_(CPIR_HIP_MALLOC(&rowsum_ws.p, 4 * 128));
   }
-  int st = launch_transpose_compress(dev, (const uint32_t*)D_dev.p, C, L, srv->dtc, (uint32_t*)flag.p, stream, hi_plane.p);
+  st = pack_into_server(dev, srv, (const uint32_t*)D_dev.p, C, L, &map, (uint32_t*)flag.p, hi_plane.p, stream);
   if (st != CPIR_OK) return fail(st);
   uint32_t ored = 0;
   TRY_(hipMemcpyAsync(&ored, flag.p, 4, hipMemcpyDeviceToHost, stream));
   TRY_(hipStreamSynchronize(stream));
+  ored |= ored_rows;  // (the pack pass of a compacted image saw the kept rows only)
   srv->setup_timings[3] = now_seconds() - t0;
   // the hint uses the UNMASKED entries of D (server.rs:61 multiplies before any masking); the packed-16 kernel is
   // exact only if every entry is < 2^16, which holds for every encoded DB (entries < 2^b <= 2^14) and is verified here
@@ -345,7 +385,7 @@ static int setup_group_from_host_matrix(const std::vector<Device*>& devs, Public
   Server* grp = server_new(devs[0], Lfull, 0, N);
   struct Work {
     DevBuf D_dev, flag, M_dev, hi_plane, rowsum_ws;  // hi_plane: the second operand plane of the hint matmul, written by the pack pass
-    uint32_t ored = 0;
+    uint32_t ored = 0, ored_rows = 0;
   };
   std::vector<Work> work(G);
   auto fail = [&](int st) { server_destroy(grp); return st; };
@@ -361,7 +401,6 @@ static int setup_group_from_host_matrix(const std::vector<Device*>& devs, Public
     DeviceGuard dg(devs[g]->ordinal);
     Server* child = server_new(devs[g], L, lo, N);
     grp->shards.push_back(child);
-    TRY_(CPIR_HIP_MALLOC(&child->dtc, (size_t)L.total_words * 4));
     TRY_(CPIR_HIP_MALLOC(&work[g].D_dev.p, (size_t)(hi - lo) * C * 4));
     TRY_(CPIR_HIP_MALLOC(&work[g].flag.p, 4));
     TRY_(CPIR_HIP_MALLOC(&work[g].M_dev.p, (size_t)CPIR_LWE_DIMENSION * C * 4));
@@ -371,12 +410,18 @@ static int setup_group_from_host_matrix(const std::vector<Device*>& devs, Public
     // (as setup_from_host_matrix: where the packed image can serve as the matmul's right-hand side, the pack pass prepares it; A's slab
     // for this shard is allocated 16-byte aligned with leading dimension hi - lo)
     const uint64_t hi_bytes = planar_hi_plane_bytes(L);
-    if (mfma_matmul_enabled() && L.packing == CPIR_PACK_PLANAR && L.mat_elem_bit_len >= 9 && (hi - lo) % 4 == 0 && mfma_pipeline() != 0) {
+    // (rows without a non-zero field are left out of a shard's image where that pays, as in setup_from_host_matrix; such a shard multiplies
+    // its slab of A by the unpacked rows.  Finding them synchronises this device's stream: the shards' uploads no longer overlap there)
+    SlotMap map;
+    if (compact_slots_mode() != 0) {
+      st = build_slot_map(devs[g], (const uint32_t*)work[g].D_dev.p, C, hi - lo, C, b, stream, &map, &work[g].ored_rows);
+      if (st != CPIR_OK) return fail(st);
+    }
+    if (!map.active() && mfma_matmul_enabled() && L.packing == CPIR_PACK_PLANAR && L.mat_elem_bit_len >= 9 && (hi - lo) % 4 == 0 && mfma_pipeline() != 0) {
       if (hi_bytes) TRY_(CPIR_HIP_MALLOC(&work[g].hi_plane.p, (size_t)hi_bytes));  // (one bit plane: none, the matmul expands it from the image)
       TRY_(CPIR_HIP_MALLOC(&work[g].rowsum_ws.p, 4 * ((CPIR_LWE_DIMENSION + 127) / 128 * 128)));
     }
-    st = launch_transpose_compress(devs[g], (const uint32_t*)work[g].D_dev.p, C, L, child->dtc, (uint32_t*)work[g].flag.p, stream,
-                                   work[g].hi_plane.p);
+    st = pack_into_server(devs[g], child, (const uint32_t*)work[g].D_dev.p, C, L, &map, (uint32_t*)work[g].flag.p, work[g].hi_plane.p, stream);
     if (st != CPIR_OK) return fail(st);
     TRY_(hipMemcpyAsync(&work[g].ored, work[g].flag.p, 4, hipMemcpyDeviceToHost, stream));
   }
@@ -384,7 +429,7 @@ static int setup_group_from_host_matrix(const std::vector<Device*>& devs, Public
   for (size_t g = 0; g < G; g++) {
     DeviceGuard dg(devs[g]->ordinal);
     TRY_(hipStreamSynchronize(devs[g]->stream));
-    ored |= work[g].ored;
+    ored |= work[g].ored | work[g].ored_rows;
   }
   grp->setup_timings[2] = now_seconds() - t0;  // D upload + pack, all devices
   const uint32_t rhs_bits = (ored >> 16) ? 32u : 16u;  // as setup_from_host_matrix
@@ -404,7 +449,7 @@ static int setup_group_from_host_matrix(const std::vector<Device*>& devs, Public
     st = upA.finish(&A_dev, g);
     if (st != CPIR_OK) return fail(st);
     const uint64_t n = child->layout.num_slots;
-    if (work[g].rowsum_ws.p && (ored >> b) == 0 && mfma_planar_rhs_applicable(A_dev, n, child->layout))
+    if (work[g].rowsum_ws.p && !child->map.active() && (ored >> b) == 0 && mfma_planar_rhs_applicable(A_dev, n, child->layout))
       st = launch_mat_x_mat_mfma_planar(devs[g], A_dev, n, child->dtc, child->layout, work[g].hi_plane.p, (uint32_t*)work[g].rowsum_ws.p,
                                         (uint32_t*)work[g].M_dev.p, C, CPIR_LWE_DIMENSION, 0, devs[g]->stream);
     else
@@ -647,16 +692,12 @@ int cpir_server_from_device_matrix(cpir_device* dev, const uint32_t* D_dev, uint
   if (slot_offset + N_shard > total_slots) return CPIR_ERR_SHARD_RANGE;
   DeviceGuard g(dev->ordinal);
   Server* srv = server_new(dev, L, slot_offset, total_slots);
-  hipError_t e = CPIR_HIP_MALLOC(&srv->dtc, (size_t)L.total_words * 4);
-  if (e != hipSuccess) {
-    set_last_hip_error(e, "hipMalloc(dtc)", __FILE__, __LINE__);
-    server_destroy(srv);
-    return CPIR_ERR_OUT_OF_DEVICE_MEMORY;
-  }
   hipStream_t s = pick_stream(dev, stream);
-  int st = launch_transpose_compress(dev, D_dev, ldd, L, srv->dtc, nullptr, s);
+  SlotMap map;  // rows without a non-zero field are left out of the image where that pays (compact.hip)
+  int st = compact_slots_mode() != 0 ? build_slot_map(dev, D_dev, ldd, N_shard, C, b, s, &map, nullptr) : CPIR_OK;
+  if (st == CPIR_OK) st = pack_into_server(dev, srv, D_dev, ldd, L, &map, nullptr, nullptr, s);
   if (st == CPIR_OK) {
-    e = hipStreamSynchronize(s);
+    const hipError_t e = hipStreamSynchronize(s);
     if (e != hipSuccess) set_last_hip_error(e, "hipStreamSynchronize", __FILE__, __LINE__), st = CPIR_ERR_HIP;
   }
   if (st != CPIR_OK) {

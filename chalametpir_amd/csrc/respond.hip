@@ -381,6 +381,9 @@ extern "C" int cpir_tuning_set(const char* key, int value) {
     set_default_dense(value != 0);
   } else if (!strcmp(key, "layout.planar")) {
     set_default_planar(value != 0);
+  } else if (!strcmp(key, "layout.compact_slots")) {
+    if (value < 0 || value > 2) return CPIR_ERR_INVALID_ARGUMENT;
+    set_compact_slots_mode(value);
   } else if (!strcmp(key, "pack.rows")) {
     if (value < -1 || value > 1) return CPIR_ERR_INVALID_ARGUMENT;
     set_pack_rows_mode(value);
@@ -406,6 +409,7 @@ extern "C" void cpir_tuning_reset(void) {
   set_mfma_pipeline(1);
   set_mfma_ablate(0);
   set_pack_rows_mode(-1);
+  set_compact_slots_mode(1);
 }
 
 uint64_t respond_multi_pass_limit_bytes() {

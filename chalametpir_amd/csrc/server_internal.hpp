@@ -35,6 +35,7 @@ namespace cpir {
 //     copy's progress (respond_alone in host_respond.hip).  (respond.host_zero_copy=0: upload first, as concurrent callers do.)
 struct RespondArena {
   uint32_t* q_dev = nullptr;     // kSeats x total_slots u32
+  uint32_t* q_compact = nullptr; // kSeats x map.n_pad u32 (servers with a slot map only): the seats' queries gathered onto the kept slots
   uint32_t* r_dev = nullptr;     // kSeats x C u32
   uint32_t* q_pinned = nullptr;  // kSeats x total_slots u32
   uint32_t* r_pinned = nullptr;  // kSeats x C u32
@@ -55,8 +56,12 @@ struct RespondArena {
 struct Server {
   std::atomic<int> refs{1};
   Device* dev = nullptr;
-  cpir_dtc_layout layout{};
-  uint32_t* dtc = nullptr;  // device, layout.total_words u32
+  cpir_dtc_layout layout{};  // the LOGICAL database of this server / shard: num_slots = the slots of the query it answers for (what the C ABI
+                             // reports, what import / export speak, what the staging of host queries is sized by)
+  cpir_dtc_layout phys{};    // the image in `dtc`.  Equal to `layout` unless only the slots with a non-zero row are served (compact.hip):
+                             // then its num_slots is map.n_kept and queries are compacted through `map` in front of every launch
+  SlotMap map;               // active(): the kept slots of this shard, relative to slot_offset
+  uint32_t* dtc = nullptr;  // device, phys.total_words u32
   uint64_t slot_offset = 0;
   uint64_t total_slots = 0;
   double setup_timings[CPIR_SETUP_TIMING_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -82,7 +87,7 @@ struct Server {
     }
   }
   bool kernel_outweighs_uploads() const {  // K >= T * u: one arena for all recent callers
-    const double k_us = (double)layout.total_words * 4 / 6.8e6, u_us = (double)layout.num_slots * 4 / 55e3 + 15;
+    const double k_us = (double)phys.total_words * 4 / 6.8e6, u_us = (double)layout.num_slots * 4 / 55e3 + 15;
     return k_us >= peak_inside * u_us;
   }
   // how long a leader whose gate is open waits for the company spread() promises: only where one pass is to answer ALL recent callers
@@ -92,7 +97,7 @@ struct Server {
   // cost 3 callers at 2^20 keys x 1 kB a fifth of their throughput).
   double batching_window_seconds() const {
     if (!kernel_outweighs_uploads()) return 0;
-    const double w = (double)layout.total_words * 4 / 6.8e12 * 0.1;
+    const double w = (double)phys.total_words * 4 / 6.8e12 * 0.1;
     return w < 100e-6 ? w : 100e-6;
   }
   uint32_t spread() const {
@@ -121,6 +126,7 @@ struct Server {
   struct GroupLane {  // per shard, per call context
     hipStream_t stream = nullptr;
     uint32_t *q_dev = nullptr, *r_dev = nullptr, *q_pinned = nullptr, *r_pinned = nullptr;
+    uint32_t* q_compact = nullptr;  // (shards with a slot map) the slice gathered onto the kept slots; part of the q_dev block
   };
   struct GroupCtx {
     bool busy = false;
@@ -166,6 +172,13 @@ void server_destroy(Server* srv);
 // every query is its own pass; either way the passes of one kind go into ONE launch
 int respond_batched(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len, uint64_t q_slot_offset,
                     uint32_t batch, uint32_t* r, uint32_t* scratch, hipStream_t stream);
+// The same for a SERVER: `batch` queries of q_len entries on the device, this server's slots starting at q_slot_offset of each.  With a
+// slot map the queries are first gathered onto the kept slots (into qc, batch x map.n_pad words, or a stream-ordered allocation when qc
+// is NULL).  lone: batch == 1 answered as cpir_server_respond_device does (one launch, no batching logic).
+int server_respond_on_device(const Server* srv, const uint32_t* q, uint64_t q_len, uint64_t q_slot_offset, uint32_t batch, bool lone, uint32_t* r,
+                             uint32_t* scratch, uint32_t* qc, hipStream_t stream);
+// after the image is packed: adopt `map` (moved from) and the physical layout it implies
+void server_set_physical(Server* srv, const cpir_dtc_layout& phys, SlotMap* map);
 
 // host_setup.hip
 // slots per shard are multiples of this: no packed word of either layout and no 16-byte query piece straddles two shards

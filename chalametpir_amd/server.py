@@ -264,6 +264,18 @@ def tuning_set(key: str, value: int) -> None:
     _check(_native.load().cpir_tuning_set(key.encode(), int(value)))
 
 
+def host_gather(src: np.ndarray, idx: np.ndarray) -> np.ndarray:
+    """src[idx] through the library's host gather (the routine that compacts a lone host query; cpir_host_gather_words)"""
+    src, idx = np.ascontiguousarray(src, dtype=np.uint32), np.ascontiguousarray(idx, dtype=np.uint32)
+    out = np.empty(idx.size, dtype=np.uint32)
+    _check(_native.load().cpir_host_gather_words(_ptr(out), _ptr(src), _ptr(idx), idx.size))
+    return out
+
+
+def host_gather_variant() -> str:
+    return _native.load().cpir_host_gather_variant().decode()
+
+
 def tuning_reset() -> None:
     """every tuning key back to its default (cpir_tuning_reset)"""
     _native.load().cpir_tuning_reset()
@@ -305,7 +317,10 @@ class Server:
         self.device = device
         L = DtcLayout()
         _check(self._lib.cpir_server_layout(self._h, C.byref(L)))
-        self.layout = L
+        self.layout = L  # the LOGICAL database (num_slots = the query slots this server answers for)
+        P = DtcLayout()
+        _check(self._lib.cpir_server_physical_layout(self._h, C.byref(P)))
+        self.physical_layout = P  # the resident image: fewer slots when only the rows with a non-zero field are served (slots_served)
         off, tot = C.c_uint64(), C.c_uint64()
         _check(self._lib.cpir_server_shard(self._h, C.byref(off), C.byref(tot)))
         self.slot_offset, self.total_slots = off.value, tot.value
@@ -443,6 +458,22 @@ class Server:
     @property
     def response_len(self) -> int:
         return int(self.layout.num_cols)
+
+    def slots_served(self) -> Tuple[int, int]:
+        """(slots resident in the image, slots of the logical database): they differ when rows of D without a non-zero field were left
+        out (a real encoded database: the slots no key owns, reference matrix.rs:702-746); a group handle sums over its shards"""
+        a, b = C.c_uint64(), C.c_uint64()
+        _check(self._lib.cpir_server_slots_served(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def kept_slots(self) -> Optional[np.ndarray]:
+        """the slots the image holds (increasing, relative to this shard's first slot), or None when every slot is served"""
+        served, of = self.slots_served()
+        if served == of or self.group_shards():
+            return None
+        out = np.empty(served, dtype=np.uint32)
+        _check(self._lib.cpir_server_kept_slots(self._h, _ptr(out), out.size))
+        return out
 
     def group_shards(self):
         """[(device ordinal, first slot, slots)] of a group handle (Server.setup(..., devices=[...])); [] for an ordinary server"""

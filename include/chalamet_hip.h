@@ -264,7 +264,9 @@ int cpir_op_synth_fill(cpir_device* dev, uint32_t* out, uint64_t count, uint64_t
  *   "pack.rows" {-1,0,1} (the planar pack pass: 1 = a block streams whole rows of D, 0 = 64-column waves, -1 -- the default -- by width),
  *   "layout.dense" {0,1} and "layout.planar" {0,1}
  *   (default packing chosen by cpir_dtc_layout_for and therefore by every cpir_server_* constructor: planar where it is
- *   offered and enabled, else dense64 where offered and enabled, else the reference packing).
+ *   offered and enabled, else dense64 where offered and enabled, else the reference packing),
+ *   "layout.compact_slots" {0,1,2} (whether a constructor leaves the rows of D without a non-zero field out of the resident image:
+ *   0 never, 1 -- the default -- where they are at least 1/32 of the rows, 2 whenever there is one; see cpir_server_slots_served).
  * Process-wide; results are bit-identical for every setting. */
 int cpir_tuning_set(const char* key, int value);
 /* Every key back to its default (what a test harness calls between tests: the knobs are process-wide state). */
@@ -372,9 +374,28 @@ int cpir_server_setup_timings(const cpir_server* srv, double out[CPIR_SETUP_TIMI
 
 cpir_server* cpir_server_retain(cpir_server* srv);  /* #[derive(Clone)] (server.rs:15) */
 void cpir_server_release(cpir_server* srv);         /* Drop */
-int cpir_server_layout(const cpir_server* srv, cpir_dtc_layout* out);
+int cpir_server_layout(const cpir_server* srv, cpir_dtc_layout* out);  /* the LOGICAL database: num_slots = the query slots it answers for */
 int cpir_server_shard(const cpir_server* srv, uint64_t* slot_offset, uint64_t* total_slots);
-const uint32_t* cpir_server_dtc_device_ptr(const cpir_server* srv);
+const uint32_t* cpir_server_dtc_device_ptr(const cpir_server* srv);     /* the resident image: cpir_server_physical_layout describes it */
+
+/* Serving only the slots that hold something.  A real encoded database (Matrix::from_kv_database, matrix.rs:702-746) has
+ * N = num_fingerprints rows of which only n = number of keys are ever written (the slot the filter's peel order assigns to each key,
+ * matrix.rs:727-740): N - n rows -- 11 % at arity 3, 7 % at arity 4 -- are all zero and contribute 0 to every response whatever the
+ * query holds there.  Setup finds such rows on the device (after masking to b bits, what row_wise_compress keeps, matrix.rs:121) and,
+ * where they make up at least 1/32 of the database, packs only the others; every respond entry point then gathers the query onto the
+ * kept slots in front of the kernel (device queries: a 4.7 MB gather kernel; a lone host query: while it is copied into the page-locked
+ * block the kernel reads).  Responses are bit-identical by construction; export/import still speak the reference's C x ceil(N/cf) matrix.
+ * cpir_tuning_set("layout.compact_slots", 0 | 1 | 2): never / when >= 1/32 of the rows are zero (default) / whenever a row is zero.
+ *   cpir_server_physical_layout: the layout of the resident image (num_slots = kept slots; equal to cpir_server_layout without a map)
+ *   cpir_server_slots_served:    kept slots and the slots they were chosen from (a group handle: summed over its shards)
+ *   cpir_server_kept_slots:      the kept slots, increasing, relative to the shard's first slot (CPIR_ERR_INVALID_ARGUMENT without a map) */
+int cpir_server_physical_layout(const cpir_server* srv, cpir_dtc_layout* out);
+int cpir_server_slots_served(const cpir_server* srv, uint64_t* served, uint64_t* of_slots);
+int cpir_server_kept_slots(const cpir_server* srv, uint32_t* out, uint64_t cap);
+/* dst[i] = src[idx[i]] on the host, as the lone-caller path compacts a query (AVX-512 / AVX2 gathers where the CPU has them, chosen
+ * once per process; CPIR_GATHER=scalar|avx2 in the environment forces a variant): exposed for tests */
+const char* cpir_host_gather_variant(void);
+int cpir_host_gather_words(uint32_t* dst, const uint32_t* src, const uint32_t* idx, uint64_t count);
 
 /* Server::respond(&self, query: &[u8]) -> Result<Vec<u8>, _> on wire bytes (server.rs:184-190):
  * from_bytes validation (matrix.rs:973-1010) -> mat-vec -> to_bytes. response_cap >= 8 + 4*C. */

@@ -154,6 +154,11 @@ unsafe extern "C" {
     pub fn cpir_server_layout(srv: *const cpir_server, out: *mut cpir_dtc_layout) -> c_int;
     pub fn cpir_server_shard(srv: *const cpir_server, slot_offset: *mut u64, total_slots: *mut u64) -> c_int;
     pub fn cpir_server_dtc_device_ptr(srv: *const cpir_server) -> *const u32;
+    pub fn cpir_server_physical_layout(srv: *const cpir_server, out: *mut cpir_dtc_layout) -> c_int;
+    pub fn cpir_server_slots_served(srv: *const cpir_server, served: *mut u64, of_slots: *mut u64) -> c_int;
+    pub fn cpir_server_kept_slots(srv: *const cpir_server, out: *mut u32, cap: u64) -> c_int;
+    pub fn cpir_host_gather_variant() -> *const c_char;
+    pub fn cpir_host_gather_words(dst: *mut u32, src: *const u32, idx: *const u32, count: u64) -> c_int;
     pub fn cpir_server_respond_bytes(srv: *const cpir_server, query: *const u8, query_len: usize, response: *mut u8,
                                      response_cap: usize, response_len: *mut usize) -> c_int;
     pub fn cpir_server_respond(srv: *const cpir_server, q: *const u32, q_rows: u32, q_cols: u64, r_out: *mut u32) -> c_int;

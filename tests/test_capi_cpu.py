@@ -239,3 +239,16 @@ def test_the_suite_registers_only_mappings_of_its_own():
         for m in re.finditer(r"cudaHost(?:Un)?[Rr]egister\(([^,)]*)", text):
             assert m.group(1).strip() == "own.address", (name, m.group(0))
         assert "hipHostRegister(" not in text or name == "_cases.py" or "OwnMapping" in text, name
+
+
+def test_host_gather_variants_agree(native):
+    """the host routine that compacts a lone query (host_gather.cpp): whatever variant this CPU runs equals numpy's take, on ragged
+    counts around the vector widths"""
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, 1 << 32, size=100003, dtype=np.uint64).astype(np.uint32)
+    for count in (0, 1, 7, 8, 15, 16, 17, 31, 33, 1000, 65536, 90001):
+        idx = np.sort(rng.choice(src.size, size=count, replace=False)).astype(np.uint32)
+        assert np.array_equal(cp.host_gather(src, idx), src[idx]), count
+    assert cp.host_gather_variant() in ("scalar", "avx2", "avx512")
