@@ -832,7 +832,7 @@ def multirank_check(torch, dist, device, sharded, N, C, b, mask, lo, hi, rank, w
     }
 
 
-def host_path_timing(server, q_pool, N, torch):
+def host_path_timing(server, q_pool, N, torch, full=True):
     """Server::respond as the drop-in sees it (cpir_server_respond: host query in, host response out, PCIe both ways):
     latency of one caller, and throughput with 8 and 16 concurrent callers on the one handle (the reference serves an
     Arc<Server> from many tokio tasks), from pageable and from page-locked query buffers; next to it the host link itself
@@ -842,7 +842,7 @@ def host_path_timing(server, q_pool, N, torch):
     import chalametpir_amd as cp
 
     # the link: 256 MiB page-locked <-> device, HIP events on the copy stream
-    nbig = 64 << 20
+    nbig = (64 << 20) if full else (8 << 20)
     hp = torch.empty(nbig, dtype=torch.int32).pin_memory()
     dv = torch.empty(nbig, dtype=torch.int32, device="cuda")
     cs = torch.cuda.Stream()
@@ -901,6 +901,18 @@ def host_path_timing(server, q_pool, N, torch):
         return threads * per / (time.perf_counter() - t0)
 
     throughput(8, 4, False)  # warm-up (first use of every arena)
+    if not full:  # the short form (the real-database section): one caller both ways, eight callers
+        out = {
+            "one_caller_us_per_query": round(lat * 1e6, 1),
+            "one_caller_pinned_query_us_per_query": round(lat_pinned * 1e6, 1),
+            "one_caller_pinned_query_upload_first_us_per_query": round(lat_pinned_upload * 1e6, 1),
+            "eight_callers_queries_per_sec": round(throughput(8, 48, False), 1),
+            "eight_callers_pinned_queries_per_sec": round(throughput(8, 48, True), 1),
+            "host_gather": cp.host_gather_variant(),
+        }
+        for p in pins:
+            p.close()
+        return out
     out = {
         "one_caller_us_per_query": round(lat * 1e6, 1),
         "one_caller_queries_per_sec": round(1.0 / lat, 1),
@@ -1312,20 +1324,27 @@ def setup_kv_and_real_db(cp, device, torch, args, n_keys, arity, value_bytes, q_
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / (n_steps * qps_step)
         full_bytes = 4 * C * -(-N // cf) + 4 * N + 4 * C
-        resident = int(srv.layout.total_words) * 4
+        resident = int(srv.physical_layout.total_words) * 4
+        served, of = srv.slots_served()
         real = {
             "queries_per_sec": round(1e6 / us, 1),
             "us_per_query": round(us, 2),
             "rows_owned_by_no_key": N - n_keys,
             "rows_owned_by_no_key_frac": round((N - n_keys) / N, 4),
-            "slots_served": int(srv.layout.num_slots),
+            "slots_served": served,
+            "slots_of": of,
             "resident_bytes": resident,
             "frac": round(full_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
-            "frac_moved": round((resident + 4 * int(srv.layout.num_slots) + 4 * C) / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+            # (bytes moved: the compact image + the query gathered onto the kept slots -- read whole, written compact, read again -- + r)
+            "frac_moved": round((resident + 4 * N + 8 * served + 4 * C) / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
             "note": "the headline's loop (uniform random queries -- what an LWE query is to the server --, one query per pass, "
                     f"{qps_step} passes a launch) on the server that Server::setup built from the key-value database; `frac` uses the same "
                     "algorithmic bytes as the headline (the reference packing of all N slots)",
         }
+        if not args.no_host_path:
+            cp.tuning_set("respond.batch_fusion", 1)
+            real["respond_host_path"] = host_path_timing(srv, q_pool, N, torch, full=False)
+            cp.tuning_set("respond.batch_fusion", 0)
         if args.real_db_keys > 0:
             real["end_to_end"] = real_db_lookup(cp, srv, hint_bytes, filter_bytes, keys, values, n_keys, value_bytes, args.real_db_keys)
         out["real_db"] = real

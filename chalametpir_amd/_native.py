@@ -129,6 +129,7 @@ SIGNATURES = {
     "cpir_server_kept_slots": (C.c_int, [vp, u32p, C.c_uint64]),
     "cpir_host_gather_variant": (C.c_char_p, []),
     "cpir_host_gather_words": (C.c_int, [u32p, u32p, u32p, C.c_uint64]),
+    "cpir_host_compress_words": (C.c_int, [u32p, u32p, vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "cpir_server_dtc_device_ptr": (vp, [vp]),
     "cpir_server_respond_bytes": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "cpir_server_respond": (C.c_int, [vp, u32p, C.c_uint32, C.c_uint64, u32p]),

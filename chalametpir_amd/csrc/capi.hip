@@ -437,6 +437,12 @@ int cpir_host_gather_words(uint32_t* dst, const uint32_t* src, const uint32_t* i
   return CPIR_OK;
 }
 
+int cpir_host_compress_words(uint32_t* dst, const uint32_t* src, const uint8_t* bits, uint64_t s_lo, uint64_t s_hi, uint64_t* count) {
+  if (!dst || !src || !bits || !count || s_lo > s_hi) return CPIR_ERR_INVALID_ARGUMENT;
+  *count = compress_words(dst, src, bits, (size_t)s_lo, (size_t)s_hi);
+  return CPIR_OK;
+}
+
 int cpir_server_shard(const cpir_server* srv, uint64_t* slot_offset, uint64_t* total_slots) {
   if (!srv) return CPIR_ERR_INVALID_ARGUMENT;
   if (slot_offset) *slot_offset = srv->slot_offset;

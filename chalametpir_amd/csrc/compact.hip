@@ -113,6 +113,8 @@ void SlotMap::reset() {
   keep_dev = nullptr;
   keep_host.clear();
   keep_host.shrink_to_fit();
+  keep_bits.clear();
+  keep_bits.shrink_to_fit();
   n_kept = n_pad = n_orig = 0;
 }
 
@@ -167,6 +169,9 @@ int build_slot_map(const Device* dev, const uint32_t* D_dev, uint64_t ldd, uint6
     return e == hipErrorOutOfMemory ? CPIR_ERR_OUT_OF_DEVICE_MEMORY : CPIR_ERR_HIP;
   }
   map->keep_host.resize((size_t)map->n_kept);  // the host copy holds the kept slots only
+  map->keep_bits.assign((size_t)(N + 7) / 8 + 8, 0);
+  for (uint64_t n = 0; n < N; n++)
+    if (flags[n]) map->keep_bits[(size_t)(n >> 3)] |= (uint8_t)(1u << (n & 7));
   return CPIR_OK;
 }
 

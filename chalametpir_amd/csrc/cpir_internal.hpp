@@ -160,6 +160,7 @@ struct SlotMap {
   uint32_t* keep_dev = nullptr;     // device: compact index -> slot (relative to the first slot of this database / shard), increasing;
                                     // n_pad entries, the padding holds 0xFFFFFFFF
   std::vector<uint32_t> keep_host;  // the same, n_kept entries (a lone host query is compacted on the host while it is staged)
+  std::vector<uint8_t> keep_bits;   // the same as a bitmap over the n_orig slots (+ 8 bytes of padding): the streaming form of that compaction
   uint64_t n_kept = 0;              // 0: no map, every slot is served
   uint64_t n_pad = 0;               // stride and length of a compact query: n_kept rounded up to 128 words
   uint64_t n_orig = 0;              // slots the map selects from
@@ -178,6 +179,10 @@ int launch_expand_ref(const Device* dev, const uint32_t* compact_ref, uint64_t W
 // host_gather.cpp: dst[i] = src[idx[i]] on the host (AVX-512 / AVX2 gathers where the CPU has them)
 void gather_words(uint32_t* dst, const uint32_t* src, const uint32_t* idx, size_t count);
 const char* gather_words_variant();
+// the same from a bitmap of the kept slots (bit s of bits[]: slot s is kept; padded by 8 readable bytes): the words src[s], s in
+// [s_lo, s_hi), whose bit is set, in order; returns how many.  The AVX-512 form streams; without it callers use gather_words.
+bool compress_words_vectorised();
+size_t compress_words(uint32_t* dst, const uint32_t* src, const uint8_t* bits, size_t s_lo, size_t s_hi);
 
 // matmul.hip
 int launch_mat_x_mat(const Device* dev, const uint32_t* A, uint64_t lda, const uint32_t* D, uint64_t ldd, uint32_t* M,

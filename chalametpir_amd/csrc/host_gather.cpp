@@ -1,10 +1,15 @@
-// host_gather.cpp -- dst[i] = src[idx[i]] on the host: how a lone host query is compacted onto the slots a server really holds
-// (compact.hip) WHILE it is copied into the page-locked block the kernel reads in place (host_respond.hip, respond_alone).  The index
-// list is increasing and skips about one slot in nine (the rows of a binary-fuse-encoded database that no key owns), so the source is
-// read almost sequentially; what decides the speed is how the indices are turned into loads.  Three variants, picked once per process:
-//   avx512: 16 indices per vpgatherdd, one 64-byte store;   avx2: 8 per vpgatherdd;   scalar: one load per word.
-// The kernel consumes a compact query at ~25 GB/s (4.2 MB under a 170 us stream), four threads copy side by side: each has to sustain
-// ~6 GB/s, i.e. 1.5 words per nanosecond -- which the scalar loop (about one word per nanosecond) does not reach and the gathers do.
+// host_gather.cpp -- compacting a query on the host: how a lone host query is brought onto the slots a server really holds (compact.hip)
+// WHILE it is copied into the page-locked block the kernel reads in place (host_respond.hip, respond_alone).  The kept slots are
+// increasing and skip about one slot in nine (the rows of a binary-fuse-encoded database that no key owns), so the source is read almost
+// sequentially; what decides the speed is how that is put to the CPU.  The kernel consumes a compact query at ~25 GB/s (4.2 MB under a
+// 170 us stream) and four threads copy side by side: each has to sustain ~6 GB/s of output.
+//   compress_words   the kept slots as a BITMAP over the source: 16 source words per step -- one sequential 64-byte load, vpcompressd in
+//                    registers (compressing straight to memory is microcoded on Zen 4), one masked store of popcount words.  A few cycles
+//                    per 16 source words, and the loads are plain sequential ones the prefetchers follow.  AVX-512 hosts (every GPU box).
+//   gather_words     dst[i] = src[idx[i]] from an index list: 16 / 8 indices per vpgatherdd (AVX-512 / AVX2) or one load per word;
+//                    measured ~1.3 words per nanosecond and thread on the GPU box's EPYC 9575F with the source hot in cache, i.e. below what the
+//                    kernel wants: a lone query took 231 us page-locked / 315 us from a cold pageable buffer against 214 / 247 without a
+//                    slot map -- which is why the bitmap form exists.  Kept as the fallback for hosts without AVX-512.
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif
@@ -23,13 +28,18 @@ void gather_scalar(uint32_t* dst, const uint32_t* src, const uint32_t* idx, size
   for (size_t i = 0; i < count; i++) dst[i] = src[idx[i]];
 }
 
+size_t compress_scalar(uint32_t* dst, const uint32_t* src, const uint8_t* bits, size_t s_lo, size_t s_hi) {
+  uint32_t* d = dst;
+  for (size_t s = s_lo; s < s_hi; s++)
+    if ((bits[s >> 3] >> (s & 7)) & 1) *d++ = src[s];
+  return (size_t)(d - dst);
+}
+
 #if defined(__x86_64__)
 __attribute__((target("avx2"))) void gather_avx2(uint32_t* dst, const uint32_t* src, const uint32_t* idx, size_t count) {
   size_t i = 0;
   for (; i + 8 <= count; i += 8) {
     const __m256i k = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(idx + i));
-    // (indices are below 2^32 - 16 and are used as UNSIGNED offsets: the gather sign-extends 32-bit indices, so anything at or above
-    // 2^31 words goes through the scalar tail below -- a 8 GiB query, far beyond any shard)
     _mm256_storeu_si256(reinterpret_cast<__m256i*>(dst + i), _mm256_i32gather_epi32(reinterpret_cast<const int*>(src), k, 4));
   }
   for (; i < count; i++) dst[i] = src[idx[i]];
@@ -43,28 +53,59 @@ __attribute__((target("avx512f"))) void gather_avx512(uint32_t* dst, const uint3
   }
   for (; i < count; i++) dst[i] = src[idx[i]];
 }
+
+__attribute__((target("avx512f,avx512bw,popcnt"))) size_t compress_avx512(uint32_t* dst, const uint32_t* src, const uint8_t* bits, size_t s_lo,
+                                                                            size_t s_hi) {
+  uint32_t* d = dst;
+  size_t s = s_lo;
+  for (; s + 16 <= s_hi; s += 16) {
+    uint32_t w;
+    memcpy(&w, bits + (s >> 3), 4);  // bits [s, s + 16) start at bit s % 8 of these 4 bytes (the bitmap is padded by 8 bytes)
+    const __mmask16 m = (__mmask16)(w >> (s & 7));
+    const __m512i v = _mm512_maskz_compress_epi32(m, _mm512_loadu_si512(src + s));
+    const unsigned k = (unsigned)_mm_popcnt_u32(m);
+    _mm512_mask_storeu_epi32(d, (__mmask16)((1u << k) - 1u), v);  // exactly k words: the words behind belong to another thread's job
+    d += k;
+  }
+  if (s < s_hi) {  // fewer than 16 source words left: nothing at or beyond s_hi is read
+    const unsigned r = (unsigned)(s_hi - s);
+    uint32_t w;
+    memcpy(&w, bits + (s >> 3), 4);
+    const __mmask16 in = (__mmask16)((1u << r) - 1u);
+    const __mmask16 m = (__mmask16)((w >> (s & 7)) & in);
+    const __m512i v = _mm512_maskz_compress_epi32(m, _mm512_maskz_loadu_epi32(in, src + s));
+    const unsigned k = (unsigned)_mm_popcnt_u32(m);
+    _mm512_mask_storeu_epi32(d, (__mmask16)((1u << k) - 1u), v);
+    d += k;
+  }
+  return (size_t)(d - dst);
+}
 #endif
 
 using GatherFn = void (*)(uint32_t*, const uint32_t*, const uint32_t*, size_t);
+using CompressFn = size_t (*)(uint32_t*, const uint32_t*, const uint8_t*, size_t, size_t);
 
 struct Picked {
-  GatherFn fn;
-  const char* name;
+  GatherFn gather;
+  const char* gather_name;
+  CompressFn compress;  // the vector one, or NULL (the caller then gathers from the index list)
 };
 
 Picked pick() {
-  const char* force = getenv("CPIR_GATHER");  // "scalar" / "avx2" / "avx512": tests compare the variants; anything else = best available
+  const char* force = getenv("CPIR_GATHER");  // "scalar" / "avx2" / "avx512-gather": forces a lesser variant (tests, A/B timing)
 #if defined(__x86_64__)
   __builtin_cpu_init();
-  const bool has512 = __builtin_cpu_supports("avx512f"), has2 = __builtin_cpu_supports("avx2");
-  if (force && !strcmp(force, "scalar")) return {gather_scalar, "scalar"};
-  if (force && !strcmp(force, "avx2") && has2) return {gather_avx2, "avx2"};
-  if (has512) return {gather_avx512, "avx512"};
-  if (has2) return {gather_avx2, "avx2"};
+  const bool has512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("popcnt");
+  const bool has2 = __builtin_cpu_supports("avx2");
+  if (force && !strcmp(force, "scalar")) return {gather_scalar, "scalar", nullptr};
+  if (force && !strcmp(force, "avx2") && has2) return {gather_avx2, "avx2", nullptr};
+  if (force && !strcmp(force, "avx512-gather") && has512) return {gather_avx512, "avx512", nullptr};
+  if (has512) return {gather_avx512, "avx512", compress_avx512};
+  if (has2) return {gather_avx2, "avx2", nullptr};
 #else
   (void)force;
 #endif
-  return {gather_scalar, "scalar"};
+  return {gather_scalar, "scalar", nullptr};
 }
 
 const Picked& picked() {
@@ -77,9 +118,15 @@ const Picked& picked() {
 void gather_words(uint32_t* dst, const uint32_t* src, const uint32_t* idx, size_t count) {
   // the vector gathers sign-extend their 32-bit indices: keep them for index lists that stay below 2^31 (the list is increasing: look at its end)
   if (count && idx[count - 1] >= 0x80000000u) return gather_scalar(dst, src, idx, count);
-  picked().fn(dst, src, idx, count);
+  picked().gather(dst, src, idx, count);
 }
 
-const char* gather_words_variant() { return picked().name; }
+const char* gather_words_variant() { return picked().compress ? "avx512-compress" : picked().gather_name; }
+
+bool compress_words_vectorised() { return picked().compress != nullptr; }
+
+size_t compress_words(uint32_t* dst, const uint32_t* src, const uint8_t* bits, size_t s_lo, size_t s_hi) {
+  return picked().compress ? picked().compress(dst, src, bits, s_lo, s_hi) : compress_scalar(dst, src, bits, s_lo, s_hi);
+}
 
 }  // namespace cpir

@@ -18,11 +18,15 @@ class StagingHelpers {
     const void* src;
     size_t bytes;
     std::atomic<int>* done;  // set to 1 when copied
-    const uint32_t* idx = nullptr;  // NULL: dst <- src, `bytes` bytes; else dst[i] = src[idx[i]] for bytes / 4 words (a query compacted
-                                    // onto the slots the server holds, compact.hip)
+    // a query compacted onto the slots the server holds (compact.hip) instead of copied: dst[i] = src[idx[i]] for bytes / 4 words --
+    // streamed through the bitmap of the kept slots where the CPU has the instructions for it (host_gather.cpp), gathered otherwise
+    const uint32_t* idx = nullptr;
+    const uint8_t* bits = nullptr;
   };
   static void copy(const Job& j) {
-    if (j.idx) gather_words(static_cast<uint32_t*>(j.dst), static_cast<const uint32_t*>(j.src), j.idx, j.bytes / 4);
+    const size_t n = j.bytes / 4;
+    if (j.idx && j.bits && n) (void)compress_words(static_cast<uint32_t*>(j.dst), static_cast<const uint32_t*>(j.src), j.bits, j.idx[0], (size_t)j.idx[n - 1] + 1);
+    else if (j.idx) gather_words(static_cast<uint32_t*>(j.dst), static_cast<const uint32_t*>(j.src), j.idx, n);
     else memcpy(j.dst, j.src, j.bytes);
   }
   ~StagingHelpers() {
@@ -481,6 +485,7 @@ void server_set_physical(Server* srv, const cpir_dtc_layout& phys, SlotMap* map)
   if (map && map->active()) {
     srv->map.keep_dev = map->keep_dev, map->keep_dev = nullptr;
     srv->map.keep_host = std::move(map->keep_host);
+    srv->map.keep_bits = std::move(map->keep_bits);
     srv->map.n_kept = map->n_kept, srv->map.n_pad = map->n_pad, srv->map.n_orig = map->n_orig;
     map->reset();
   }
@@ -598,6 +603,7 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
     uint32_t* const qp = mapped ? a->q_pinned : a->q_pinned + q_lo;
     const uint32_t* const src = q + q_lo;
     const uint32_t* const idx = mapped ? srv->map.keep_host.data() : nullptr;
+    const uint8_t* const bits = (mapped && compress_words_vectorised()) ? srv->map.keep_bits.data() : nullptr;
     constexpr size_t kJob = (size_t)1 << 16;  // 256 KiB of u32, a multiple of the kernel's 512-slot step
     static_assert(kJob % CPIR_PLANAR_SLOTS_PER_TILE == 0, "a copy job must end on a step boundary: the kernel is told whole steps");
     constexpr size_t kStepsPerJob = kJob / CPIR_PLANAR_SLOTS_PER_TILE;
@@ -606,7 +612,7 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
     // job i: words [i * kJob, ...) of what the kernel reads
     auto job = [&](size_t i, std::atomic<int>* done) {
       const size_t o = i * kJob, n = (words - o < kJob) ? words - o : kJob;
-      return mapped ? StagingHelpers::Job{qp + o, src, n * 4, done, idx + o} : StagingHelpers::Job{qp + o, src + o, n * 4, done, nullptr};
+      return mapped ? StagingHelpers::Job{qp + o, src, n * 4, done, idx + o, bits} : StagingHelpers::Job{qp + o, src + o, n * 4, done, nullptr, nullptr};
     };
     // how long a wave waits for the words of a step (the tuning value, default 2 ms), but never less than the whole copy would take at
     // 5 GB/s -- a quarter of what ONE core copies: the last steps of a long query are legitimately waited for that long
@@ -661,8 +667,8 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
       for (size_t i = 0; i < n_jobs; i++) wait_for_job(i);  // every job must have run before the stack array goes away, whatever happened
       g_staging.release();
     } else {
-      if (mapped) gather_words(qp, src, idx, words);
-      else memcpy(qp, src, words * 4);
+      // (a short query, or the helpers are taken: this thread copies / compacts alone)
+      StagingHelpers::copy(StagingHelpers::Job{qp, src, words * 4, nullptr, idx, mapped ? bits : nullptr});
       rc = launch_respond_read_once(srv->dev, srv->dtc, L, a->q_pinned_dev, kq_len, kq_off, a->r_dev, st);
     }
   }

@@ -272,6 +272,17 @@ def host_gather(src: np.ndarray, idx: np.ndarray) -> np.ndarray:
     return out
 
 
+def host_compress(src: np.ndarray, keep_mask: np.ndarray, s_lo: int = 0, s_hi: Optional[int] = None) -> np.ndarray:
+    """src[s] for s in [s_lo, s_hi) with keep_mask[s] set, through the library's streaming compaction (cpir_host_compress_words)"""
+    src = np.ascontiguousarray(src, dtype=np.uint32)
+    s_hi = src.size if s_hi is None else s_hi
+    bits = np.concatenate([np.packbits(np.asarray(keep_mask, dtype=bool), bitorder="little"), np.zeros(8, dtype=np.uint8)])
+    out = np.empty(max(1, s_hi - s_lo), dtype=np.uint32)
+    n = C.c_uint64()
+    _check(_native.load().cpir_host_compress_words(_ptr(out), _ptr(src), bits.ctypes.data, s_lo, s_hi, C.byref(n)))
+    return out[: n.value].copy()
+
+
 def host_gather_variant() -> str:
     return _native.load().cpir_host_gather_variant().decode()
 

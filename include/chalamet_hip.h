@@ -393,9 +393,12 @@ int cpir_server_physical_layout(const cpir_server* srv, cpir_dtc_layout* out);
 int cpir_server_slots_served(const cpir_server* srv, uint64_t* served, uint64_t* of_slots);
 int cpir_server_kept_slots(const cpir_server* srv, uint32_t* out, uint64_t cap);
 /* dst[i] = src[idx[i]] on the host, as the lone-caller path compacts a query (AVX-512 / AVX2 gathers where the CPU has them, chosen
- * once per process; CPIR_GATHER=scalar|avx2 in the environment forces a variant): exposed for tests */
+ * once per process; CPIR_GATHER=scalar|avx2|avx512-gather in the environment forces a lesser variant): exposed for tests */
 const char* cpir_host_gather_variant(void);
 int cpir_host_gather_words(uint32_t* dst, const uint32_t* src, const uint32_t* idx, uint64_t count);
+/* the streaming form (AVX-512 hosts: "avx512-compress"): the words src[s], s in [s_lo, s_hi), whose bit s is set in `bits` (padded by 8
+ * readable bytes), in order; *count = how many were written */
+int cpir_host_compress_words(uint32_t* dst, const uint32_t* src, const uint8_t* bits, uint64_t s_lo, uint64_t s_hi, uint64_t* count);
 
 /* Server::respond(&self, query: &[u8]) -> Result<Vec<u8>, _> on wire bytes (server.rs:184-190):
  * from_bytes validation (matrix.rs:973-1010) -> mat-vec -> to_bytes. response_cap >= 8 + 4*C. */

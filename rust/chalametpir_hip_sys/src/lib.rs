@@ -159,6 +159,7 @@ unsafe extern "C" {
     pub fn cpir_server_kept_slots(srv: *const cpir_server, out: *mut u32, cap: u64) -> c_int;
     pub fn cpir_host_gather_variant() -> *const c_char;
     pub fn cpir_host_gather_words(dst: *mut u32, src: *const u32, idx: *const u32, count: u64) -> c_int;
+    pub fn cpir_host_compress_words(dst: *mut u32, src: *const u32, bits: *const u8, s_lo: u64, s_hi: u64, count: *mut u64) -> c_int;
     pub fn cpir_server_respond_bytes(srv: *const cpir_server, query: *const u8, query_len: usize, response: *mut u8,
                                      response_cap: usize, response_len: *mut usize) -> c_int;
     pub fn cpir_server_respond(srv: *const cpir_server, q: *const u32, q_rows: u32, q_cols: u64, r_out: *mut u32) -> c_int;

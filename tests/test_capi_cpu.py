@@ -251,4 +251,13 @@ def test_host_gather_variants_agree(native):
     for count in (0, 1, 7, 8, 15, 16, 17, 31, 33, 1000, 65536, 90001):
         idx = np.sort(rng.choice(src.size, size=count, replace=False)).astype(np.uint32)
         assert np.array_equal(cp.host_gather(src, idx), src[idx]), count
-    assert cp.host_gather_variant() in ("scalar", "avx2", "avx512")
+    assert cp.host_gather_variant() in ("scalar", "avx2", "avx512", "avx512-compress")
+    # the streaming form: a bitmap over the source, any [s_lo, s_hi) window (copy jobs start and end at arbitrary source words)
+    for n in (1, 15, 16, 17, 1000, 100003):
+        keep = rng.random(n) < 0.89
+        assert np.array_equal(cp.host_compress(src[:n], keep), src[:n][keep]), n
+        for _ in range(4):
+            lo = int(rng.integers(0, n))
+            hi = int(rng.integers(lo, n + 1))
+            assert np.array_equal(cp.host_compress(src[:n], keep, lo, hi), src[lo:hi][keep[lo:hi]]), (n, lo, hi)
+    assert cp.host_compress(src[:64], np.zeros(64, dtype=bool)).size == 0 and np.array_equal(cp.host_compress(src[:64], np.ones(64, dtype=bool)), src[:64])
