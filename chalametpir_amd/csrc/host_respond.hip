@@ -54,6 +54,14 @@ class StagingHelpers {
     }
     cv_.notify_one();
   }
+  template <class MakeJob>
+  void submit_all(size_t n, MakeJob&& make) {  // one lock, one wake-up for the lot
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      for (size_t i = 0; i < n; i++) jobs_.push_back(make(i));
+    }
+    cv_.notify_all();
+  }
   // the submitter helps: run one queued job, if any
   bool help() {
     Job j;
@@ -314,6 +322,11 @@ void server_destroy(Server* srv) {
     fprintf(stderr, "; served alone (query read in place) %llu, %.1f us each; of those %llu by one launch polling the copy, %u such launches gave up\n",
             (unsigned long long)t.solo.load(), t.solo.load() ? t.ns_solo.load() / (double)t.solo.load() / 1e3 : 0.0,
             (unsigned long long)srv->fill_polled.load(), srv->fill_aborts.load());
+    if (t.polled.load()) {
+      const double np = (double)t.polled.load();
+      fprintf(stderr, "[cpir respond trace] polled launches, us from entry: jobs with the helpers %.1f, launch call back %.1f, last job copied %.1f\n",
+              t.ns_p_submit.load() / np / 1e3, t.ns_p_launch.load() / np / 1e3, t.ns_p_copied.load() / np / 1e3);
+    }
   }
   if (!srv->shards.empty()) {
     group_ctx_destroy(srv);
@@ -604,10 +617,15 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
     const uint32_t* const src = q + q_lo;
     const uint32_t* const idx = mapped ? srv->map.keep_host.data() : nullptr;
     const uint8_t* const bits = (mapped && compress_words_vectorised()) ? srv->map.keep_bits.data() : nullptr;
-    constexpr size_t kJob = (size_t)1 << 16;  // 256 KiB of u32, a multiple of the kernel's 512-slot step
-    static_assert(kJob % CPIR_PLANAR_SLOTS_PER_TILE == 0, "a copy job must end on a step boundary: the kernel is told whole steps");
-    constexpr size_t kStepsPerJob = kJob / CPIR_PLANAR_SLOTS_PER_TILE;
-    constexpr size_t kMaxJobs = 512;
+    // copy jobs of 64 KiB (32 steps of the kernel): the grid starts on the first 256 steps at once, and those 512 KiB are in place when
+    // FOUR threads have copied two jobs each, not when two threads have copied 256 KiB each; queries too long for the job table take
+    // 256 KiB jobs.  Measured, one caller, 16 pageable buffers taken in turn (scripts/host_path_cold.py): 231 us per query against 235-244
+    // with 256 KiB jobs; more helper threads (7 instead of 3) and launching before handing out the jobs change nothing.
+    constexpr size_t kJobSmall = (size_t)1 << 14, kJobBig = (size_t)1 << 16, kMaxJobs = 512;
+    static_assert(kJobSmall % CPIR_PLANAR_SLOTS_PER_TILE == 0 && kJobBig % CPIR_PLANAR_SLOTS_PER_TILE == 0,
+                  "a copy job must end on a step boundary: the kernel is told whole steps");
+    const size_t kJob = (words + kJobSmall - 1) / kJobSmall <= kMaxJobs ? kJobSmall : kJobBig;
+    const size_t kStepsPerJob = kJob / CPIR_PLANAR_SLOTS_PER_TILE;
     const size_t n_jobs = (words + kJob - 1) / kJob;
     // job i: words [i * kJob, ...) of what the kernel reads
     auto job = [&](size_t i, std::atomic<int>* done) {
@@ -620,9 +638,11 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
     if (fill_timeout_us > 0 && words * 4 / 5000 > fill_timeout_us) fill_timeout_us = (uint32_t)(words * 4 / 5000);
     if (words >= ((size_t)1 << 19) && n_jobs <= kMaxJobs && g_staging.try_acquire()) {
       std::atomic<int> done[kMaxJobs];
-      // ONE launch, in front of the copy: the kernel takes the steps of q round-robin (front to back over the whole grid) and waits
+      // ONE launch that overlaps the copy: the kernel takes the steps of q round-robin (front to back over the whole grid) and waits
       // for each step's words to be in place, which this thread announces job by job in *fill_progress; the copy (~55 us for 4.7 MB)
-      // runs underneath the stream (~200 us).  A wave that has waited fill_timeout_us gives up and flags the launch as void: the query
+      // runs underneath the stream (~200 us).  The jobs are handed to the helpers FIRST -- their wake-up and the first kilobytes overlap
+      // the ~10 us this thread spends in the launch call -- and the count starts at 0, so the kernel cannot run ahead of them.
+      // A wave that has waited fill_timeout_us gives up and flags the launch as void: the query
       // is then answered again from the (by then complete) pinned block -- a launch that cannot start before this thread moves on
       // (synchronous launches under a debugger or a serialising profiler) costs that timeout once, and after three such launches the
       // server stops polling and launches each half of the query when it is in place.
@@ -630,17 +650,20 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
       // line whose tail belongs to job i + 1: the words the kernel reads must start on a line boundary, which every shard_unit() multiple
       // does, and a compact query does by starting at word 0)
       polled = fill_timeout_us > 0 && srv->fill_aborts.load(std::memory_order_relaxed) < 3 && (mapped || (q_lo * 4) % 128 == 0);
+      const bool ptr = srv->trace_on && polled;
+      const double tp0 = ptr ? now_seconds() : 0;
+      double tp1 = 0, tp2 = 0;
+      if (polled) publish_fill_progress(a->fill_progress, 0u);
+      for (size_t i = 0; i < n_jobs; i++) done[i].store(0, std::memory_order_relaxed);
+      g_staging.submit_all(n_jobs, [&](size_t i) { return job(i, &done[i]); });
+      if (ptr) tp1 = now_seconds();
       if (polled) {
         journal_note("respond: polled launch", a->q_pinned, words * 4, __FILE__, __LINE__);
-        publish_fill_progress(a->fill_progress, 0u);
         const PlanarHostFill fill{a->fill_progress_dev, a->r_dev + C, fill_timeout_us};
         rc = launch_respond_read_once(srv->dev, srv->dtc, L, a->q_pinned_dev, kq_len, kq_off, a->r_dev, st, 0, 0, &fill);
         if (rc != CPIR_OK) polled = false;  // nothing was launched
       }
-      for (size_t i = 0; i < n_jobs; i++) {
-        done[i].store(0, std::memory_order_relaxed);
-        g_staging.submit(job(i, &done[i]));
-      }
+      if (ptr) tp2 = now_seconds();
       auto wait_for_job = [&](size_t i) {
         while (!done[i].load(std::memory_order_acquire))
           if (!g_staging.help()) {
@@ -666,6 +689,12 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
       }
       for (size_t i = 0; i < n_jobs; i++) wait_for_job(i);  // every job must have run before the stack array goes away, whatever happened
       g_staging.release();
+      if (ptr) {
+        const double tp3 = now_seconds();
+        srv->trace.polled++;
+        srv->trace.ns_p_submit += (uint64_t)((tp1 - tp0) * 1e9), srv->trace.ns_p_launch += (uint64_t)((tp2 - tp0) * 1e9);
+        srv->trace.ns_p_copied += (uint64_t)((tp3 - tp0) * 1e9);
+      }
     } else {
       // (a short query, or the helpers are taken: this thread copies / compacts alone)
       StagingHelpers::copy(StagingHelpers::Job{qp, src, words * 4, nullptr, idx, mapped ? bits : nullptr});

@@ -538,10 +538,15 @@ respond_planar_ks_kernel(const PlanarArgs a) {
       const uint32_t tg_n = last_of_visit ? visit_tg0(v + 1) : tg + 1, ks_n = last_of_visit ? nks : ks;
       const bool build = (a.q_far ? last_of_visit : first_of_visit) && more_visits;  // block-uniform
       const bool g_n = more_visits && guarded_step(nks);
-      if (first_of_visit && more_visits) {
-        wait_for_step(nks);
-        if (!g_n) a_issue(raw, nks, pass);
-      }
+      // The next visit's query words.  q complete where it lies: requested now, a whole visit ahead of their use.  q still being FILLED by
+      // the host: the fill count is only REQUESTED now (one 64-byte read over the link, ~2 us) and looked at after this unit's MFMAs, and
+      // the words are requested then -- a wave that waited for the count here, in front of its tile prefetch, left its SIMD and its share
+      // of the HBM stream idle for those 2 us in every visit (one block per CU: nobody else to fill in): ~18 of 200 us per query.
+      const bool want_next = first_of_visit && more_visits;
+      const bool ask = want_next && my_progress && !gave_up && seen <= nks;
+      uint32_t early = 0;
+      if (ask) early = __hip_atomic_load(my_progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (want_next && !my_progress && !g_n) a_issue(raw, nks, pass);
       // ALWAYS issued (the very last unit asks for its own tile again: 9 KiB per block and pass): with a conditional prefetch the compiler
       // cannot count the loads in flight and waits for all of them, this tile's successor included, before the first MFMA
       load_tile(nxt, last ? tg : tg_n, last ? ks : ks_n);
@@ -583,6 +588,14 @@ respond_planar_ks_kernel(const PlanarArgs a) {
             atomicAdd(&racc[query * cpad + Tw * 16 + cl], val);  // LDS; this wave owns tile T of every step
           }
         }
+      }
+      if (want_next && my_progress) {
+        if (ask) {
+          seen = early;
+          if (seen <= nks) wait_for_step(nks);  // not there yet: poll as before (with the timeout that lets the grid drain)
+          else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // the words are requested after the count was seen, in program order
+        }
+        if (!g_n) a_issue(raw, nks, pass);
       }
       if (build) {
         if (!g_n) a_finish(raw, par ^ 1);

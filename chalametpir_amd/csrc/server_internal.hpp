@@ -108,6 +108,9 @@ struct Server {
   struct Trace {
     std::atomic<uint64_t> calls{0}, solo{0}, ns_solo{0}, batches{0}, ns_seat{0}, ns_stage{0}, ns_gate{0}, ns_enqueue{0}, ns_gpu{0}, ns_follow{0}, ns_out{0};
     std::atomic<uint64_t> batch_hist[9] = {};
+    // a lone caller whose query is staged under a polled launch: until the jobs are with the helpers / until the launch call is back /
+    // until the last job is published / until the response is there
+    std::atomic<uint64_t> polled{0}, ns_p_submit{0}, ns_p_launch{0}, ns_p_copied{0}, ns_p_done{0};
   } trace;
   bool trace_on = false;
   std::mutex mu;

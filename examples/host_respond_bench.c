@@ -7,7 +7,7 @@
  * latency of a lone caller (pageable / page-locked query) and throughput of T closed-loop callers, T = 1, 2, 4, 8, 16.
  * Every response is compared with the first answer to the same query (the queries repeat), so a wrong answer cannot go unnoticed.
  *
- *   build:  make -C chalametpir_amd/csrc host_respond_bench      run:  chalametpir_amd/lib/host_respond_bench [n_keys_log2=20] [value_bytes=1024] [arity=3]
+ *   build:  make -C chalametpir_amd/csrc host_respond_bench      run:  chalametpir_amd/lib/host_respond_bench [n_keys_log2=20] [value_bytes=1024] [arity=3] [lone]
  * prints one JSON object. */
 #include <pthread.h>
 #include <stdint.h>
@@ -121,7 +121,8 @@ int main(int argc, char** argv) {
     g_want[k] = (uint32_t*)malloc(4 * (size_t)g_C);
     CHECK(cpir_server_respond(g_srv, g_q[k], 1, g_N, g_want[k]));
   }
-  (void)run(8, 4, 0); /* first use of every arena */
+  const int lone_only = argc > 4 && !strcmp(argv[4], "lone"); /* 4th argument "lone": the single-caller latencies only */
+  if (!lone_only) (void)run(8, 4, 0); /* first use of every arena */
   const int lone = 200;
   /* the lone caller is the thread that allocated the buffers and built the server (memory placed where it runs) */
   double lone_pageable, lone_pinned;
@@ -139,7 +140,7 @@ int main(int argc, char** argv) {
          "\"one_caller_us_per_query\": %.1f, \"one_caller_pinned_query_us_per_query\": %.1f",
          lg, (unsigned long long)value_bytes, arity, (unsigned long long)g_N, g_C, b, (unsigned long long)(4 * g_N), lone_pageable, lone_pinned);
   const int threads[] = {2, 4, 8, 16};
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < 4 && !lone_only; i++) {
     const int T = threads[i], calls = 640 / T;
     const double qp = run(T, calls, 0), qn = run(T, calls, 1);
     printf(", \"callers_%d_queries_per_sec\": %.0f, \"callers_%d_pinned_queries_per_sec\": %.0f", T, qp, T, qn);
