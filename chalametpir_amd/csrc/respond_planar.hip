@@ -59,6 +59,7 @@ struct PlanarArgs {
   uint32_t q_scalar;       // q not 16-byte loadable -> guarded scalar loads everywhere
   uint32_t interleave;     // order of the passes of one launch (see the kernel)
   uint32_t q_far;          // step-major kernel: q sits behind the host link -> a whole step of units between requesting and using it
+  uint32_t two_halves;     // step-major kernel, several passes: racc holds two halves and a pass's responses are trickled out during the next pass
   const uint32_t* colsum;  // step-major kernel: per-column field sums behind the tiles (NULL: this launch does not cover step 0)
   // step-major kernel, q read in place from host memory that is still being FILLED while the kernel runs (a lone pageable host query):
   uint32_t strided;          // blocks take whole steps round-robin (step s -> block s % blocks), so the grid consumes q front to back
@@ -367,7 +368,7 @@ respond_planar_ks_kernel(const PlanarArgs a) {
   const uint32_t sel01 = limb | ((4 + limb) << 8);
   const uint4* const tiles = reinterpret_cast<const uint4*>(a.dtc);
 
-  auto guarded_step = [&](uint32_t ks_) {
+  auto guarded_step = [&](uint32_t ks_) __attribute__((always_inline)) {
     const uint64_t slot0 = (uint64_t)ks_ * CPIR_PLANAR_SLOTS_PER_TILE;
     return a.q_scalar || slot0 + CPIR_PLANAR_SLOTS_PER_TILE > a.num_slots || a.q_slot_offset + slot0 + CPIR_PLANAR_SLOTS_PER_TILE > a.q_len;
   };
@@ -381,7 +382,7 @@ respond_planar_ks_kernel(const PlanarArgs a) {
   bool gave_up = false;
   uint32_t seen = 0;
   const uint32_t* const my_progress = a.progress ? a.progress + (blockIdx.x % CPIR_FILL_LINES) * 16 : nullptr;
-  auto wait_for_step = [&](uint32_t ks_) {
+  auto wait_for_step = [&](uint32_t ks_) __attribute__((always_inline)) {
     if (!my_progress || gave_up || seen > ks_) return;
     const uint64_t t0 = wall_clock64();
     // RELAXED system-scope loads (they bypass the caches by themselves): an acquire would invalidate the L2 under the whole grid's feet
@@ -400,7 +401,7 @@ respond_planar_ks_kernel(const PlanarArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
   const uint32_t half = lane >> 5, l32 = lane & 31;
-  auto a_issue = [&](uint4(&raw)[2 * NS], uint32_t ks_, uint32_t pass_) {
+  auto a_issue = [&](uint4(&raw)[2 * NS], uint32_t ks_, uint32_t pass_) __attribute__((always_inline)) {
     const uint64_t base = (uint64_t)ks_ * CPIR_PLANAR_SLOTS_PER_TILE + wave * 128 + l32 * 4;
 #pragma unroll
     for (int i = 0; i < 2 * NS; i++) {
@@ -411,7 +412,7 @@ respond_planar_ks_kernel(const PlanarArgs a) {
   };
   // this wave's sum of the query words of a step, per query: the four lanes that share a query word (one per byte limb) count it once
   // (limb 0), the four 16-slot groups are added up with two shuffles, lane (group 0, limb 0) of every query writes
-  auto store_ksum = [&](const uint32_t(&part)[NS], int par) {
+  auto store_ksum = [&](const uint32_t(&part)[NS], int par) __attribute__((always_inline)) {
 #pragma unroll
     for (int s = 0; s < NS; s++) {
       uint32_t v = part[s];
@@ -430,7 +431,7 @@ respond_planar_ks_kernel(const PlanarArgs a) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
-  auto a_finish = [&](const uint4(&raw)[2 * NS], int par) {
+  auto a_finish = [&](const uint4(&raw)[2 * NS], int par) __attribute__((always_inline)) {
     uint32_t part[NS];
 #pragma unroll
     for (int s = 0; s < NS; s++) {
@@ -460,7 +461,7 @@ respond_planar_ks_kernel(const PlanarArgs a) {
     }
     store_ksum(part, par);
   };
-  auto a_guarded = [&](uint32_t ks_, uint32_t pass_, int par) {
+  auto a_guarded = [&](uint32_t ks_, uint32_t pass_, int par) __attribute__((always_inline)) {
     const uint64_t slot0 = (uint64_t)ks_ * CPIR_PLANAR_SLOTS_PER_TILE;
     uint32_t part[NS];
     for (int s = 0; s < NS; s++) {
@@ -488,7 +489,7 @@ respond_planar_ks_kernel(const PlanarArgs a) {
     }
     store_ksum(part, par);
   };
-  auto load_tile = [&](uint4(&dst)[NL], uint32_t tg_, uint32_t ks_) {
+  auto load_tile = [&](uint4(&dst)[NL], uint32_t tg_, uint32_t ks_) __attribute__((always_inline)) {
     const uint32_t T = (a.tg_lo + tg_) * kM + wave;
     const uint4* p = tiles + (T < a.col_tiles ? ((uint64_t)T * a.ks_total + ks_) * ST16 : 0) + lane;
 #pragma unroll
@@ -497,136 +498,179 @@ respond_planar_ks_kernel(const PlanarArgs a) {
   // valid slots of a step: inside the shard and inside the query
   const uint64_t room = a.q_len > a.q_slot_offset ? a.q_len - a.q_slot_offset : 0;
   const uint64_t nvalid_total = a.num_slots < room ? a.num_slots : room;
-  auto valid_slots = [&](uint32_t ks_) -> uint32_t {
+  auto valid_slots = [&](uint32_t ks_) __attribute__((always_inline)) -> uint32_t {
     const uint64_t lo = (uint64_t)ks_ * CPIR_PLANAR_SLOTS_PER_TILE;
     if (lo >= nvalid_total) return 0u;
     const uint64_t left = nvalid_total - lo;
     return left < CPIR_PLANAR_SLOTS_PER_TILE ? (uint32_t)left : CPIR_PLANAR_SLOTS_PER_TILE;
   };
 
-  for (uint32_t pass = 0; pass < a.passes; pass++) {
-    for (uint32_t i = threadIdx.x; i < nq * cpad; i += kThreads) racc[i] = 0;
-    // prologue of the pass: A fragments of the first visit's step, the first tile
-    uint32_t v = 0;
-    uint32_t cks = visit_ks(0), ctg1 = visit_tg1(0);  // the current visit
-    uint32_t tg = visit_tg0(0);
-    uint4 b0[NL], b1[NL];
-    load_tile(b0, tg, cks);
-    wait_for_step(cks);
-    if (guarded_step(cks)) {
-      a_guarded(cks, pass, 0);
-    } else {
-      uint4 raw0[2 * NS];
-      a_issue(raw0, cks, pass);
-      a_finish(raw0, 0);
+  // ---- the passes of the launch as ONE pipeline --------------------------------------------------------------------------------------
+  // A pass ends where the next begins: the last unit of a pass prefetches the next pass's first tile (the same tile -- every pass walks the
+  // same visits) and its last visit builds the next pass's first fragments, exactly as for the next visit inside a pass.  The pass's
+  // responses do not leave at its end either: racc has TWO halves when there are several passes; at a pass boundary the halves swap and the
+  // finished one is trickled out during the next pass, a few atomics per thread and unit, each thread zeroing the words it has sent so that
+  // the half is clean when its turn comes again.  Only the last pass flushes at the end.  (Measured at 2^20 keys, 8 queries per pass:
+  // flushing 512 blocks x 7 680 words at every pass end cost ~12 of 211 us per pass -- the burst alone takes 10-20 us,
+  // scripts/probes/atomic_flush_probe.hip -- and the drained pipeline + prologue of every pass a few more.)
+  const uint32_t rtotal = nq * cpad;
+  const bool two_halves = a.two_halves != 0;
+  uint32_t cur_off = 0, old_off = rtotal;  // the half being accumulated into / the half being trickled out (only touched when two_halves)
+  for (uint32_t i = threadIdx.x; i < rtotal * (two_halves ? 2u : 1u); i += kThreads) racc[i] = 0;
+  uint32_t pass = 0;
+  // the pending half: pass it belongs to, and this thread's next word of it (words threadIdx.x, + 256, ...); every block starts its
+  // round at an offset of its own so that the blocks are spread over the words
+  const uint32_t fstart = (uint32_t)(((uint64_t)blockIdx.x * rtotal) / gridDim.x) & ~63u;
+  uint32_t pend_pass = 0, pend_i = rtotal;  // nothing pending
+  // (half_off: 0 or rtotal -- an offset, not a pointer: racc stays an LDS address for the compiler)
+  auto flush_some = [&](uint32_t half_off, uint32_t of_pass, uint32_t& cursor, uint32_t count, bool zero) __attribute__((always_inline)) {
+    for (uint32_t k = 0; k < count && cursor < rtotal; k++, cursor += kThreads) {
+      uint32_t i2 = cursor + fstart;
+      if (i2 >= rtotal) i2 -= rtotal;
+      const uint32_t query = i2 / cpad, col = a.tg_lo * (kM * 16) + i2 % cpad, val = racc[half_off + i2];
+      if (zero) racc[half_off + i2] = 0;
+      if (col < a.num_cols && val) atomicAdd(a.r + ((uint64_t)of_pass * nq + query) * a.num_cols + col, val);
     }
-    __syncthreads();
+  };
 
-    int par = 0;
-    // The NEXT visit's query words are requested in the first unit of the current visit; they are turned into fragments in the same
-    // unit when q is near (L2), in the visit's last unit when q is far (host memory: a whole visit's worth of units, tens of
-    // microseconds, covers the latency of the link).
-    bool first_of_visit = true;
-    bool done = false;
-    uint4 raw[2 * NS];
-    auto unit = [&](uint4(&cur)[NL], uint4(&nxt)[NL]) __attribute__((always_inline)) {
-      const uint32_t ks = cks;
-      const bool last_of_visit = tg + 1 == ctg1;
-      const bool more_visits = v + 1 < n_visits;
-      const uint32_t nks = visit_ks(v + 1);  // the next visit (unused values when there is none)
-      const bool last = last_of_visit && !more_visits;
-      const uint32_t tg_n = last_of_visit ? visit_tg0(v + 1) : tg + 1, ks_n = last_of_visit ? nks : ks;
-      const bool build = (a.q_far ? last_of_visit : first_of_visit) && more_visits;  // block-uniform
-      const bool g_n = more_visits && guarded_step(nks);
-      // The next visit's query words.  q complete where it lies: requested now, a whole visit ahead of their use.  q still being FILLED by
-      // the host: the fill count is only REQUESTED now (one 64-byte read over the link, ~2 us) and looked at after this unit's MFMAs, and
-      // the words are requested then -- a wave that waited for the count here, in front of its tile prefetch, left its SIMD and its share
-      // of the HBM stream idle for those 2 us in every visit (one block per CU: nobody else to fill in): ~18 of 200 us per query.
-      const bool want_next = first_of_visit && more_visits;
-      const bool ask = want_next && my_progress && !gave_up && seen <= nks;
-      uint32_t early = 0;
-      if (ask) early = __hip_atomic_load(my_progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      if (want_next && !my_progress && !g_n) a_issue(raw, nks, pass);
-      // ALWAYS issued (the very last unit asks for its own tile again: 9 KiB per block and pass): with a conditional prefetch the compiler
-      // cannot count the loads in flight and waits for all of them, this tile's successor included, before the first MFMA
-      load_tile(nxt, last ? tg : tg_n, last ? ks : ks_n);
-      v4i acc_lo[NS], acc_hi[NS];
+  // prologue: A fragments of the first visit's step of pass 0, the first tile
+  uint32_t v = 0;
+  uint32_t cks = visit_ks(0), ctg1 = visit_tg1(0);  // the current visit
+  uint32_t tg = visit_tg0(0);
+  uint4 b0[NL], b1[NL];
+  load_tile(b0, tg, cks);
+  wait_for_step(cks);
+  if (guarded_step(cks)) {
+    a_guarded(cks, 0, 0);
+  } else {
+    uint4 raw0[2 * NS];
+    a_issue(raw0, cks, 0);
+    a_finish(raw0, 0);
+  }
+  __syncthreads();
+
+  int par = 0;
+  // The NEXT visit's query words are requested in the first unit of the current visit; they are turned into fragments in the same
+  // unit when q is near (L2), in the visit's last unit when q is far (host memory: a whole visit's worth of units, tens of
+  // microseconds, covers the latency of the link).
+  bool first_of_visit = true;
+  bool done = false;
+  uint4 raw[2 * NS];
+  auto unit = [&](uint4(&cur)[NL], uint4(&nxt)[NL]) __attribute__((always_inline)) {
+    const uint32_t ks = cks;
+    const bool last_of_visit = tg + 1 == ctg1;
+    const bool pass_ends = v + 1 == n_visits;             // this visit is the pass's last
+    const bool more_visits = !pass_ends || pass + 1 < a.passes;  // something follows: the next visit, or visit 0 of the next pass
+    const uint32_t nv = pass_ends ? 0u : v + 1, npass = pass_ends ? pass + 1 : pass;
+    const uint32_t nks = visit_ks(nv);  // (unused values when nothing follows)
+    const bool last = last_of_visit && !more_visits;
+    const uint32_t tg_n = last_of_visit ? visit_tg0(nv) : tg + 1, ks_n = last_of_visit ? nks : ks;
+    const bool build = (a.q_far ? last_of_visit : first_of_visit) && more_visits;  // block-uniform
+    const bool g_n = more_visits && guarded_step(nks);
+    // The next visit's query words.  q complete where it lies: requested now, a whole visit ahead of their use.  q still being FILLED by
+    // the host: the fill count is only REQUESTED now (one 64-byte read over the link, ~2 us) and looked at after this unit's MFMAs, and
+    // the words are requested then -- a wave that waited for the count here, in front of its tile prefetch, left its SIMD and its share
+    // of the HBM stream idle for those 2 us in every visit (one block per CU: nobody else to fill in): ~18 of 200 us per query.
+    const bool want_next = first_of_visit && more_visits;
+    const bool ask = want_next && my_progress && !gave_up && seen <= nks;
+    uint32_t early = 0;
+    if (ask) early = __hip_atomic_load(my_progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (want_next && !my_progress && !g_n) a_issue(raw, nks, npass);
+    // ALWAYS issued (the very last unit asks for its own tile again: 9 KiB per block and launch): with a conditional prefetch the compiler
+    // cannot count the loads in flight and waits for all of them, this tile's successor included, before the first MFMA
+    load_tile(nxt, last ? tg : tg_n, last ? ks : ks_n);
+    v4i acc_lo[NS], acc_hi[NS];
 #pragma unroll
-      for (int s = 0; s < NS; s++) acc_lo[s] = v4i{0, 0, 0, 0}, acc_hi[s] = v4i{0, 0, 0, 0};
-      const uint32_t Tw = tg * kM + wave;          // tile of the window (indexes the LDS accumulators)
-      const uint32_t T = a.tg_lo * kM + Tw;        // tile of the image
-      if (T < a.col_tiles) {
+    for (int s = 0; s < NS; s++) acc_lo[s] = v4i{0, 0, 0, 0}, acc_hi[s] = v4i{0, 0, 0, 0};
+    const uint32_t Tw = tg * kM + wave;          // tile of the window (indexes the LDS accumulators)
+    const uint32_t T = a.tg_lo * kM + Tw;        // tile of the image
+    if (T < a.col_tiles) {
 #pragma unroll
-        for (int kb = 0; kb < 8; kb++) {
-          v4i hb;
+      for (int kb = 0; kb < 8; kb++) {
+        v4i hb;
 #pragma unroll
-          for (int d = 0; d < 4; d++) {
-            uint32_t x = 0;
+        for (int d = 0; d < 4; d++) {
+          uint32_t x = 0;
 #pragma unroll
-            for (int p = 0; p < HB; p++) x += ((comp(cur[8 + p], kb >> 1) >> (4 * (kb & 1) + d)) & 0x01010101u) << p;
-            hb[d] = (int)x;
-          }
-#pragma unroll
-          for (int s = 0; s < NS; s++) {
-            const uint4 au = abuf[par][s][kb][lane];
-            const v4i af = as_v4i(au);
-            acc_lo[s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, as_v4i(cur[kb]), acc_lo[s], 0, 0, 0);
-            if constexpr (HB > 0) acc_hi[s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, hb, acc_hi[s], 0, 0, 0);
-          }
+          for (int p = 0; p < HB; p++) x += ((comp(cur[8 + p], kb >> 1) >> (4 * (kb & 1) + d)) & 0x01010101u) << p;
+          hb[d] = (int)x;
         }
-        const uint32_t nvs = valid_slots(ks);
-        const uint32_t col_term = (ks == 0 && a.colsum) ? 0x80808080u * a.colsum[T * 16 + cl] : 0u;
 #pragma unroll
         for (int s = 0; s < NS; s++) {
-          uint32_t val = 0;
+          const uint4 au = abuf[par][s][kb][lane];
+          const v4i af = as_v4i(au);
+          acc_lo[s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, as_v4i(cur[kb]), acc_lo[s], 0, 0, 0);
+          if constexpr (HB > 0) acc_hi[s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, hb, acc_hi[s], 0, 0, 0);
+        }
+      }
+      const uint32_t nvs = valid_slots(ks);
+      const uint32_t col_term = (ks == 0 && a.colsum) ? 0x80808080u * a.colsum[T * 16 + cl] : 0u;
 #pragma unroll
-          for (int i = 0; i < 4; i++) val += ((uint32_t)acc_lo[s][i] + ((uint32_t)acc_hi[s][i] << 8)) << (8 * i);
-          const uint32_t query = 4 * s + grp;
-          if (query < nq) {
-            const uint32_t qsum = (ksum[par][0][query] + ksum[par][1][query]) + (ksum[par][2][query] + ksum[par][3][query]);
-            val += 128u * qsum - 0x40404000u * nvs + col_term;  // 128 * 0x80808080 = 0x40404000 mod 2^32
-            atomicAdd(&racc[query * cpad + Tw * 16 + cl], val);  // LDS; this wave owns tile T of every step
+      for (int s = 0; s < NS; s++) {
+        uint32_t val = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) val += ((uint32_t)acc_lo[s][i] + ((uint32_t)acc_hi[s][i] << 8)) << (8 * i);
+        const uint32_t query = 4 * s + grp;
+        if (query < nq) {
+          const uint32_t qsum = (ksum[par][0][query] + ksum[par][1][query]) + (ksum[par][2][query] + ksum[par][3][query]);
+          val += 128u * qsum - 0x40404000u * nvs + col_term;  // 128 * 0x80808080 = 0x40404000 mod 2^32
+          atomicAdd(&racc[cur_off + query * cpad + Tw * 16 + cl], val);  // LDS; this wave owns tile T of every step
+        }
+      }
+    }
+    // a little of the previous pass's responses (its half is read-only now; each thread sends and zeroes words of its own)
+    if (two_halves) flush_some(old_off, pend_pass, pend_i, 2, true);
+    if (want_next && my_progress) {
+      if (ask) {
+        seen = early;
+        if (seen <= nks) wait_for_step(nks);  // not there yet: poll as before (with the timeout that lets the grid drain)
+        else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // the words are requested after the count was seen, in program order
+      }
+      if (!g_n) a_issue(raw, nks, npass);
+    }
+    if (build) {
+      if (!g_n) a_finish(raw, par ^ 1);
+      else a_guarded(nks, npass, par ^ 1);
+    }
+    first_of_visit = false;
+    if (last_of_visit) {
+      if (more_visits) {
+        // a pass boundary: what is still pending of the half before last must be out (and zeroed) before the halves swap
+        if (pass_ends && two_halves) flush_some(old_off, pend_pass, pend_i, 0xffffffffu, true);
+        __syncthreads();  // everybody is done with this step's fragments (and, at a pass boundary, with this pass's half); the next step's are complete
+        par ^= 1;
+        first_of_visit = true;
+        if (pass_ends) {
+          if (two_halves) {
+            const uint32_t t = cur_off;
+            cur_off = old_off, old_off = t;
+            pend_pass = pass, pend_i = threadIdx.x;
+          } else {  // one half: the pass's responses leave now (the next pass's first tile and fragments are on their way meanwhile)
+            uint32_t cursor = threadIdx.x;
+            flush_some(cur_off, pass, cursor, 0xffffffffu, true);
+            __syncthreads();  // clean before anybody accumulates for the next pass
           }
+          pass = npass;
         }
+        v = nv, cks = nks, ctg1 = visit_tg1(v);
+      } else {
+        done = true;
       }
-      if (want_next && my_progress) {
-        if (ask) {
-          seen = early;
-          if (seen <= nks) wait_for_step(nks);  // not there yet: poll as before (with the timeout that lets the grid drain)
-          else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // the words are requested after the count was seen, in program order
-        }
-        if (!g_n) a_issue(raw, nks, pass);
-      }
-      if (build) {
-        if (!g_n) a_finish(raw, par ^ 1);
-        else a_guarded(nks, pass, par ^ 1);
-      }
-      first_of_visit = false;
-      if (last_of_visit) {
-        if (more_visits) {
-          __syncthreads();  // everybody is done with this step's fragments; the next step's are complete
-          par ^= 1;
-          first_of_visit = true;
-          v++, cks = nks, ctg1 = visit_tg1(v);
-        } else {
-          done = true;
-        }
-      }
-      tg = tg_n;
-    };
-    while (!done) {
-      unit(b0, b1);
-      if (done) break;
-      unit(b1, b0);
     }
+    tg = tg_n;
+  };
+  while (!done) {
+    unit(b0, b1);
+    if (done) break;
+    unit(b1, b0);
+  }
 
-    // ---- this block's part of the pass's responses ----
-    __syncthreads();
-    for (uint32_t i2 = threadIdx.x; i2 < nq * cpad; i2 += kThreads) {
-      const uint32_t query = i2 / cpad, col = a.tg_lo * (kM * 16) + i2 % cpad, v = racc[i2];
-      if (col < a.num_cols && v) atomicAdd(a.r + ((uint64_t)pass * nq + query) * a.num_cols + col, v);
-    }
-    __syncthreads();
+  // ---- what is left: the rest of the pass before last, and the last pass ----
+  if (two_halves) flush_some(old_off, pend_pass, pend_i, 0xffffffffu, false);
+  __syncthreads();
+  {
+    uint32_t cursor = threadIdx.x;
+    flush_some(cur_off, pass, cursor, 0xffffffffu, false);
   }
 }
 
@@ -767,8 +811,19 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
   // (a query read in place over the host link must be read ONCE: one window or nothing)
   KernelFn fn_ks = (want_ks && !inter && (windows == 1 || ks_mode != 3)) ? pick_ks(hb, batch, nt) : nullptr;
   if (ks_mode == 3 && !fn_ks) return CPIR_ERR_INVALID_ARGUMENT;  // the caller relies on q being read once
-  int bpc = blocks_per_cu > 0 ? blocks_per_cu : (fn_ks ? (batch <= 4 ? 1 : 2) : (inter ? 3 : 2));
+  // (several passes in one step-major launch: the responses of a pass leave during the NEXT pass, from the second half of a
+  // double-sized LDS accumulator -- up to 2 x 48 KiB beside the A fragments, so one block per CU; measured at 2^20 keys, 8 queries per
+  // pass, one block per CU streams as fast as two: 26.5-26.9 against 26.0-26.8 us per query before the halves existed)
+  // Measured: NO gain -- 27.0 us per query against 26.4 with one half and a flush at every pass boundary (flushing costs ~1.5 us per query:
+  // 24.3-25.4 without it).  The trickled atomics sit in the wave's vector-memory queue between the tile prefetch and its wait, and the
+  // wait, counted in issue order, then covers them too; a separate flusher wave would not have that problem.  Kept behind the
+  // (undocumented, diagnosis) environment switch CPIR_RESPOND_TWO_HALVES=1.
+  static const bool want_two_halves = getenv("CPIR_RESPOND_TWO_HALVES") != nullptr;
+  const bool two_halves = want_two_halves && fn_ks && passes > 1;
+  int bpc = blocks_per_cu > 0 ? blocks_per_cu : (fn_ks ? ((batch <= 4 || two_halves) ? 1 : 2) : (inter ? 3 : 2));
   if (batch > 4 && bpc > 2) bpc = 2;
+  if (two_halves && batch > 4) bpc = 1;
+  a.two_halves = two_halves ? 1u : 0u;
   // grid of a launch over `tgs` tile groups
   auto grid_for_units = [&](uint32_t tgs, uint32_t* nx_out) {
     const uint64_t units = (uint64_t)tgs * (a.ks_hi - a.ks_lo);
@@ -795,7 +850,7 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
       if (a.tg_lo >= a.tile_groups) break;
       a.tg_n = a.tile_groups - a.tg_lo < tg_per_window ? a.tile_groups - a.tg_lo : tg_per_window;
       const uint64_t grid = grid_for_units(a.tg_n, &a.nx);
-      const size_t racc_bytes = (size_t)batch * a.tg_n * (kM * 16) * sizeof(uint32_t);
+      const size_t racc_bytes = (size_t)batch * a.tg_n * (kM * 16) * sizeof(uint32_t) * (two_halves ? 2 : 1);
       hipLaunchKernelGGL(fn_ks, dim3((unsigned)grid), dim3(kThreads), racc_bytes, stream, a);
     }
     CPIR_HIP_TRY(hipGetLastError());
