@@ -688,6 +688,20 @@ def live_traffic(args, passes_per_launch: int):
     }
 
 
+def mix_ceiling(read_bytes: int):
+    """what a plain mixed stream (7 reads : 2 writes, everything coalesced) moves on this device right now: the yardstick of the pack pass"""
+    import subprocess
+
+    tool = os.path.join(ROOT, "chalametpir_amd", "lib", "hbm_read_ceiling")
+    if not os.path.exists(tool):
+        return None
+    try:
+        p = subprocess.run([tool, "--mix", str(int(read_bytes))], capture_output=True, text=True, timeout=90)
+        return json.loads(p.stdout.strip().splitlines()[-1]) if p.returncode == 0 else None
+    except Exception:  # noqa: BLE001 -- an optional extra must never take the headline down
+        return None
+
+
 def read_ceiling(nbytes: int):
     """what a bare read-only kernel gets from this device's HBM right now (chalametpir_amd/lib/hbm_read_ceiling, a child process)"""
     import subprocess
@@ -1002,7 +1016,29 @@ def group_host_path_timing(cp, torch, device0, single, q_pool, N, C, b, mask, sh
     [t.start() for t in ts]
     [t.join() for t in ts]
     thr = threads * per / (time.perf_counter() - t0)
+    # the same handle asked on DEVICE pointers: the shards pull their slots of the queries from the root device over the peer link and push
+    # their partial responses into its table, a kernel there adds them up (no host, no collective library)
+    nb = min(16, q_pool.shape[0])
+    rdev = torch.empty((nb, C), dtype=torch.int32, device="cuda")
+    cp.tuning_set("respond.batch_fusion", 0)
+    for _ in range(2):
+        grp.respond_batch_device(q_pool[:nb], nb, rdev, stream=stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(8):
+        grp.respond_batch_device(q_pool[:nb], nb, rdev, stream=stream)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    dev_us = e0.elapsed_time(e1) * 1e3 / (8 * nb)
+    rsingle = torch.empty((nb, C), dtype=torch.int32, device="cuda")
+    single.respond_batch_device(q_pool[:nb], nb, rsingle, stream=stream)
+    torch.cuda.synchronize()
+    dev_same = bool(torch.equal(rdev, rsingle))
+    cp.tuning_set("respond.batch_fusion", 1)
     out = {
+        "device_queries_us_per_query": round(dev_us, 2),
+        "device_queries_equal_single_device": dev_same,
         "shards": grp.group_shards(),
         "visible_devices": n_vis,
         "one_caller_us_per_query": round(lat * 1e6, 1),
@@ -1012,7 +1048,9 @@ def group_host_path_timing(cp, torch, device0, single, q_pool, N, C, b, mask, sh
         "hint_checksum": int(hint.sum(dtype=np.uint64) & 0xFFFFFFFFFFFFFFFF),
         "responses_equal_single_device": same,
         "note": "cpir_server_setup_multi + cpir_server_respond: one process, database split along the filter slots over the listed "
-                "devices, query slices scattered over each device's own host link, C-word partial responses summed on the host",
+                "devices, query slices scattered over each device's own host link, C-word partial responses summed on the host; "
+                "device_queries_*: cpir_server_respond_batch_device on the same handle (16 queries, one pass each): peer copies of the "
+                "query slices, per-shard responds, partials pushed to the root and summed there by a kernel, all stream-ordered",
     }
     grp.close()
     return out
@@ -1196,7 +1234,7 @@ def setup_kernel_roofline(cp, device, torch, N, C, b, cf, mask, layout, stream):
             "hbm_frac": round(b_setup / (mm_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
         },
         "transpose_compress": {
-            "kernel": "planar_pack_stream_kernel" if layout.packing == 2 else "transpose_compress_kernel",
+            "kernel": cp.pack_kernel_name(layout),  # as the kernel trace shows it
             "ms": round(pk_ms, 3),
             "bound": "hbm",
             "algorithmic_bytes": b_pack_alg,
@@ -1225,6 +1263,14 @@ def setup_kernel_roofline(cp, device, torch, N, C, b, cf, mask, layout, stream):
         out["transpose_compress"]["without_plane_ms"] = round(pack_alone_ms, 3)
     del A, D, M, dtc
     torch.cuda.empty_cache()
+    # the pack pass moves a 3.55 : 1 mix of reads and writes; what a plain copy-like kernel of that mix reaches on THIS device, measured now
+    # (a child process, after the buffers above are gone), is its ceiling -- 8 TB/s is the data sheet's read+write peak, which no kernel sees
+    mix = mix_ceiling(min(4 * N * C, 16 << 30))
+    if mix:
+        tc = out["transpose_compress"]
+        tc["copy_ceiling_GBps"] = mix["mix_ceiling_GBps"]
+        tc["frac_vs_copy_ceiling"] = round(tc["moved_GBps"] / mix["mix_ceiling_GBps"], 4)
+        tc["copy_ceiling_note"] = mix["kernel"]
     return out
 
 

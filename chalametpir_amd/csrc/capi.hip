@@ -339,6 +339,7 @@ int cpir_op_synth_fill(cpir_device* dev, uint32_t* out, uint64_t count, uint64_t
 }
 
 const char* cpir_respond_kernel_name(const cpir_dtc_layout* layout) { return layout ? respond_kernel_name(*layout) : ""; }
+const char* cpir_pack_kernel_name(const cpir_dtc_layout* layout) { return layout ? pack_kernel_name(*layout) : ""; }
 
 
 int cpir_server_export_compressed(const cpir_server* srv, uint32_t* compressed_out, uint64_t out_words) {

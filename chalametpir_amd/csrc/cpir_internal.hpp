@@ -150,6 +150,7 @@ int launch_transpose_compress(const Device* dev, const uint32_t* D, uint64_t ldd
 // 0x80 of every field as 1 KiB MFMA operand pieces [column tile of 16][k-block of 64 slots] -- with the low-byte pieces of the image
 // itself the right-hand side of the hint matmul, so that Server::setup reads D once (launch_mat_x_mat_mfma_planar)
 uint64_t planar_hi_plane_bytes(const cpir_dtc_layout& L);
+const char* pack_kernel_name(const cpir_dtc_layout& L);
 int pack_rows_mode();
 void set_pack_rows_mode(int m);
 int launch_dtc_import(const Device* dev, const uint32_t* compressed, const cpir_dtc_layout& L, uint32_t* dtc, hipStream_t stream);

@@ -286,7 +286,27 @@ static int arena_create(Server* srv, RespondArena& a) {
 }
 
 
+static void group_dev_destroy(Server* srv) {
+  for (Server::GroupDevCtx& c : srv->gdev) {
+    for (size_t g = 0; g < c.stream.size(); g++) {
+      Device* d = srv->shards[g]->dev;
+      DeviceGuard dg(d->ordinal);
+      if (c.stream[g]) device_stream_release(d, c.stream[g]);  // (drains it)
+      if (g < c.ev.size() && c.ev[g]) (void)hipEventDestroy(c.ev[g]);
+      if (g < c.buf.size() && c.buf[g]) (void)CPIR_HIP_FREE(c.buf[g]);
+    }
+    if (!srv->shards.empty()) {
+      DeviceGuard dg(srv->shards[0]->dev->ordinal);
+      if (c.in_ev) (void)hipEventDestroy(c.in_ev);
+      if (c.done_ev) (void)hipEventDestroy(c.done_ev);
+      if (c.partials) (void)CPIR_HIP_FREE(c.partials);
+    }
+    c = Server::GroupDevCtx{};
+  }
+}
+
 static void group_ctx_destroy(Server* srv) {
+  group_dev_destroy(srv);
   for (auto& w : srv->workers) {
     {
       std::lock_guard<std::mutex> lk(w->mu);
@@ -477,6 +497,112 @@ static int group_respond(Server* srv, const uint32_t* q, uint32_t* r_out) {
   return CPIR_OK;
 }
 
+
+// partial responses of the shards, [shards][stride] words on the root device -> r[i] = sum over shards (u32 wrap-around)
+__global__ void __launch_bounds__(256) group_sum_kernel(const uint32_t* __restrict__ partials, uint32_t shards, uint64_t stride, uint64_t count,
+                                                        uint32_t* __restrict__ r) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256) {
+    uint32_t v = 0;
+    for (uint32_t g = 0; g < shards; g++) v += partials[(uint64_t)g * stride + i];
+    r[i] = v;
+  }
+}
+
+static int group_dev_create(Server* srv, Server::GroupDevCtx& c) {
+  const size_t G = srv->shards.size();
+  const uint32_t C = srv->layout.num_cols;
+  Device* root = srv->shards[0]->dev;
+  c.stream.assign(G, nullptr), c.ev.assign(G, nullptr), c.buf.assign(G, nullptr);
+  auto fail = [&](hipError_t e, const char* what) {
+    set_last_hip_error(e, what, __FILE__, __LINE__);
+    return e == hipErrorOutOfMemory ? CPIR_ERR_OUT_OF_DEVICE_MEMORY : CPIR_ERR_HIP;
+  };
+  hipError_t e;
+  for (size_t g = 0; g < G; g++) {
+    const Server* child = srv->shards[g];
+    DeviceGuard dg(child->dev->ordinal);
+    if (child->dev->ordinal != root->ordinal) {  // peer access both ways where the hardware offers it (else the runtime stages the copies)
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, child->dev->ordinal, root->ordinal) == hipSuccess && can) {
+        const hipError_t pe = hipDeviceEnablePeerAccess(root->ordinal, 0);
+        if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+        else (void)hipGetLastError();
+      }
+    }
+    if (!(c.stream[g] = device_stream_acquire(child->dev))) return CPIR_ERR_HIP;
+    if ((e = hipEventCreateWithFlags(&c.ev[g], hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreateWithFlags(group)");
+    const size_t words = ((size_t)child->layout.num_slots + 3) / 4 * 4 * Server::kBatchCap + (size_t)(C + 3) / 4 * 4 * Server::kBatchCap +
+                         (size_t)child->map.n_pad * Server::kBatchCap;
+    if ((e = CPIR_HIP_MALLOC(&c.buf[g], words * 4)) != hipSuccess) return fail(e, "hipMalloc(group lane)");
+  }
+  DeviceGuard dg(root->ordinal);
+  for (size_t g = 1; g < G; g++) {
+    int can = 0;
+    const int peer = srv->shards[g]->dev->ordinal;
+    if (peer != root->ordinal && hipDeviceCanAccessPeer(&can, root->ordinal, peer) == hipSuccess && can) {
+      (void)hipDeviceEnablePeerAccess(peer, 0);
+      (void)hipGetLastError();
+    }
+  }
+  if ((e = hipEventCreateWithFlags(&c.in_ev, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreateWithFlags(group)");
+  if ((e = hipEventCreateWithFlags(&c.done_ev, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreateWithFlags(group)");
+  if ((e = CPIR_HIP_MALLOC(&c.partials, G * (size_t)Server::kBatchCap * C * 4)) != hipSuccess) return fail(e, "hipMalloc(group partials)");
+  c.ready = true, c.used = false;
+  return CPIR_OK;
+}
+
+// cpir_server_respond_device / _batch_device on a GROUP handle: q_dev (batch x N words) and r_dev (batch x C words) on the root device
+// (the device of shard 0), `stream` a stream of that device.  Everything is enqueued; nothing waits on the host.
+static int group_respond_device(Server* srv, const uint32_t* q_dev, uint32_t batch, uint32_t* r_dev, hipStream_t stream) {
+  const size_t G = srv->shards.size();
+  const uint32_t C = srv->layout.num_cols;
+  const uint64_t N = srv->total_slots;
+  Device* root = srv->shards[0]->dev;
+  std::lock_guard<std::mutex> lk(srv->gdev_mu);
+  Server::GroupDevCtx& c = srv->gdev[srv->gdev_next++ % Server::kGroupCtx];
+  if (!c.ready) {
+    const int st = group_dev_create(srv, c);
+    if (st != CPIR_OK) {
+      group_dev_destroy(srv);
+      return st;
+    }
+  }
+#define TRY_(expr) do { const hipError_t _e = (expr); if (_e != hipSuccess) { set_last_hip_error(_e, #expr, __FILE__, __LINE__); return CPIR_ERR_HIP; } } while (0)
+  for (uint32_t done = 0; done < batch; done += Server::kBatchCap) {
+    const uint32_t nb = batch - done < Server::kBatchCap ? batch - done : Server::kBatchCap;
+    {
+      DeviceGuard dg(root->ordinal);
+      TRY_(hipEventRecord(c.in_ev, stream));
+    }
+    for (size_t g = 0; g < G; g++) {
+      const Server* child = srv->shards[g];
+      DeviceGuard dg(child->dev->ordinal);
+      hipStream_t s = c.stream[g];
+      const size_t n = (size_t)child->layout.num_slots, qw = (n + 3) / 4 * 4, rw = (size_t)(C + 3) / 4 * 4;
+      uint32_t* q_loc = c.buf[g];
+      uint32_t* r_loc = q_loc + qw * Server::kBatchCap;
+      uint32_t* qc_loc = child->map.active() ? r_loc + rw * Server::kBatchCap : nullptr;
+      TRY_(hipStreamWaitEvent(s, c.in_ev, 0));
+      if (c.used) TRY_(hipStreamWaitEvent(s, c.done_ev, 0));  // the previous round's table has been summed before this one writes into it
+      // this shard's slots of the nb queries: rows of n words out of rows of N words, over the peer link where the devices differ
+      TRY_(hipMemcpy2DAsync(q_loc, qw * 4, q_dev + (uint64_t)done * N + child->slot_offset, N * 4, n * 4, nb, hipMemcpyDeviceToDevice, s));
+      CPIR_TRY(server_respond_on_device(child, q_loc, qw, 0, nb, nb == 1, r_loc, nullptr, qc_loc, s));
+      TRY_(hipMemcpyAsync(c.partials + (g * Server::kBatchCap) * (size_t)C, r_loc, (size_t)nb * C * 4, hipMemcpyDeviceToDevice, s));
+      TRY_(hipEventRecord(c.ev[g], s));
+    }
+    DeviceGuard dg(root->ordinal);
+    for (size_t g = 0; g < G; g++) TRY_(hipStreamWaitEvent(stream, c.ev[g], 0));
+    const uint64_t count = (uint64_t)nb * C;
+    const unsigned blocks = (unsigned)((count + 255) / 256 < 1024 ? (count + 255) / 256 : 1024);
+    hipLaunchKernelGGL(group_sum_kernel, dim3(blocks), dim3(256), 0, stream, c.partials, (uint32_t)G, (uint64_t)Server::kBatchCap * C, count,
+                       r_dev + (uint64_t)done * C);
+    TRY_(hipGetLastError());
+    TRY_(hipEventRecord(c.done_ev, stream));
+    c.used = true;
+  }
+#undef TRY_
+  return CPIR_OK;
+}
 
 Server* server_new(Device* dev, const cpir_dtc_layout& L, uint64_t slot_offset, uint64_t total_slots) {
   Server* s = new Server;
@@ -980,14 +1106,17 @@ int cpir_server_respond_bytes(const cpir_server* srv, const uint8_t* query, size
 }
 
 int cpir_server_respond_device(const cpir_server* srv, const uint32_t* q_dev, uint32_t* r_dev, uint32_t* scratch_dev, void* stream) {
-  if (!srv || !q_dev || !r_dev || !srv->shards.empty()) return CPIR_ERR_INVALID_ARGUMENT;  // device pointers belong to ONE device
+  if (!srv || !q_dev || !r_dev) return CPIR_ERR_INVALID_ARGUMENT;
+  if (!srv->shards.empty())  // a group: q and r on the device of shard 0; the exchange is peer copies + a sum kernel there
+    return group_respond_device(const_cast<cpir_server*>(srv), q_dev, 1, r_dev, pick_stream(srv->shards[0]->dev, stream));
   DeviceGuard g(srv->dev->ordinal);
   return server_respond_on_device(srv, q_dev, srv->total_slots, srv->slot_offset, 1, true, r_dev, scratch_dev, nullptr, pick_stream(srv->dev, stream));
 }
 
 int cpir_server_respond_batch_device(const cpir_server* srv, const uint32_t* q_dev, uint32_t batch, uint32_t* r_dev, uint32_t* scratch_dev,
                                      void* stream) {
-  if (!srv || !q_dev || !r_dev || batch == 0 || !srv->shards.empty()) return CPIR_ERR_INVALID_ARGUMENT;
+  if (!srv || !q_dev || !r_dev || batch == 0) return CPIR_ERR_INVALID_ARGUMENT;
+  if (!srv->shards.empty()) return group_respond_device(const_cast<cpir_server*>(srv), q_dev, batch, r_dev, pick_stream(srv->shards[0]->dev, stream));
   DeviceGuard g(srv->dev->ordinal);
   return server_respond_on_device(srv, q_dev, srv->total_slots, srv->slot_offset, batch, false, r_dev, scratch_dev, nullptr,
                                   pick_stream(srv->dev, stream));

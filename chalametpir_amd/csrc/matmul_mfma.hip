@@ -41,6 +41,16 @@ constexpr uint32_t kPiecesA = 8 * 4, kPiecesB = 8 * 2;  // 1 KiB pieces per LDS 
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
+// Where the 16 bytes of A-operand lane l = 16 * g + r (k-group g, row r of the 16-row tile) sit inside a 1 KiB A piece in LDS: at slot l with
+// bits 2 and 4 swapped (r's bit 2 <-> g's bit 0).  The conversion of A writes ONE dword per lane and limb (ds_write_b32: two groups of 32
+// lanes, bank = dword address mod 32), and a wave-instruction covers 4 rows x both g of a pair: in lane order the two g land 64 dwords
+// apart, i.e. on the same banks -- every one of the 16 writes of a wave and k-step paid a 2-way conflict (SQ_LDS_BANK_CONFLICT: exactly 32
+// extra cycles per wave and k-step, 5.3e8 per hint at 2^20 keys).  With the swap the low three slot bits of a write group are (g0, r1, r0):
+// 8 distinct values x 4 dwords = all 32 banks once.  The fragment reads (ds_read_b128: four groups of 16 lanes, {0-3,12-15,20-27} ..., bank =
+// dword address mod 64) stay conflict-free: each group's slots still cover the 16 residues mod 16 once.  The D pieces arrive by LDS-DMA in
+// stored order and are not affected.
+__device__ __forceinline__ uint32_t a_slot(uint32_t l) { return (l & 0x2Bu) | ((l >> 2) & 1u) << 4 | ((l >> 4) & 1u) << 2; }
+
 // ---------------------------------------------------------------------------------------------------------------
 // 1. right-hand side -> byte planes + column sums
 // ---------------------------------------------------------------------------------------------------------------
@@ -183,7 +193,7 @@ __global__ void __launch_bounds__(kMT) __attribute__((amdgpu_waves_per_eu(2, 2))
     const uint32_t q = 8 * h + q8;  // 16-byte quad of the row's 256 bytes: k = 4q .. 4q + 3
     kq[j] = 4 * q;
     // dword index (inside the A region of a buffer) of limb 0: piece (row tile of 16, limb), slot 16*(q >> 2) + row % 16, dword q & 3
-    wdw[j] = (((row_l[j] >> 4) * 4) * 64 + 16 * (q >> 2) + (row_l[j] & 15)) * 4 + (q & 3);
+    wdw[j] = (((row_l[j] >> 4) * 4) * 64 + a_slot(16 * (q >> 2) + (row_l[j] & 15))) * 4 + (q & 3);
   }
 
   for (uint64_t u = slot; u < units; u += slots) {
@@ -258,7 +268,7 @@ __global__ void __launch_bounds__(kMT) __attribute__((amdgpu_waves_per_eu(2, 2))
         v4i af[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-          const uint4 t = A_[((wm * 4 + m) * 4 + i) * 64 + lane];
+          const uint4 t = A_[((wm * 4 + m) * 4 + i) * 64 + a_slot(lane)];
           af[i] = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
         }
 #pragma unroll
@@ -524,6 +534,7 @@ __device__ __forceinline__ void mfma_pipe_unit(const MfmaArgs& a, const PipeLane
   constexpr bool PLANAR = RHS != kRhsPlanes;
   constexpr bool BIT = RHS == kRhsImageBit;
   const uint32_t wm = wave >> 2, wn = wave & 3;
+  const uint32_t alane = a_slot(lane);  // this lane's slot inside an A piece (see a_slot)
   v4i S0[4], S1[4];
   // kRhsImageBit: ONE register carries the bit-plane dword of the next k-step.  At the end of k-step t (behind the wait that covers its
   // load, in front of the barrier) the piece of k-step t + 1 is expanded from it into stage (t + 1) % 3, and the dword of k-step t + 2 is
@@ -587,7 +598,7 @@ __device__ __forceinline__ void mfma_pipe_unit(const MfmaArgs& a, const PipeLane
       v4i af[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        const uint4 q = A_[((wm * 4 + m) * 4 + i) * 64 + lane];
+        const uint4 q = A_[((wm * 4 + m) * 4 + i) * 64 + alane];
         af[i] = v4i{(int)q.x, (int)q.y, (int)q.z, (int)q.w};
       }
       uint32_t* const wbase = reinterpret_cast<uint32_t*>(lds + ((t + 1) & 1) * kPiecesA * 64) + pl.wdw[m];
@@ -644,7 +655,7 @@ __device__ __forceinline__ void mfma_pipe_unit(const MfmaArgs& a, const PipeLane
         }
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        const uint4 q = A_[((wm * 4 + 0) * 4 + i) * 64 + lane];
+        const uint4 q = A_[((wm * 4 + 0) * 4 + i) * 64 + alane];
         af0[i] = v4i{(int)q.x, (int)q.y, (int)q.z, (int)q.w};
       }
       {
@@ -684,7 +695,7 @@ __device__ __forceinline__ void mfma_pipe_unit(const MfmaArgs& a, const PipeLane
           if (m == 0) {
             af[i] = af0[i];
           } else {
-            const uint4 q = A_[((wm * 4 + m) * 4 + i) * 64 + lane];
+            const uint4 q = A_[((wm * 4 + m) * 4 + i) * 64 + alane];
             af[i] = v4i{(int)q.x, (int)q.y, (int)q.z, (int)q.w};
           }
         }
@@ -750,7 +761,7 @@ __global__ void __launch_bounds__(kMT) __attribute__((amdgpu_waves_per_eu(2, 2))
     pl.row_l[j] = 8 * rb + r8;
     const uint32_t q = 8 * h + pl.q8;
     pl.kq[j] = 4 * q;
-    pl.wdw[j] = (((pl.row_l[j] >> 4) * 4) * 64 + 16 * (q >> 2) + (pl.row_l[j] & 15)) * 4 + (q & 3);
+    pl.wdw[j] = (((pl.row_l[j] >> 4) * 4) * 64 + a_slot(16 * (q >> 2) + (pl.row_l[j] & 15))) * 4 + (q & 3);
   }
 
   for (uint64_t un = slot; un < units; un += slots) {

@@ -797,6 +797,21 @@ int launch_planar_pack(const uint32_t* src, uint64_t ld, bool from_ref, const cp
   return CPIR_OK;
 }
 
+}  // namespace (reopened below)
+
+// name of the kernel launch_transpose_compress runs for a database of this layout (packed from D, 16-byte loadable), as a kernel trace
+// shows it -- so that a benchmark line and a rocprof summary can be matched
+const char* pack_kernel_name(const cpir_dtc_layout& L) {
+  if (L.packing == CPIR_PACK_DENSE64) return "transpose_compress_dense_kernel";
+  if (L.packing != CPIR_PACK_PLANAR) return "transpose_compress_kernel";
+  const uint32_t hb = planar_hi_planes(L.mat_elem_bit_len), col_tiles = L.rows_padded / 16;
+  const int rows_mode = pack_rows_mode();
+  const bool rows = rows_mode > 0 || (rows_mode < 0 && col_tiles >= 32 && hb <= 1);  // (the same rule as launch_planar_pack)
+  return rows ? "planar_pack_rows_kernel" : "planar_pack_stream_kernel";
+}
+
+namespace {
+
 uint32_t grid_for(const Device* dev, uint64_t total) {
   uint64_t blocks = (total + kThreads - 1) / kThreads;
   const uint64_t cap = (uint64_t)dev->num_cus * 8;

@@ -135,7 +135,23 @@ struct Server {
     bool busy = false;
     std::vector<GroupLane> lanes;
   };
+  // The same handle asked on DEVICE pointers (cpir_server_respond_device / _batch_device on a group): q and r live on the device of shard 0
+  // (the root); every shard's stream copies its slots of the queries over the peer link, answers them, and copies its C-word partial
+  // responses into the root's table; a kernel on the caller's stream, behind one event per shard, adds the table up.  Nothing touches the
+  // host and no collective library is involved -- xGMI peer copies and stream-ordered events only.
+  struct GroupDevCtx {
+    bool ready = false, used = false;
+    std::vector<hipStream_t> stream;   // per shard, on its device
+    std::vector<hipEvent_t> ev;        // per shard: its partial responses are in the root's table
+    std::vector<uint32_t*> buf;        // per shard, one device block: [kBatchCap x slots] queries, [kBatchCap x C] responses, (slot map) compact queries
+    uint32_t* partials = nullptr;      // root: shards x kBatchCap x C
+    hipEvent_t in_ev = nullptr, done_ev = nullptr;  // root: the queries are ready / the table has been summed (it may be overwritten)
+  };
+  static constexpr uint32_t kBatchCap = 32;  // queries per round of a device-resident group call (larger batches go round by round)
   static constexpr int kGroupCtx = 4;  // concurrent callers served at once; further callers wait
+  GroupDevCtx gdev[kGroupCtx];
+  uint32_t gdev_next = 0;
+  std::mutex gdev_mu;  // one enqueue sequence at a time
   GroupCtx gctx[kGroupCtx];
   bool gctx_ready = false;
   // one persistent host thread per shard does that shard's staging, enqueues and wait, so the per-device host work of a

@@ -256,6 +256,11 @@ class PinnedArray:
             pass
 
 
+def pack_kernel_name(layout: DtcLayout) -> str:
+    """the kernel Device.transpose_compress runs for this layout, as a kernel trace names it"""
+    return _native.load().cpir_pack_kernel_name(C.byref(layout)).decode()
+
+
 def mat_x_mat_kernel_name(rhs_max_bits: int = 16) -> str:
     return _native.load().cpir_mat_x_mat_kernel_name(rhs_max_bits).decode()
 

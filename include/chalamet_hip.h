@@ -273,6 +273,8 @@ int cpir_tuning_set(const char* key, int value);
 void cpir_tuning_reset(void);
 /* Name of the dominant kernel last launched by cpir_op_respond for this layout (for matching rocprof traces). */
 const char* cpir_respond_kernel_name(const cpir_dtc_layout* layout);
+/* Name of the kernel cpir_op_transpose_compress runs for this layout (under the current "pack.rows" setting), as a kernel trace shows it. */
+const char* cpir_pack_kernel_name(const cpir_dtc_layout* layout);
 
 /* ------------------------------------------------------------------------------------------------
  * Server handle: the device-resident replacement of `struct Server` (server.rs:15-21).
@@ -316,8 +318,14 @@ int cpir_server_setup_kv(cpir_device* dev, uint32_t arity, const uint8_t seed_mu
  * multiplies its slab by them, and the per-shard partial hints are summed on the host.  The handle behaves like any other in
  * cpir_server_respond / _respond_bytes / _export_compressed / _retain / _release: a host query is SCATTERED -- device g receives only
  * its slots of q over its own host link, answers its shard, and the C-word partial responses are summed on the host (u32
- * wrap-around, bit-identical to one device).  The *_device entry points reject a group handle (device pointers belong to one
- * device; multi-process callers use one ordinary shard server per rank: cpir_server_from_device_matrix). */
+ * wrap-around, bit-identical to one device).  THE EXCHANGE OF THE HOST ENTRY POINTS IS A HOST SUM, not a collective: 3.7 kB per
+ * shard and query, already in page-locked memory when the shards' downloads complete.
+ * The *_device entry points take a group handle too: q_dev and r_dev then live on the device of shard 0 (the root), every shard's own
+ * stream pulls its slots of the queries over the peer link (xGMI between GPUs of one node; peer access is enabled where the hardware
+ * offers it), answers them, and pushes its C-word partial responses into a table on the root, where a kernel on the caller's stream --
+ * behind one event per shard -- adds them up.  Stream-ordered end to end: nothing waits on the host, no collective library is involved
+ * (multi-PROCESS callers use one ordinary shard server per rank, cpir_server_from_device_matrix, and their own collective: RCCL
+ * through torch.distributed in chalametpir_amd/distributed.py). */
 int cpir_server_setup_multi(cpir_device* const* devs, uint32_t n_dev, const uint8_t seed_mu[CPIR_SEED_BYTE_LEN], const uint32_t* pub_mat_a,
                             const uint32_t* D, uint64_t N, uint32_t C, uint32_t mat_elem_bit_len, uint32_t* hint_out, cpir_server** out);
 int cpir_server_setup_kv_multi(cpir_device* const* devs, uint32_t n_dev, uint32_t arity, const uint8_t seed_mu[CPIR_SEED_BYTE_LEN],
@@ -410,7 +418,9 @@ int cpir_server_respond(const cpir_server* srv, const uint32_t* q, uint32_t q_ro
 /* Device-resident variant: q_dev (total_slots u32) and r_dev (C u32) on the server's device; enqueues on `stream`
  * (NULL = HIP's default stream) and returns without synchronising.  For a shard, r_dev receives the shard's
  * PARTIAL response; the caller sum-reduces partials across shards (u32 wrap-around add). `scratch_dev` must hold
- * cpir_respond_scratch_words() u32, or NULL to use a per-stream scratch owned by the handle. */
+ * cpir_respond_scratch_words() u32, or NULL to use a per-stream scratch owned by the handle.
+ * A GROUP handle: q_dev, r_dev and `stream` belong to the device of shard 0; r_dev receives the COMPLETE response (see
+ * cpir_server_setup_multi); scratch_dev is ignored. */
 int cpir_server_respond_device(const cpir_server* srv, const uint32_t* q_dev, uint32_t* r_dev, uint32_t* scratch_dev,
                                void* stream);
 int cpir_server_respond_batch_device(const cpir_server* srv, const uint32_t* q_dev, uint32_t batch, uint32_t* r_dev,

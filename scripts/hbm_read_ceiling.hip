@@ -27,6 +27,43 @@ __global__ void __launch_bounds__(256) read_kernel(const u32x4* __restrict__ src
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;  // practically never: keeps the loads
 }
 
+// The same for a MIXED stream: per iteration a lane reads UR x 16 bytes and writes UW x 16 bytes (non-temporal both ways), every wave-instruction
+// 1 KiB contiguous -- the friendliest possible form of what the pack pass does (4.44 GB of D read, 1.25 GB of image written at 2^20 keys:
+// 3.55 : 1, here 7 : 2).  What THIS reaches is the ceiling of that pass; the 8 TB/s of the data sheet is not.
+template <int UR, int UW>
+__global__ void __launch_bounds__(256) mix_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, uint64_t iters_total) {
+  const uint64_t per = iters_total / gridDim.x;  // iterations (of 256 lanes) per block
+  const u32x4* p = src + (uint64_t)blockIdx.x * per * 256 * UR + threadIdx.x;
+  u32x4* q = dst + (uint64_t)blockIdx.x * per * 256 * UW + threadIdx.x;
+  for (uint64_t i = 0; i < per; i++) {
+    u32x4 v[UR];
+#pragma unroll
+    for (int u = 0; u < UR; u++) v[u] = __builtin_nontemporal_load(p + (i * UR + u) * 256);
+    u32x4 acc = v[0];
+#pragma unroll
+    for (int u = 1; u < UR; u++) acc ^= v[u];
+#pragma unroll
+    for (int u = 0; u < UW; u++) __builtin_nontemporal_store(acc + (uint32_t)u, q + (i * UW + u) * 256);
+  }
+}
+
+template <int UR, int UW>
+double run_mix(const u32x4* src, u32x4* dst, uint64_t read_bytes, int blocks) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  const uint64_t iters = read_bytes / (16ull * 256 * UR) / blocks * blocks;
+  hipLaunchKernelGGL((mix_kernel<UR, UW>), dim3(blocks), dim3(256), 0, 0, src, dst, iters);
+  hipEventRecord(e0);
+  const int reps = 6;
+  for (int r = 0; r < reps; r++) hipLaunchKernelGGL((mix_kernel<UR, UW>), dim3(blocks), dim3(256), 0, 0, src, dst, iters);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  return (double)iters * 256 * 16 * (UR + UW) * reps / (ms * 1e-3) / 1e12;  // bytes moved (read + written) per second
+}
+
 template <int U, bool NT>
 double run(const u32x4* buf, uint64_t n16, uint32_t* out, int blocks) {
   hipEvent_t e0, e1;
@@ -45,6 +82,29 @@ double run(const u32x4* buf, uint64_t n16, uint32_t* out, int blocks) {
 }
 
 int main(int argc, char** argv) {
+  if (argc > 1 && strcmp(argv[1], "--mix") == 0) {  // --mix [READ_BYTES]: one JSON line with the best mixed-stream rate (7 reads : 2 writes)
+    uint64_t rbytes = argc > 2 ? strtoull(argv[2], nullptr, 10) : 4435476480ull;
+    if (rbytes < (256ull << 20)) rbytes = 256ull << 20;
+    if (rbytes > (40ull << 30)) rbytes = 40ull << 30;
+    u32x4 *src, *dst;
+    if (hipMalloc(&src, rbytes) != hipSuccess || hipMalloc(&dst, rbytes * 2 / 7 + (1 << 20)) != hipSuccess) {
+      fprintf(stderr, "hbm_read_ceiling: no device memory\n");
+      return 1;
+    }
+    hipMemset(src, 1, rbytes);
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    double best = 0;
+    int best_bpc = 0;
+    for (int bpc : {2, 3, 4, 8}) {
+      const double m = run_mix<7, 2>(src, dst, rbytes, prop.multiProcessorCount * bpc);
+      if (m > best) best = m, best_bpc = bpc;
+    }
+    printf("{\"mix_ceiling_GBps\": %.1f, \"read_bytes\": %llu, \"write_bytes\": %llu, \"blocks_per_cu\": %d, \"device\": \"%s\", "
+           "\"kernel\": \"7 x 16-byte nt loads : 2 x 16-byte nt stores per lane and iteration, 1 KiB contiguous per wave-instruction; rate = bytes read + written\"}\n",
+           best * 1e3, (unsigned long long)rbytes, (unsigned long long)(rbytes * 2 / 7), best_bpc, prop.name);
+    return 0;
+  }
   const bool json = argc > 1 && strcmp(argv[1], "--json") == 0;
   uint64_t bytes = 1257512304ull;
   if (json && argc > 2) bytes = strtoull(argv[2], nullptr, 10);

@@ -101,20 +101,30 @@ def test_group_respond_is_reentrant(orc, device):
     assert not errors
 
 
-def test_device_pointer_entry_points_reject_a_group(device):
+def test_device_pointer_entry_points_take_a_group_on_the_default_stream(orc, device):
+    """(round 3 rejected a group here; since round 4 the exchange runs on the devices: see the peer-exchange test below) -- the NULL
+    stream and a tiny database"""
     import torch
 
     import chalametpir_amd as cp
 
     rng = np.random.default_rng(5)
     N, C, b = 4 * 1536, 8, 9
-    srv, _ = cp.Server.setup_from_matrix(rng.bytes(32), random_db_matrix(rng, N, C, b), b, devices=[device, device])
-    q = torch.zeros(N, dtype=torch.int32, device="cuda")
+    D = random_db_matrix(rng, N, C, b)
+    srv, _ = cp.Server.setup_from_matrix(rng.bytes(32), D, b, devices=[device, device])
+    dtc = orc.row_wise_compress(orc.transpose(D), b)
+    qh = random_query(rng, N)
+    q = torch.from_numpy(qh.view(np.int32)).cuda()
     r = torch.zeros(C, dtype=torch.int32, device="cuda")
-    with pytest.raises(cp.ChalametPIRError):
-        srv.respond_device(q, r)
-    with pytest.raises(cp.ChalametPIRError):
-        srv.respond_batch_device(q, 1, r)
+    srv.respond_device(q, r)
+    torch.cuda.synchronize()
+    want = orc.row_vector_x_compressed_transposed_matrix(qh, dtc, N, b)[0]
+    assert np.array_equal(r.cpu().numpy().view(np.uint32), want)
+    r.zero_()
+    srv.respond_batch_device(q, 1, r)
+    torch.cuda.synchronize()
+    assert np.array_equal(r.cpu().numpy().view(np.uint32), want)
+    srv.close()
 
 
 def test_lifecycle_stress_servers_groups_and_setups_from_many_threads(orc, device):
@@ -165,3 +175,56 @@ def test_lifecycle_stress_servers_groups_and_setups_from_many_threads(orc, devic
     [t.join(600) for t in threads]
     assert not any(t.is_alive() for t in threads), "a worker hung"
     assert not errors, errors[:5]
+
+
+@pytest.mark.parametrize("b,holes", [(9, False), (9, True), (12, True)])
+def test_group_answers_device_queries_with_a_peer_exchange(b, holes, orc, device):
+    """cpir_server_respond_device / _batch_device on a group handle: q and r on the root device, every shard pulls its slots over the
+    peer link, the C-word partials are pushed into the root's table and summed by a kernel on the caller's stream -- same responses as
+    the oracle on the whole matrix, for one query, for batches around and beyond the 32-query round, on databases with and without rows
+    that are left out of the image (compact.hip)"""
+    import torch
+
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(6000 + b + holes)
+    C, N = 23, 21504 * 3 + 901
+    D = random_db_matrix(rng, N, C, b)
+    if holes:
+        D[rng.random(N) < 0.15] = 0
+    seed = rng.bytes(32)
+    _, want_dtc = orc.server_setup_from_matrix(seed, D, b)
+    grp, _ = cp.Server.setup_from_matrix(seed, D, b, devices=[device] * 3)
+    try:
+        assert len(grp.group_shards()) == 3
+        if holes:
+            assert grp.slots_served()[0] < N
+        stream = torch.cuda.current_stream()
+        qs = np.stack([random_query(rng, N) for _ in range(70)])
+        wants = np.stack([orc.row_vector_x_compressed_transposed_matrix(q, want_dtc, N, b)[0] for q in qs[:40]])
+        q_dev = torch.from_numpy(qs.view(np.int32)).cuda()
+        r1 = torch.full((C,), -1, dtype=torch.int32, device="cuda")
+        grp.respond_device(q_dev[7], r1, stream=stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(r1.cpu().numpy().view(np.uint32), wants[7])
+        for batch in (1, 2, 9, 32, 33, 40):
+            r = torch.full((batch, C), -1, dtype=torch.int32, device="cuda")
+            grp.respond_batch_device(q_dev[:batch], batch, r, stream=stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(r.cpu().numpy().view(np.uint32), wants[:batch]), batch
+        # calls enqueued back to back on two streams (every call takes the next of four contexts; a context is reused behind its own sum)
+        s2 = torch.cuda.Stream()
+        outs = []
+        for i in range(10):
+            r = torch.empty((4, C), dtype=torch.int32, device="cuda")
+            st = stream if i % 2 == 0 else s2
+            with torch.cuda.stream(st):
+                grp.respond_batch_device(q_dev[4 * (i % 8):4 * (i % 8) + 4], 4, r, stream=st)
+            outs.append((i, r))
+        torch.cuda.synchronize()
+        for i, r in outs:
+            assert np.array_equal(r.cpu().numpy().view(np.uint32), wants[4 * (i % 8):4 * (i % 8) + 4]), i
+        # and the host entry point of the same handle still agrees
+        assert np.array_equal(grp.respond_array(qs[3]), wants[3])
+    finally:
+        grp.close()
