@@ -40,7 +40,13 @@ static constexpr unsigned kJournal = 512;
 static JournalEntry g_journal[kJournal];
 static std::atomic<uint64_t> g_journal_n{0};
 
+// Only kept while the fatal-signal backtrace is switched on (CPIR_ABORT_BACKTRACE=1, read once when the library is loaded): the ring's
+// slots are plain structs written without synchronisation -- good enough for a diagnosis aid that a dying process prints, not something
+// every allocation of a production server should race on.
+static std::atomic<bool> g_journal_on{false};
+
 void journal_note(const char* what, const void* p, size_t bytes, const char* file, int line) {
+  if (!g_journal_on.load(std::memory_order_relaxed)) return;
   const uint64_t i = g_journal_n.fetch_add(1, std::memory_order_relaxed);
   JournalEntry& e = g_journal[i % kJournal];
   const char* slash = strrchr(file, '/');
@@ -88,6 +94,7 @@ static void abort_backtrace_handler(int sig, siginfo_t* info, void* uctx) {
 __attribute__((constructor)) static void install_abort_backtrace() {
   const char* on = getenv("CPIR_ABORT_BACKTRACE");
   if (!on || on[0] != '1') return;
+  g_journal_on.store(true, std::memory_order_relaxed);
   void* warm[4];
   (void)backtrace(warm, 4);  // loads libgcc's unwinder now, not inside the handler
   struct sigaction sa;

@@ -129,6 +129,23 @@ def test_bench_json_contract():
     assert cpu["gpu_results_bit_exact"] is True
 
 
+def test_bench_default_sections_at_the_reference_tests_ceiling():
+    """the sections the driver's default run carries besides the headline, at 2^16 keys so that it takes seconds: Server::setup from the
+    key-value database (the reference's own `server_setup` bench), the real database it built served without its empty rows and looked
+    up end to end, the pack pass against a plain mixed stream"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "cfg1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline",
+           "--no-live-traffic", "--no-host-path"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["server_setup_kv_wall_sec"] > 0 and d["server_setup_kv_phases_sec"]["encode"] > 0 and d["hint_bytes"] == 8 + 4 * 1774 * 846
+    real = d["real_db"]
+    assert real["rows_owned_by_no_key"] == 77824 - 65536 and real["slots_served"] == 65536 and real["slots_of"] == 77824
+    assert real["queries_per_sec"] > 0 and real["end_to_end"]["all_recovered"] is True and real["end_to_end"]["keys_looked_up"] >= 1
+    tc = d["setup_roofline"]["transpose_compress"]
+    assert "planar_pack" in tc["kernel"] and tc["copy_ceiling_GBps"] > 1000 and 0.05 < tc["frac_vs_copy_ceiling"] < 1.3
+
+
 def test_rccl_backend_single_rank():
     """the backend bench.py --gpus N really uses ("nccl" = RCCL), as far as a one-GPU box can take it: one rank, device tensors, the
     product's own collectives and the device path of scatter_public_matrix (tests/_rccl_worker.py)"""
