@@ -59,7 +59,6 @@ struct PlanarArgs {
   uint32_t q_scalar;       // q not 16-byte loadable -> guarded scalar loads everywhere
   uint32_t interleave;     // order of the passes of one launch (see the kernel)
   uint32_t q_far;          // step-major kernel: q sits behind the host link -> a whole step of units between requesting and using it
-  uint32_t two_halves;     // step-major kernel, several passes: racc holds two halves and a pass's responses are trickled out during the next pass
   const uint32_t* colsum;  // step-major kernel: per-column field sums behind the tiles (NULL: this launch does not cover step 0)
   // step-major kernel, q read in place from host memory that is still being FILLED while the kernel runs (a lone pageable host query):
   uint32_t strided;          // blocks take whole steps round-robin (step s -> block s % blocks), so the grid consumes q front to back
@@ -507,28 +506,26 @@ respond_planar_ks_kernel(const PlanarArgs a) {
 
   // ---- the passes of the launch as ONE pipeline --------------------------------------------------------------------------------------
   // A pass ends where the next begins: the last unit of a pass prefetches the next pass's first tile (the same tile -- every pass walks the
-  // same visits) and its last visit builds the next pass's first fragments, exactly as for the next visit inside a pass.  The pass's
-  // responses do not leave at its end either: racc has TWO halves when there are several passes; at a pass boundary the halves swap and the
-  // finished one is trickled out during the next pass, a few atomics per thread and unit, each thread zeroing the words it has sent so that
-  // the half is clean when its turn comes again.  Only the last pass flushes at the end.  (Measured at 2^20 keys, 8 queries per pass:
-  // flushing 512 blocks x 7 680 words at every pass end cost ~12 of 211 us per pass -- the burst alone takes 10-20 us,
-  // scripts/probes/atomic_flush_probe.hip -- and the drained pipeline + prologue of every pass a few more.)
+  // same visits) and its last visit builds the next pass's first fragments, exactly as for the next visit inside a pass; the pass's
+  // responses leave at the boundary, between two barriers, while those requests are in flight (round 3 drained the pipeline, flushed and
+  // ran a prologue for every pass: 26.4 us per query for passes of 8 at 2^20 keys, 25.3 now).
+  // What the flush itself costs: 512 blocks x 7 680 words -- a fused pass of 8 -- leave as 3.9 M u32 atomics in one burst: 10 us even with
+  // words of their own per block, 19.7 us when every block walks the words in the same order, 11.5 us when each starts at an offset of its
+  // own (scripts/probes/atomic_flush_probe.hip); in the kernel the pass takes 1-2 us per query less without it.  Tried and dropped: a
+  // double-sized accumulator whose finished half is trickled out during the NEXT pass, two atomics per thread and unit -- 27.0-27.4 us per
+  // query: the halves need 93 KiB of LDS, i.e. one block per CU (28.0 us on its own against 25.2 with two), and the trickled atomics sit
+  // in the wave's vector-memory queue between the tile prefetch and its wait, which, counted in issue order, then covers them too.
   const uint32_t rtotal = nq * cpad;
-  const bool two_halves = a.two_halves != 0;
-  uint32_t cur_off = 0, old_off = rtotal;  // the half being accumulated into / the half being trickled out (only touched when two_halves)
-  for (uint32_t i = threadIdx.x; i < rtotal * (two_halves ? 2u : 1u); i += kThreads) racc[i] = 0;
+  for (uint32_t i = threadIdx.x; i < rtotal; i += kThreads) racc[i] = 0;
   uint32_t pass = 0;
-  // the pending half: pass it belongs to, and this thread's next word of it (words threadIdx.x, + 256, ...); every block starts its
-  // round at an offset of its own so that the blocks are spread over the words
+  // every block starts its round over the words at an offset of its own (a multiple of 64), so that the blocks are spread over them
   const uint32_t fstart = (uint32_t)(((uint64_t)blockIdx.x * rtotal) / gridDim.x) & ~63u;
-  uint32_t pend_pass = 0, pend_i = rtotal;  // nothing pending
-  // (half_off: 0 or rtotal -- an offset, not a pointer: racc stays an LDS address for the compiler)
-  auto flush_some = [&](uint32_t half_off, uint32_t of_pass, uint32_t& cursor, uint32_t count, bool zero) __attribute__((always_inline)) {
-    for (uint32_t k = 0; k < count && cursor < rtotal; k++, cursor += kThreads) {
+  auto flush_pass = [&](uint32_t of_pass, bool zero) __attribute__((always_inline)) {
+    for (uint32_t cursor = threadIdx.x; cursor < rtotal; cursor += kThreads) {
       uint32_t i2 = cursor + fstart;
       if (i2 >= rtotal) i2 -= rtotal;
-      const uint32_t query = i2 / cpad, col = a.tg_lo * (kM * 16) + i2 % cpad, val = racc[half_off + i2];
-      if (zero) racc[half_off + i2] = 0;
+      const uint32_t query = i2 / cpad, col = a.tg_lo * (kM * 16) + i2 % cpad, val = racc[i2];
+      if (zero) racc[i2] = 0;
       if (col < a.num_cols && val) atomicAdd(a.r + ((uint64_t)of_pass * nq + query) * a.num_cols + col, val);
     }
   };
@@ -614,12 +611,10 @@ respond_planar_ks_kernel(const PlanarArgs a) {
         if (query < nq) {
           const uint32_t qsum = (ksum[par][0][query] + ksum[par][1][query]) + (ksum[par][2][query] + ksum[par][3][query]);
           val += 128u * qsum - 0x40404000u * nvs + col_term;  // 128 * 0x80808080 = 0x40404000 mod 2^32
-          atomicAdd(&racc[cur_off + query * cpad + Tw * 16 + cl], val);  // LDS; this wave owns tile T of every step
+          atomicAdd(&racc[query * cpad + Tw * 16 + cl], val);  // LDS; this wave owns tile T of every step
         }
       }
     }
-    // a little of the previous pass's responses (its half is read-only now; each thread sends and zeroes words of its own)
-    if (two_halves) flush_some(old_off, pend_pass, pend_i, 2, true);
     if (want_next && my_progress) {
       if (ask) {
         seen = early;
@@ -635,21 +630,12 @@ respond_planar_ks_kernel(const PlanarArgs a) {
     first_of_visit = false;
     if (last_of_visit) {
       if (more_visits) {
-        // a pass boundary: what is still pending of the half before last must be out (and zeroed) before the halves swap
-        if (pass_ends && two_halves) flush_some(old_off, pend_pass, pend_i, 0xffffffffu, true);
-        __syncthreads();  // everybody is done with this step's fragments (and, at a pass boundary, with this pass's half); the next step's are complete
+        __syncthreads();  // everybody is done with this step's fragments (and, at a pass boundary, with accumulating this pass); the next step's are complete
         par ^= 1;
         first_of_visit = true;
-        if (pass_ends) {
-          if (two_halves) {
-            const uint32_t t = cur_off;
-            cur_off = old_off, old_off = t;
-            pend_pass = pass, pend_i = threadIdx.x;
-          } else {  // one half: the pass's responses leave now (the next pass's first tile and fragments are on their way meanwhile)
-            uint32_t cursor = threadIdx.x;
-            flush_some(cur_off, pass, cursor, 0xffffffffu, true);
-            __syncthreads();  // clean before anybody accumulates for the next pass
-          }
+        if (pass_ends) {  // the pass's responses leave now (the next pass's first tile and fragments are on their way meanwhile)
+          flush_pass(pass, true);
+          __syncthreads();  // clean before anybody accumulates for the next pass
           pass = npass;
         }
         v = nv, cks = nks, ctg1 = visit_tg1(v);
@@ -665,13 +651,9 @@ respond_planar_ks_kernel(const PlanarArgs a) {
     unit(b1, b0);
   }
 
-  // ---- what is left: the rest of the pass before last, and the last pass ----
-  if (two_halves) flush_some(old_off, pend_pass, pend_i, 0xffffffffu, false);
+  // ---- the last pass ----
   __syncthreads();
-  {
-    uint32_t cursor = threadIdx.x;
-    flush_some(cur_off, pass, cursor, 0xffffffffu, false);
-  }
+  flush_pass(pass, false);
 }
 
 // r[q][c] += 128 * sum_n (q[n] - 0x80808080) over this block's slice of the valid slots, and (slice 0 only) += 0x80808080 * colsum[c]:
@@ -811,19 +793,8 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
   // (a query read in place over the host link must be read ONCE: one window or nothing)
   KernelFn fn_ks = (want_ks && !inter && (windows == 1 || ks_mode != 3)) ? pick_ks(hb, batch, nt) : nullptr;
   if (ks_mode == 3 && !fn_ks) return CPIR_ERR_INVALID_ARGUMENT;  // the caller relies on q being read once
-  // (several passes in one step-major launch: the responses of a pass leave during the NEXT pass, from the second half of a
-  // double-sized LDS accumulator -- up to 2 x 48 KiB beside the A fragments, so one block per CU; measured at 2^20 keys, 8 queries per
-  // pass, one block per CU streams as fast as two: 26.5-26.9 against 26.0-26.8 us per query before the halves existed)
-  // Measured: NO gain -- 27.0 us per query against 26.4 with one half and a flush at every pass boundary (flushing costs ~1.5 us per query:
-  // 24.3-25.4 without it).  The trickled atomics sit in the wave's vector-memory queue between the tile prefetch and its wait, and the
-  // wait, counted in issue order, then covers them too; a separate flusher wave would not have that problem.  Kept behind the
-  // (undocumented, diagnosis) environment switch CPIR_RESPOND_TWO_HALVES=1.
-  static const bool want_two_halves = getenv("CPIR_RESPOND_TWO_HALVES") != nullptr;
-  const bool two_halves = want_two_halves && fn_ks && passes > 1;
-  int bpc = blocks_per_cu > 0 ? blocks_per_cu : (fn_ks ? ((batch <= 4 || two_halves) ? 1 : 2) : (inter ? 3 : 2));
+  int bpc = blocks_per_cu > 0 ? blocks_per_cu : (fn_ks ? (batch <= 4 ? 1 : 2) : (inter ? 3 : 2));
   if (batch > 4 && bpc > 2) bpc = 2;
-  if (two_halves && batch > 4) bpc = 1;
-  a.two_halves = two_halves ? 1u : 0u;
   // grid of a launch over `tgs` tile groups
   auto grid_for_units = [&](uint32_t tgs, uint32_t* nx_out) {
     const uint64_t units = (uint64_t)tgs * (a.ks_hi - a.ks_lo);
@@ -850,7 +821,7 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
       if (a.tg_lo >= a.tile_groups) break;
       a.tg_n = a.tile_groups - a.tg_lo < tg_per_window ? a.tile_groups - a.tg_lo : tg_per_window;
       const uint64_t grid = grid_for_units(a.tg_n, &a.nx);
-      const size_t racc_bytes = (size_t)batch * a.tg_n * (kM * 16) * sizeof(uint32_t) * (two_halves ? 2 : 1);
+      const size_t racc_bytes = (size_t)batch * a.tg_n * (kM * 16) * sizeof(uint32_t);
       hipLaunchKernelGGL(fn_ks, dim3((unsigned)grid), dim3(kThreads), racc_bytes, stream, a);
     }
     CPIR_HIP_TRY(hipGetLastError());
