@@ -241,7 +241,7 @@ static void arenas_destroy(Server* srv) {
 
 // spare words behind the response seats of an arena's two blocks: the fill progress of a lone query in CPIR_FILL_LINES copies (pinned
 // block; + 16 words so that the copies can start on a 64-byte line), the abort flag (device block, behind seat 0's response)
-static constexpr size_t kArenaSpareWords = (size_t)CPIR_FILL_LINES * 16 + 16;
+static constexpr size_t kArenaSpareWords = (size_t)CPIR_FILL_LINES * 16 + 16 + 16;  // (+ one line behind the fill counts: the hand-over flag)
 static void publish_fill_progress(uint32_t* lines, uint32_t steps) {
   for (uint32_t i = 0; i < CPIR_FILL_LINES; i++) __atomic_store_n(lines + i * 16, steps, __ATOMIC_RELEASE);
 }
@@ -276,6 +276,10 @@ static int arena_create(Server* srv, RespondArena& a) {
     const size_t off = (qw + rw - kArenaSpareWords + 15) / 16 * 16;  // the copies start on a 64-byte line (the block itself is page-aligned)
     a.fill_progress = a.q_pinned + off;
     a.fill_progress_dev = a.q_pinned_dev + off;
+    a.handed = a.fill_progress + (size_t)CPIR_FILL_LINES * 16;  // a line of its own behind the fill counts
+    a.handed_dev = const_cast<uint32_t*>(a.fill_progress_dev) + (size_t)CPIR_FILL_LINES * 16;
+    __atomic_store_n(a.handed, 0u, __ATOMIC_RELAXED);
+    a.hand_seq = 0;
   }
   a.r0_zero = false;
   a.seat_ev.assign(Server::kSeats, nullptr);
@@ -497,6 +501,22 @@ static int group_respond(Server* srv, const uint32_t* q, uint32_t* r_out) {
   return CPIR_OK;
 }
 
+
+// A lone caller's response leaves the device by a one-block kernel behind the respond kernel on the same stream instead of a copy-engine
+// download + an event: it stores the C response words (and the abort flag behind them) into the arena's page-locked block, zeroes the
+// device copy for the next caller (no memset either), fences, and stores this call's sequence number into a flag line of that block,
+// which the caller polls.  The respond kernel's own results are complete at the kernel boundary, so no fence is needed inside the big grid
+// (round 3 tried handing over from the respond kernel's last block: every block then needed a release fence, +40 us).
+__global__ void __launch_bounds__(256) respond_hand_over_kernel(uint32_t* __restrict__ r_dev, uint32_t words, uint32_t* __restrict__ r_host,
+                                                                uint32_t* __restrict__ flag_host, uint32_t seq) {
+  for (uint32_t i = threadIdx.x; i < words; i += 256) {
+    __hip_atomic_store(r_host + i, r_dev[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    r_dev[i] = 0;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // partial responses of the shards, [shards][stride] words on the root device -> r[i] = sum over shards (u32 wrap-around)
 __global__ void __launch_bounds__(256) group_sum_kernel(const uint32_t* __restrict__ partials, uint32_t shards, uint64_t stride, uint64_t count,
@@ -827,17 +847,42 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
       rc = launch_respond_read_once(srv->dev, srv->dtc, L, a->q_pinned_dev, kq_len, kq_off, a->r_dev, st);
     }
   }
+  // (measured, one caller at 2^20 keys, scripts/host_path_cold.py: page-locked 214.5 -> 211.1 us, pageable 235 -> 232 us against the
+  // copy-engine download + event of round 3, which stays as the path of last resort)
+  constexpr bool no_hand_over = false;
   for (int attempt = 0; attempt < 2; attempt++) {
-    if (e == hipSuccess && rc == CPIR_OK) e = hipMemcpyAsync(a->r_pinned, a->r_dev, (C + 1) * 4, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess && rc == CPIR_OK) e = hipEventRecord(a->done_ev, st);
-    if (e == hipSuccess && rc == CPIR_OK) {
-      // zeros for the next lone caller, off this one's critical path
-      if (hipMemsetAsync(a->r_dev, 0, (C + 1) * 4, st) == hipSuccess) a->r0_zero = true;
-      else (void)hipGetLastError();
-      e = wait_for_event(a->done_ev);
-    } else {
-      (void)hipStreamSynchronize(st);  // whatever was enqueued reads the caller's buffer / the pinned block: drain before returning
+    if (e == hipSuccess && rc == CPIR_OK && !no_hand_over) {
+      // the response is handed over by a one-block kernel (which also leaves seat 0 of r_dev zeroed): poll its flag
+      const uint32_t seq = ++a->hand_seq ? a->hand_seq : ++a->hand_seq;  // never 0
+      uint32_t* const r_host_dev = const_cast<uint32_t*>(a->q_pinned_dev) + (a->r_pinned - a->q_pinned);
+      hipLaunchKernelGGL(respond_hand_over_kernel, dim3(1), dim3(256), 0, st, a->r_dev, (uint32_t)(C + 1), r_host_dev, a->handed_dev, seq);
+      e = hipGetLastError();
+      if (e == hipSuccess) {
+        a->r0_zero = true;
+        const double t0 = now_seconds();
+        bool got = false;
+        while (!(got = __atomic_load_n(a->handed, __ATOMIC_ACQUIRE) == seq)) {
+          if (now_seconds() - t0 > 5e-3) break;  // something is very slow or wrong: fall back to waiting on the stream
+#if defined(__x86_64__)
+          __builtin_ia32_pause();
+#endif
+        }
+        if (!got) {
+          e = hipStreamSynchronize(st);
+          if (e == hipSuccess && __atomic_load_n(a->handed, __ATOMIC_ACQUIRE) != seq) e = hipErrorUnknown;
+        }
+      }
+    } else if (e == hipSuccess && rc == CPIR_OK) {
+      e = hipMemcpyAsync(a->r_pinned, a->r_dev, (C + 1) * 4, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipEventRecord(a->done_ev, st);
+      if (e == hipSuccess) {
+        // zeros for the next lone caller, off this one's critical path
+        if (hipMemsetAsync(a->r_dev, 0, (C + 1) * 4, st) == hipSuccess) a->r0_zero = true;
+        else (void)hipGetLastError();
+        e = wait_for_event(a->done_ev);
+      }
     }
+    if (!(e == hipSuccess && rc == CPIR_OK)) (void)hipStreamSynchronize(st);  // whatever was enqueued reads the caller's buffer / the pinned block: drain before returning
     if (!(polled && e == hipSuccess && rc == CPIR_OK && a->r_pinned[C] != 0)) break;
     // the polled launch gave up waiting: its results are void.  The pinned block is complete by now: answer from it, without polling.
     polled = false;

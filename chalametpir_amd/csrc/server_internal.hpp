@@ -44,6 +44,9 @@ struct RespondArena {
   const uint32_t* q_pinned_dev = nullptr;  // q_pinned as the device addresses it (a lone query is read in place)
   uint32_t* fill_progress = nullptr;       // in the pinned block: steps of a lone query copied so far (the kernel polls it)
   const uint32_t* fill_progress_dev = nullptr;
+  uint32_t* handed = nullptr;              // in the pinned block: sequence number of the lone response last handed over (respond_hand_over_kernel)
+  uint32_t* handed_dev = nullptr;
+  uint32_t hand_seq = 0;                   // (guarded like r0_zero: one lone caller per arena at a time)
   bool r0_zero = false;                    // seat 0 of r_dev holds zeros (guarded by the arena's own leader: one at a time)
   // guarded by Server::mu
   enum State { FREE, OPEN, LAUNCHED, DONE } state = FREE;

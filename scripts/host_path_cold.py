@@ -24,6 +24,27 @@ rng = np.random.default_rng(1)
 qs = [rng.integers(0, 1 << 32, size=N, dtype=np.uint64).astype(np.uint32) for _ in range(16)]
 pin = cp.PinnedArray(N)
 pin.array[:] = qs[0]
+for kv in filter(None, os.environ.get("CPIR_TUNE", "").split(",")):  # e.g. CPIR_TUNE=respond.ks_major=3
+    k, v = kv.split("=")
+    cp.tuning_set(k, int(v))
+only = os.environ.get("CPIR_ONLY", "")  # "cold" / "pinned" / "device": one kind of call only (a kernel trace then shows that kernel alone)
+if only:
+    r_dev = torch.empty(C, dtype=torch.int32, device="cuda")
+    q_dev = torch.from_numpy(qs[0].view(np.int32)).cuda()
+    import time as _t
+    t0 = _t.perf_counter()
+    for i in range(200):
+        if only == "cold":
+            srv.respond_array(qs[i % 16])
+        elif only == "pinned":
+            srv.respond_array(pin.array)
+        else:
+            srv.respond_device(q_dev, r_dev, stream=stream)
+            torch.cuda.synchronize()
+    print(f"{only}: {(_t.perf_counter() - t0) / 200 * 1e6:.1f} us per call", flush=True)
+    pin.close()
+    srv.close()
+    sys.exit(0)
 for rep in range(3):
     for q in qs[:4]:
         srv.respond_array(q)
