@@ -131,7 +131,9 @@ uint32_t respond_host_fill_timeout_us();  // tuning "respond.host_fill_timeout_u
 bool respond_read_once_applicable(const cpir_dtc_layout& L);  // planar packing, LDS room for one response, respond.host_zero_copy on
 const char* respond_kernel_name(const cpir_dtc_layout& L);
 // respond_planar.hip (CPIR_PACK_PLANAR: the MFMA path); same contract as launch_respond, batch up to CPIR_PLANAR_MAX_QUERIES_PER_PASS
-constexpr uint32_t CPIR_PLANAR_MAX_QUERIES_PER_PASS = 8;
+constexpr uint32_t CPIR_PLANAR_MAX_QUERIES_PER_PASS = 12;  // step-major kernel: three A row sets of 4 queries; the tile-major kernel takes 8
+uint32_t planar_max_queries_per_pass(const cpir_dtc_layout& L, uint32_t passes, int interleave, int ks_mode);
+uint32_t respond_planar_pass_width(const cpir_dtc_layout& L, uint32_t batch);  // respond.hip: the above under the current tuning, for a batch
 int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                           uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, int blocks_per_cu,
                           bool nontemporal, bool xcd_split, int interleave, int ks_mode, bool r_prezeroed = false, uint64_t step_lo = 0,

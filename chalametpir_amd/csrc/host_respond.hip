@@ -694,15 +694,19 @@ int respond_batched(const Device* dev, const uint32_t* dtc, const cpir_dtc_layou
   }
   uint32_t done = 0;
   if (L.packing == CPIR_PACK_PLANAR) {
-    // the matrix-core kernel takes any 1..8 queries per pass: passes of 8, then one pass for the rest
-    const uint32_t W8 = CPIR_PLANAR_MAX_QUERIES_PER_PASS;
-    if (batch >= W8) {
-      CPIR_TRY(launch_respond(dev, dtc, L, q, q_len, q_slot_offset, W8, batch / W8, r, scratch, stream));
-      done = batch / W8 * W8;
+    // the matrix-core kernels take any 1..W queries per pass (W = 12 where the step-major kernel runs the launch, else 8): passes of W,
+    // then the rest -- as one pass if that pass may be as wide, else as passes of 8 and a last one
+    const uint32_t W = respond_planar_pass_width(L, batch);
+    if (batch >= W) {
+      CPIR_TRY(launch_respond(dev, dtc, L, q, q_len, q_slot_offset, W, batch / W, r, scratch, stream));
+      done = batch / W * W;
     }
-    if (done < batch)
-      CPIR_TRY(launch_respond(dev, dtc, L, q + (uint64_t)done * q_len, q_len, q_slot_offset, batch - done, 1,
-                              r + (uint64_t)done * L.num_cols, scratch, stream));
+    while (done < batch) {
+      const uint32_t left = batch - done;
+      const uint32_t w = left <= respond_planar_pass_width(L, left) ? left : 8u;  // (a single pass of up to 12 is always step-major)
+      CPIR_TRY(launch_respond(dev, dtc, L, q + (uint64_t)done * q_len, q_len, q_slot_offset, w, 1, r + (uint64_t)done * L.num_cols, scratch, stream));
+      done += w;
+    }
     return CPIR_OK;
   }
   for (uint32_t width : {4u, 2u, 1u}) {

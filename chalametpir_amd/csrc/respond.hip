@@ -422,6 +422,18 @@ bool respond_batch_fusion() {
   return g_tuning.batch_fusion != 0;
 }
 
+// queries per pass for a fused batch of `batch` queries on a planar image: 12 where passes of 12 would be taken by the step-major kernel
+// (a batch of up to 12 is ONE pass, which always is; larger batches on databases beyond the interleaving size too), else 8
+uint32_t respond_planar_pass_width(const cpir_dtc_layout& L, uint32_t batch) {
+  Tuning t;
+  {
+    std::lock_guard<std::mutex> lk(g_tuning_mu);
+    t = g_tuning;
+  }
+  const uint32_t passes12 = batch / CPIR_PLANAR_MAX_QUERIES_PER_PASS;
+  return planar_max_queries_per_pass(L, passes12 > 1 ? passes12 : 1, t.interleave_passes, t.ks_major);
+}
+
 uint64_t respond_scratch_words(const cpir_dtc_layout&, uint32_t) {
   // the current kernel needs no scratch (partial sums leave through integer atomics); the parameter stays in the ABI so
   // a partial-buffer variant can be swapped in without changing callers

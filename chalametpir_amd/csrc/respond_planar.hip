@@ -90,7 +90,8 @@ __device__ __forceinline__ uint32_t comp(const uint4& u, int i) { return i == 0 
 
 // One step of a block: wave w multiplies column tile 4*tg + w by the step's A fragments (shared through LDS), with the loads of
 // its NEXT tile and the block's next A fragments issued first.  P = parity of the step (register / LDS double buffering).
-// NS = sets of 16 A rows: one set answers up to 4 queries per pass, two sets up to 8 (twice the MFMAs on the same stream).
+// NS = sets of 16 A rows: one set answers up to 4 queries per pass, two sets up to 8 (twice the MFMAs on the same stream); the step-major
+// kernel below also runs with three (up to 12 queries per pass).
 template <int HB, int NS, bool NT>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NS == 1 ? 3 : 2, NS == 1 ? 3 : 2)))
 respond_planar_kernel(const PlanarArgs a) {
@@ -508,7 +509,9 @@ respond_planar_ks_kernel(const PlanarArgs a) {
   // A pass ends where the next begins: the last unit of a pass prefetches the next pass's first tile (the same tile -- every pass walks the
   // same visits) and its last visit builds the next pass's first fragments, exactly as for the next visit inside a pass; the pass's
   // responses leave at the boundary, between two barriers, while those requests are in flight (round 3 drained the pipeline, flushed and
-  // ran a prologue for every pass: 26.4 us per query for passes of 8 at 2^20 keys, 25.3 now).
+  // ran a prologue for every pass: 26.4 us per query for passes of 8 at 2^20 keys, 25.3 now).  With THREE row sets a pass answers 12
+  // queries: 18.8 us per query at 2^20 keys (two column windows of 8 / 7 tile groups, so that two blocks still share a CU's LDS), 134 with
+  // 8 kB values (194 with 8 per pass), 70.5 at 2^22 keys (97.5); 233 VGPR, no scratch.
   // What the flush itself costs: 512 blocks x 7 680 words -- a fused pass of 8 -- leave as 3.9 M u32 atomics in one burst: 10 us even with
   // words of their own per block, 19.7 us when every block walks the words in the same order, 11.5 us when each starts at an offset of its
   // own (scripts/probes/atomic_flush_probe.hip); in the kernel the pass takes 1-2 us per query less without it.  Tried and dropped: a
@@ -718,9 +721,19 @@ KernelFn pick_ks_hb(uint32_t hb, bool nt) {
   }
 }
 
-KernelFn pick_ks(uint32_t hb, uint32_t batch, bool nt) { return batch <= 4 ? pick_ks_hb<1>(hb, nt) : pick_ks_hb<2>(hb, nt); }
+KernelFn pick_ks(uint32_t hb, uint32_t batch, bool nt) {
+  return batch <= 4 ? pick_ks_hb<1>(hb, nt) : (batch <= 8 ? pick_ks_hb<2>(hb, nt) : pick_ks_hb<3>(hb, nt));
+}
 
 }  // namespace
+
+// How many queries one pass over the image can answer in a launch of `passes` passes under the current dispatch rules: 12 where the
+// step-major kernel takes the launch (three row sets of 4 queries), 8 where the tile-major kernel does (interleaved passes of small shards,
+// or the step-major kernel switched off).
+uint32_t planar_max_queries_per_pass(const cpir_dtc_layout& L, uint32_t passes, int interleave, int ks_mode) {
+  const bool inter = passes > 1 && (interleave == 1 || (interleave < 0 && L.total_words * 4 <= (960ull << 20)));
+  return (ks_mode >= 1 && !inter) ? CPIR_PLANAR_MAX_QUERIES_PER_PASS : 8u;
+}
 
 int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                           uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, int blocks_per_cu,
@@ -736,7 +749,7 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
   const bool inter = passes > 1 && (interleave == 1 || (interleave < 0 && L.total_words * 4 <= (960ull << 20)));
   // `nt` loads keep a once-per-query stream out of the caches; passes that are meant to share bytes on die use plain loads
   const bool nt = nontemporal && !inter;
-  KernelFn fn = pick(hb, batch, nt);
+  KernelFn fn = pick(hb, batch > 8 ? 8 : batch, nt);  // (batch > 8 never reaches it: checked below)
   if (!fn || L.chunk_words != (8 + hb) * 256 || L.rows_padded % 16 != 0) return CPIR_ERR_INVALID_ARGUMENT;
   const uint64_t ks_total = (L.num_slots + CPIR_PLANAR_SLOTS_PER_TILE - 1) / CPIR_PLANAR_SLOTS_PER_TILE;
   if (ks_total > 0xffffffffull || ks_total * (L.chunk_words / 16) != L.words_per_row_padded) return CPIR_ERR_INVALID_ARGUMENT;
@@ -783,7 +796,10 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
   // each a launch of its own over all steps -- the query words are gathered once per window (a few MB against the GBs of the stream).
   // (blocks of the two-row-set kernel run two per CU and share its 160 KiB: 48 KiB each beside the 32 KiB of A fragments.  One block per CU
   // with 112 KiB -- 3 windows instead of 5 at 8 kB values -- measured the same: 191.9 against 193.5 us per query)
-  const uint32_t max_tg = (48u << 10) / (batch * kM * 16 * (uint32_t)sizeof(uint32_t));  // 24 tile groups for 8 queries, 192 for one
+  // (three row sets -- 9 to 12 queries per pass, step-major kernel only -- keep 48 KiB of A fragments, so their accumulators get 31 KiB:
+  // two blocks still share a CU, and a database wider than 10 tile groups is answered in column windows: 2 at 2^20 keys x 1 kB)
+  const uint32_t racc_budget = batch > 8 ? (31u << 10) : (48u << 10);
+  const uint32_t max_tg = racc_budget / (batch * kM * 16 * (uint32_t)sizeof(uint32_t));  // 24 tile groups for 8 queries, 192 for one, 10 for 12
   const uint32_t windows = (a.tile_groups + max_tg - 1) / max_tg;
   const uint32_t tg_per_window = (a.tile_groups + windows - 1) / windows;
   // (a query beyond 8 MiB no longer stays in the XCDs' L2 next to the stream, and the tile-major kernel gathers every word of it once
@@ -793,6 +809,7 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
   // (a query read in place over the host link must be read ONCE: one window or nothing)
   KernelFn fn_ks = (want_ks && !inter && (windows == 1 || ks_mode != 3)) ? pick_ks(hb, batch, nt) : nullptr;
   if (ks_mode == 3 && !fn_ks) return CPIR_ERR_INVALID_ARGUMENT;  // the caller relies on q being read once
+  if (batch > 8 && !fn_ks) return CPIR_ERR_INVALID_ARGUMENT;      // the tile-major kernel has two row sets at most (planar_max_queries_per_pass)
   int bpc = blocks_per_cu > 0 ? blocks_per_cu : (fn_ks ? (batch <= 4 ? 1 : 2) : (inter ? 3 : 2));
   if (batch > 4 && bpc > 2) bpc = 2;
   // grid of a launch over `tgs` tile groups
