@@ -1396,6 +1396,20 @@ def setup_kv_and_real_db(cp, device, torch, args, n_keys, arity, value_bytes, q_
                     f"{qps_step} passes a launch) on the server that Server::setup built from the key-value database; `frac` uses the same "
                     "algorithmic bytes as the headline (the reference packing of all N slots)",
         }
+        if pool >= 64:  # the same database with 12 queries per pass (fused batches, 48 a launch)
+            cp.tuning_set("respond.batch_fusion", 1)
+            rb = torch.zeros((48, C), dtype=torch.int32, device="cuda")
+            for k in range(2):
+                srv.respond_batch_device(q_pool[16 * (k % 2):16 * (k % 2) + 48], 48, rb, stream=stream)
+            torch.cuda.synchronize()
+            e0.record(stream)
+            for k in range(6):
+                srv.respond_batch_device(q_pool[16 * (k % 2):16 * (k % 2) + 48], 48, rb, stream=stream)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            real["fused_12_per_pass_us_per_query"] = round(e0.elapsed_time(e1) * 1e3 / (6 * 48), 2)
+            cp.tuning_set("respond.batch_fusion", 0)
+            del rb
         if not args.no_host_path:
             cp.tuning_set("respond.batch_fusion", 1)
             real["respond_host_path"] = host_path_timing(srv, q_pool, N, torch, full=False)

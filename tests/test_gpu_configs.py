@@ -238,7 +238,7 @@ def test_batches_equal_single_responds(cfg, device):
     import chalametpir_amd as cp
 
     f = cfg
-    batch = 11  # one pass of 8 (two A row sets) + one pass of 3 when fused; 11 independent passes in one launch when not
+    batch = 11  # ONE pass on three A row sets when fused (in column windows at these widths); 11 independent passes in one launch when not
     Q = torch.empty((batch, f.N), dtype=torch.int32, device="cuda")
     for i in range(batch):
         device.synth_fill(Q, f.N, 0x5000 + i, offset_words=i * f.N, stream=f.stream)

@@ -472,9 +472,10 @@ def test_random_shapes_every_kernel_order(orc, device):
 
 
 def test_wide_database_fused_batches_go_window_by_window(orc, device):
-    """more columns than the step-major kernel's LDS accumulators hold for a fused batch (8 queries: 1 536 columns): the launch is repeated
-    over column windows; every batch size around the window arithmetic (1 window for 1..3 queries per pass at this width, 2 for 4..8) gives
-    the same responses as single responds, tile-major and step-major dispatch alike"""
+    """more columns than the step-major kernel's LDS accumulators hold for a fused batch (8 queries: 1 536 columns; 12 queries: 640): the
+    launch is repeated over column windows; every batch size around the window arithmetic (1 window for 1..3 queries per pass at this
+    width, 2 for 4..8, more for the 9..12 of three row sets) gives the same responses as single responds, tile-major and step-major
+    dispatch alike"""
     import torch
 
     import chalametpir_amd as cp
@@ -491,7 +492,7 @@ def test_wide_database_fused_batches_go_window_by_window(orc, device):
         Q_dev = torch.from_numpy(Q.view(np.int32)).cuda()
         for ks_major in (1, 2, 0):
             cp.tuning_set("respond.ks_major", ks_major)
-            for k in (1, 2, 3, 4, 5, 8, 9, 16, 19):
+            for k in (1, 2, 3, 4, 5, 8, 9, 12, 13, 16, 19):  # (9..12: one pass on three row sets; 13+: a pass of 12 and the rest)
                 R = torch.full((k, C), -1, dtype=torch.int32, device="cuda")
                 srv.respond_batch_device(Q_dev, k, R, stream=stream)
                 torch.cuda.synchronize()
