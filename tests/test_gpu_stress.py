@@ -41,8 +41,14 @@ def test_server_lifecycle_under_mixed_callers(order, orc, device):
             if time.time() > t_end:
                 break
             D = random_db_matrix(rng, N, C, b)
+            if rnd == 1:  # the middle round: a database with empty rows, served through the slot map (compact.hip) -- the lone pageable
+                D[rng.random(N) < 0.12] = 0  # caller's copy jobs compact, concurrent callers are gathered on the device
             dtc = orc.row_wise_compress(orc.transpose(D), b)
-            srv = cp.Server.from_compressed(dtc, N, b, device=device)
+            if rnd == 1:
+                srv = cp.Server.from_device_matrix(torch.from_numpy(D.view(np.int32)).cuda(), N, C, b, device=device, stream=torch.cuda.current_stream())
+                assert srv.slots_served()[0] < N
+            else:
+                srv = cp.Server.from_compressed(dtc, N, b, device=device)
 
             def want(q):
                 return orc.row_vector_x_compressed_transposed_matrix(q, dtc, N, b)[0]
