@@ -17,13 +17,20 @@ import chalametpir_amd as cp  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=120)
+ap.add_argument("--holes", type=float, default=0.0, help="fraction of the rows of D set to zero (a real encoded database has 0.11): the servers "
+                                                         "then keep only the other rows resident and every path goes through the slot map")
 args = ap.parse_args()
 dev = cp.Device(0)
 N, C, b = 1179648, 940, 9
 stream = torch.cuda.current_stream()
 D = torch.empty((N, C), dtype=torch.int32, device="cuda")
 dev.synth_fill(D, N * C, 0xD, mask=(1 << b) - 1, stream=stream)
+if args.holes > 0:
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    D[torch.rand(N, device="cuda", generator=g) < args.holes] = 0
 srv = cp.Server.from_device_matrix(D, N, C, b, device=dev, stream=stream)
+print("slots served:", srv.slots_served(), flush=True)
 grp, _ = cp.Server.setup_from_matrix(bytes(32), D.cpu().numpy().view(np.uint32), b, devices=[dev] * 5)
 torch.cuda.synchronize()
 
@@ -43,7 +50,7 @@ t_end = time.time() + args.seconds
 rounds = checks = 0
 seed = 0x9000
 while time.time() < t_end:
-    k = 8
+    k = 8 if rounds % 2 == 0 else 13  # (13: a pass of 12 on three row sets + one more)
     Q = torch.empty((k, N), dtype=torch.int32, device="cuda")
     for i in range(k):
         dev.synth_fill(Q, N, seed + i, offset_words=i * N, stream=stream)
@@ -61,6 +68,11 @@ while time.time() < t_end:
             got.append(("batch", fusion, order, R.cpu().numpy().view(np.uint32).copy()))
     cp.tuning_set("respond.batch_fusion", 1)
     cp.tuning_set("respond.interleave_passes", -1)
+    # the in-process group asked on DEVICE pointers (peer exchange + sum kernel on the root)
+    R.fill_(-1)
+    grp.respond_batch_device(Q, k, R, stream=stream)
+    torch.cuda.synchronize()
+    got.append(("group-device", 1, -1, R.cpu().numpy().view(np.uint32).copy()))
     for name, fusion, order, r in got:
         for i in range(k):
             if not np.array_equal(r[i], want[i]):
