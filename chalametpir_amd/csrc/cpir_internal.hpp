@@ -142,6 +142,11 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
 // 32 us per query at 8 per pass) and for single-pass launches (a lone query: 192 against 201 us), the tile-major kernel for one query per
 // pass over many passes; 2 = the step-major kernel wherever it applies; 3 = the
 // step-major kernel or fail: the caller needs every query word read exactly once (a query read in place from page-locked host memory).  r_prezeroed: the caller has zeroed r already.
+// the wide pass: one 8-wave block per CU, up to 24 queries (six A row sets, looped) per stream of the database; slice order only
+constexpr uint32_t CPIR_PLANAR_WIDE_MAX_QUERIES_PER_PASS = 24;
+int launch_respond_planar_wide(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
+                               uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, bool nontemporal,
+                               bool xcd_split);
 bool respond_batch_fusion();
 uint64_t respond_multi_pass_limit_bytes();
 

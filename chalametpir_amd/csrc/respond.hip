@@ -297,6 +297,7 @@ struct Tuning {
   int host_fill_timeout_us = 2000;  // a lone pageable host query: ONE launch polling the copy's progress, each wave for at most this long (0: off)
   int host_zero_copy = 1;          // a lone host query is read by the kernel in place (page-locked memory), not uploaded first
   int ks_major = 1;                // the step-major matrix-core kernel: 0 never, 1 fused batches + lone launches, 2 wherever it applies
+  int wide_min_batch = 13;         // fused batches of at least this many queries go through the wide pass (up to 24 queries per stream of the database); 0 = never
 };
 Tuning g_tuning;
 std::mutex g_tuning_mu;
@@ -377,6 +378,9 @@ extern "C" int cpir_tuning_set(const char* key, int value) {
   } else if (!strcmp(key, "respond.ks_major")) {
     if (value < 0 || value > 3) return CPIR_ERR_INVALID_ARGUMENT;  // 3: as the in-place host path launches it (diagnosis)
     g_tuning.ks_major = value;
+  } else if (!strcmp(key, "respond.wide_min_batch")) {
+    if (value < 0 || value > 1000000) return CPIR_ERR_INVALID_ARGUMENT;
+    g_tuning.wide_min_batch = value;
   } else if (!strcmp(key, "layout.dense")) {
     set_default_dense(value != 0);
   } else if (!strcmp(key, "layout.planar")) {
@@ -429,6 +433,11 @@ uint32_t respond_planar_pass_width(const cpir_dtc_layout& L, uint32_t batch) {
   {
     std::lock_guard<std::mutex> lk(g_tuning_mu);
     t = g_tuning;
+  }
+  // the wide pass: as few passes as 24 queries each allow, all of (almost) the same width -- 32 queries are two passes of 16, not 24 + 8
+  if (t.wide_min_batch > 0 && batch >= (uint32_t)t.wide_min_batch && t.ks_major >= 1) {
+    const uint32_t passes = (batch + CPIR_PLANAR_WIDE_MAX_QUERIES_PER_PASS - 1) / CPIR_PLANAR_WIDE_MAX_QUERIES_PER_PASS;
+    return (batch + passes - 1) / passes;
   }
   const uint32_t passes12 = batch / CPIR_PLANAR_MAX_QUERIES_PER_PASS;
   return planar_max_queries_per_pass(L, passes12 > 1 ? passes12 : 1, t.interleave_passes, t.ks_major);
@@ -484,6 +493,9 @@ int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout
     std::lock_guard<std::mutex> lk(g_tuning_mu);
     t = g_tuning;
   }
+  // a pass of more queries than the step-major kernel's three row sets: the wide pass (also below that where the tuning asks for it)
+  if (L.packing == CPIR_PACK_PLANAR && (batch > CPIR_PLANAR_MAX_QUERIES_PER_PASS || (t.wide_min_batch > 0 && batch >= (uint32_t)t.wide_min_batch)))
+    return launch_respond_planar_wide(dev, dtc, L, q, q_len, q_slot_offset, batch, passes, r, stream, t.nontemporal != 0, t.xcd_split != 0);
   if (L.packing == CPIR_PACK_PLANAR)  // the matrix-core path (respond_planar.hip)
     return launch_respond_planar(dev, dtc, L, q, q_len, q_slot_offset, batch, passes, r, stream, t.planar_blocks_per_cu, t.nontemporal != 0,
                                  t.xcd_split != 0, t.interleave_passes, t.ks_major);

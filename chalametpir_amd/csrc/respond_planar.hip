@@ -659,6 +659,283 @@ respond_planar_ks_kernel(const PlanarArgs a) {
   flush_pass(pass, false);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The WIDE pass (round 4): up to 24 queries answered by ONE stream of the database.
+//
+// What bounds a fused pass is the LDS, not the matrix cores (three row sets keep them 27 % busy): a query costs 2 KiB of A fragments per
+// step and 4 bytes per column of accumulators, and the step-major kernel above runs TWO 4-wave blocks per CU, each with its own
+// double-buffered fragments -- 12 queries per pass, and at 2^20 keys x 1 kB only in two column windows, i.e. the 12 queries are gathered
+// twice.  Here ONE 8-wave block owns the CU's whole LDS: single-buffered fragments (6 row sets x 8 KiB) + the accumulators of up to 24
+// queries x 1 024 columns (96 KiB).  Same walk (512-slot steps, contiguous units split evenly over the blocks, slot axis split over the
+// XCDs), same arithmetic, same packed image, same responses bit for bit; differences to the kernel above:
+//   * a unit is a step x 8 column tiles (one per wave); PlanarArgs::tg_lo / tg_n count groups of EIGHT tiles here;
+//   * every wave gathers ONE k-block (64 slots) of all row sets: one 16-byte load per lane and row set (a row set's four query rows x
+//     256 contiguous bytes), parked in the fragment slab it is about to fill and read back in fragment order, as above;
+//   * the row sets are a LOOP (their number is a run-time value, the tile stays in registers and is multiplied by one set after the
+//     other, two accumulators live at a time), not an unrolled dimension: 6 sets unrolled would need ~400 VGPRs;
+//   * fragments are single-buffered: the step's last unit ends with barrier / build the next step's fragments from registers (their
+//     loads were issued in the step's first unit) / barrier; the next tile's loads are in flight across both.
+constexpr int kWThreads = 512;
+constexpr int kWM = 8;        // column tiles per work unit = waves per block
+constexpr int kWMaxSets = 6;  // row sets of 4 queries
+
+template <int HB, bool NT>
+__global__ void __launch_bounds__(kWThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+respond_planar_wide_kernel(const PlanarArgs a) {
+  constexpr int NL = 8 + HB;
+  constexpr int ST16 = NL * 64;
+  extern __shared__ uint4 wsm[];
+  const uint32_t nq = a.q_per_pass;
+  const uint32_t ns = (nq + 3) >> 2;                                    // row sets in use (1..6)
+  uint4* const abuf = wsm;                                             // [ns][8 k-blocks][64 lanes]: A fragments of the current step
+  uint32_t* const qs = reinterpret_cast<uint32_t*>(wsm + ns * 512);    // [parity of the step][32]: per query, the sum of the step's query words
+  uint32_t* const racc = qs + 64;                                      // [query of the pass][padded column of the window]
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const uint32_t cl = lane & 15;
+  const uint32_t grp = lane >> 4;
+  const uint32_t cpad = a.tg_n * (kWM * 16);
+
+  const uint32_t nx = a.nx;
+  const uint32_t xcd = blockIdx.x % nx;
+  const uint32_t j = blockIdx.x / nx;
+  const uint32_t nb = gridDim.x / nx;  // host guarantees gridDim.x % nx == 0
+  const uint32_t ks_len = a.ks_hi - a.ks_lo;
+  const uint32_t kb0 = a.ks_lo + (uint32_t)(((uint64_t)ks_len * xcd) / nx);
+  const uint32_t ke0 = a.ks_lo + (uint32_t)(((uint64_t)ks_len * (xcd + 1)) / nx);
+  const uint32_t TG = a.tg_n;
+  // visits (step, first tile group, one past the last): units u = (step kb0 + u / TG, tile group u % TG) split evenly over the blocks
+  const uint64_t units = (uint64_t)TG * (ke0 - kb0);
+  const uint64_t sb = units * j / nb, se = units * (j + 1) / nb;
+  const uint32_t n_visits = se > sb ? (uint32_t)((se - 1) / TG - sb / TG + 1) : 0;
+  if (n_visits == 0) return;  // block-uniform: an idle block takes part in nothing
+  const uint32_t first_ks = kb0 + (uint32_t)(sb / TG), first_tg0 = (uint32_t)(sb % TG), last_tg1 = (uint32_t)((se - 1) % TG) + 1;
+  auto visit_ks = [=](uint32_t v) { return first_ks + v; };
+  auto visit_tg0 = [=](uint32_t v) { return v == 0 ? first_tg0 : 0u; };
+  auto visit_tg1 = [=](uint32_t v) { return v + 1 == n_visits ? last_tg1 : TG; };
+
+  const uint32_t limb = cl & 3;
+  const uint32_t sel01 = limb | ((4 + limb) << 8);
+  const uint4* const tiles = reinterpret_cast<const uint4*>(a.dtc);
+  const uint32_t rr = lane >> 4, l16 = lane & 15;  // as a LOADER of query words: row of the set, 16-byte piece of the wave's 64 slots
+
+  auto guarded_step = [&](uint32_t ks_) __attribute__((always_inline)) {
+    const uint64_t slot0 = (uint64_t)ks_ * CPIR_PLANAR_SLOTS_PER_TILE;
+    return a.q_scalar || slot0 + CPIR_PLANAR_SLOTS_PER_TILE > a.num_slots || a.q_slot_offset + slot0 + CPIR_PLANAR_SLOTS_PER_TILE > a.q_len;
+  };
+  auto a_issue = [&](uint4(&raw)[kWMaxSets], uint32_t ks_, uint32_t pass_) __attribute__((always_inline)) {
+    const uint64_t base = (uint64_t)ks_ * CPIR_PLANAR_SLOTS_PER_TILE + wave * 64 + l16 * 4;
+#pragma unroll
+    for (int s = 0; s < kWMaxSets; s++) {
+      raw[s] = make_uint4(0, 0, 0, 0);
+      const uint32_t row = 4 * s + rr;
+      if (row < nq) raw[s] = *reinterpret_cast<const uint4*>(a.q + ((uint64_t)pass_ * nq + row) * a.q_len + a.q_slot_offset + base);
+    }
+  };
+  auto wave_lds_fence = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  // this wave's sum of the query words of its k-block, per query: counted once by the limb-0 lane of every 16-slot group, the four groups
+  // added up with two shuffles, added to the step's sum by lane (group 0, limb 0).  The sums of a step live in qs[parity of the step]:
+  // zeroed while the step BEFORE is being multiplied (after the barrier that ended its build, when the last reader of that half is
+  // long gone), added to between the two barriers of the build, read -- one word per row set and tile -- until the next build.
+  auto store_ksum = [&](uint32_t part, int s, int par) __attribute__((always_inline)) {
+    uint32_t v = part;
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    const uint32_t query = 4 * s + (cl >> 2);
+    if (grp == 0 && limb == 0 && query < nq) atomicAdd(&qs[par * 32 + query], v);
+  };
+  auto a_finish = [&](const uint4(&raw)[kWMaxSets], int par) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < kWMaxSets; s++) {
+      if ((uint32_t)s < ns) {  // block-uniform
+        uint32_t* const stage = reinterpret_cast<uint32_t*>(abuf + (s * 8 + wave) * 64);  // 4 rows x 64 words: this wave's slab of the set
+        *reinterpret_cast<uint4*>(stage + rr * 64 + l16 * 4) = raw[s];
+        wave_lds_fence();
+        uint4 back[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++) back[d] = *reinterpret_cast<const uint4*>(stage + (cl >> 2) * 64 + grp * 16 + d * 4);
+        wave_lds_fence();
+        const bool arow = 4 * s + (cl >> 2) < nq;
+        uint32_t part = 0, o[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+          const uint4 t = back[d];
+          part += (t.x + t.y) + (t.z + t.w);
+          const uint32_t v = gather_limb(t.x, t.y, t.z, t.w, sel01) ^ 0x80808080u;
+          o[d] = arow ? v : 0u;
+        }
+        abuf[(s * 8 + wave) * 64 + lane] = make_uint4(o[0], o[1], o[2], o[3]);
+        store_ksum(part, s, par);
+      }
+    }
+  };
+  auto a_guarded = [&](uint32_t ks_, uint32_t pass_, int par) __attribute__((always_inline)) {
+    const uint64_t base = (uint64_t)ks_ * CPIR_PLANAR_SLOTS_PER_TILE + wave * 64 + grp * 16;
+    for (uint32_t s = 0; s < ns; s++) {
+      const uint32_t query = 4 * s + (cl >> 2);
+      const bool arow = query < nq;
+      const uint32_t* qrow = a.q + ((uint64_t)pass_ * nq + (arow ? query : 0)) * a.q_len + a.q_slot_offset;
+      uint32_t part = 0, o[4];
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const uint64_t n = base + d * 4 + e;
+          const bool ok = n < a.num_slots && a.q_slot_offset + n < a.q_len;
+          const uint32_t x = ok ? qrow[n] : 0u;
+          part += x;
+          w[e] = ok ? (x ^ 0x80808080u) : 0u;
+        }
+        o[d] = arow ? gather_limb(w[0], w[1], w[2], w[3], sel01) : 0u;
+      }
+      abuf[(s * 8 + wave) * 64 + lane] = make_uint4(o[0], o[1], o[2], o[3]);
+      store_ksum(part, (int)s, par);
+    }
+  };
+  auto load_tile = [&](uint4(&dst)[NL], uint32_t tg_, uint32_t ks_) __attribute__((always_inline)) {
+    const uint32_t T = (a.tg_lo + tg_) * kWM + wave;
+    const uint4* p = tiles + (T < a.col_tiles ? ((uint64_t)T * a.ks_total + ks_) * ST16 : 0) + lane;
+#pragma unroll
+    for (int i = 0; i < NL; i++) dst[i] = load16<NT>(p + i * 64);
+  };
+  const uint64_t room = a.q_len > a.q_slot_offset ? a.q_len - a.q_slot_offset : 0;
+  const uint64_t nvalid_total = a.num_slots < room ? a.num_slots : room;
+  auto valid_slots = [&](uint32_t ks_) __attribute__((always_inline)) -> uint32_t {
+    const uint64_t lo = (uint64_t)ks_ * CPIR_PLANAR_SLOTS_PER_TILE;
+    if (lo >= nvalid_total) return 0u;
+    const uint64_t left = nvalid_total - lo;
+    return left < CPIR_PLANAR_SLOTS_PER_TILE ? (uint32_t)left : CPIR_PLANAR_SLOTS_PER_TILE;
+  };
+
+  const uint32_t rtotal = nq * cpad;
+  for (uint32_t i = threadIdx.x; i < rtotal; i += kWThreads) racc[i] = 0;
+  if (threadIdx.x < 64) qs[threadIdx.x] = 0;
+  __syncthreads();  // (the first build adds to the sums)
+  const uint32_t fstart = (uint32_t)(((uint64_t)blockIdx.x * rtotal) / gridDim.x) & ~63u;  // every block starts its round at an offset of its own
+  auto flush_pass = [&](uint32_t of_pass, bool zero) __attribute__((always_inline)) {
+    for (uint32_t cursor = threadIdx.x; cursor < rtotal; cursor += kWThreads) {
+      uint32_t i2 = cursor + fstart;
+      if (i2 >= rtotal) i2 -= rtotal;
+      const uint32_t query = i2 / cpad, col = a.tg_lo * (kWM * 16) + i2 % cpad, val = racc[i2];
+      if (zero) racc[i2] = 0;
+      if (col < a.num_cols && val) atomicAdd(a.r + ((uint64_t)of_pass * nq + query) * a.num_cols + col, val);
+    }
+  };
+
+  // prologue: the first tile, the fragments of the first visit's step of pass 0
+  uint32_t pass = 0, v = 0;
+  uint32_t cks = visit_ks(0), ctg1 = visit_tg1(0);
+  uint32_t tg = visit_tg0(0);
+  uint4 b0[NL], b1[NL];
+  uint4 raw[kWMaxSets];
+  load_tile(b0, tg, cks);
+  if (guarded_step(cks)) {
+    a_guarded(cks, 0, 0);
+  } else {
+    a_issue(raw, cks, 0);
+    a_finish(raw, 0);
+  }
+  __syncthreads();
+
+  int par = 0;  // parity of the current step's sums
+  bool first_of_visit = true;
+  bool done = false;
+  auto unit = [&](uint4(&cur)[NL], uint4(&nxt)[NL]) __attribute__((always_inline)) {
+    const uint32_t ks = cks;
+    const bool last_of_visit = tg + 1 == ctg1;
+    const bool pass_ends = v + 1 == n_visits;
+    const bool more_visits = !pass_ends || pass + 1 < a.passes;
+    const uint32_t nv = pass_ends ? 0u : v + 1, npass = pass_ends ? pass + 1 : pass;
+    const uint32_t nks = visit_ks(nv);
+    const bool last = last_of_visit && !more_visits;
+    const uint32_t tg_n = last_of_visit ? visit_tg0(nv) : tg + 1, ks_n = last_of_visit ? nks : ks;
+    const bool g_n = more_visits && guarded_step(nks);
+    // the next visit's query words: requested now, a whole visit ahead of their use (L2 / HBM)
+    if (first_of_visit && more_visits && !g_n) a_issue(raw, nks, npass);
+    if (first_of_visit && threadIdx.x < 32) qs[(par ^ 1) * 32 + threadIdx.x] = 0;  // the next step's sums start from zero
+    load_tile(nxt, last ? tg : tg_n, last ? ks : ks_n);  // always issued (the very last unit asks for its own tile again), see above
+    const uint32_t Tw = tg * kWM + wave;      // tile of the window (indexes the LDS accumulators)
+    const uint32_t T = a.tg_lo * kWM + Tw;    // tile of the image
+    if (T < a.col_tiles) {
+      v4i hbv[HB > 0 ? 8 : 1];
+      if constexpr (HB > 0) {
+#pragma unroll
+        for (int kb = 0; kb < 8; kb++)
+#pragma unroll
+          for (int d = 0; d < 4; d++) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int p = 0; p < HB; p++) x += ((comp(cur[8 + p], kb >> 1) >> (4 * (kb & 1) + d)) & 0x01010101u) << p;
+            hbv[kb][d] = (int)x;
+          }
+      }
+      const uint32_t nvs = valid_slots(ks);
+      const uint32_t base_term = ((ks == 0 && a.colsum) ? 0x80808080u * a.colsum[T * 16 + cl] : 0u) - 0x40404000u * nvs;
+      uint32_t* const rcol = racc + Tw * 16 + cl;
+      // The row sets one after the other: 16 MFMAs each on the fragments in f[], every fragment register refilled with the NEXT set's
+      // fragment of the same k-block right behind the two MFMAs that read it -- a read is issued eight MFMA pairs (256 cycles of
+      // matrix-core issue) before its use.  (With the reads in front of their MFMAs, two by two, a set cost four LDS round trips: 32 us
+      // per set and pass at 2^20 keys against 16 us of matrix-core issue.  A second full set of registers -- all eight reads in front
+      // of the set -- does not fit: 18 to 39 VGPRs spilled.)  The last set re-reads itself: no condition in the loop.
+      uint4 f[8];
+#pragma unroll
+      for (int kb = 0; kb < 8; kb++) f[kb] = abuf[kb * 64 + lane];
+#pragma unroll 1
+      for (uint32_t s = 0; s < ns; s++) {
+        const uint4* const ap = abuf + (s + 1 < ns ? s + 1 : s) * 512 + lane;
+        // no branch around the rows of a partly filled last set: they add 0 to the last query's word (their fragments are 0)
+        const uint32_t query = 4 * s + grp, qq = query < nq ? query : nq - 1;
+        const uint32_t qsum = qs[par * 32 + qq];  // (requested in front of the MFMAs, used behind them)
+        v4i acc_lo = v4i{0, 0, 0, 0}, acc_hi = v4i{0, 0, 0, 0};
+#pragma unroll
+        for (int kb = 0; kb < 8; kb++) {
+          acc_lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(as_v4i(f[kb]), as_v4i(cur[kb]), acc_lo, 0, 0, 0);
+          if constexpr (HB > 0) acc_hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(as_v4i(f[kb]), hbv[kb], acc_hi, 0, 0, 0);
+          f[kb] = ap[kb * 64];
+        }
+        uint32_t val = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) val += ((uint32_t)acc_lo[i] + ((uint32_t)acc_hi[i] << 8)) << (8 * i);
+        val += 128u * qsum + base_term;  // 128 * 0x80808080 = 0x40404000 mod 2^32
+        atomicAdd(rcol + qq * cpad, query < nq ? val : 0u);  // LDS; this wave owns tile T of the step
+      }
+    }
+    first_of_visit = false;
+    if (last_of_visit) {
+      if (more_visits) {
+        __syncthreads();  // everybody is done with this step's fragments (and, at a pass boundary, with accumulating this pass)
+        if (pass_ends) {
+          flush_pass(pass, true);  // (nobody accumulates for the next pass before the barrier below)
+          pass = npass;
+        }
+        if (!g_n) a_finish(raw, par ^ 1);
+        else a_guarded(nks, npass, par ^ 1);
+        __syncthreads();  // the next step's fragments are complete
+        par ^= 1;
+        first_of_visit = true;
+        v = nv, cks = nks, ctg1 = visit_tg1(v);
+      } else {
+        done = true;
+      }
+    }
+    tg = tg_n;
+  };
+  while (!done) {
+    unit(b0, b1);
+    if (done) break;
+    unit(b1, b0);
+  }
+
+  __syncthreads();
+  flush_pass(pass, false);
+}
+
 // r[q][c] += 128 * sum_n (q[n] - 0x80808080) over this block's slice of the valid slots, and (slice 0 only) += 0x80808080 * colsum[c]:
 // the two correction terms of the signed-byte split (top of the file).  r was zeroed on the stream before; all updates are u32
 // atomic adds, so their order against the main kernel's does not matter.
@@ -724,6 +1001,22 @@ KernelFn pick_ks_hb(uint32_t hb, bool nt) {
 KernelFn pick_ks(uint32_t hb, uint32_t batch, bool nt) {
   return batch <= 4 ? pick_ks_hb<1>(hb, nt) : (batch <= 8 ? pick_ks_hb<2>(hb, nt) : pick_ks_hb<3>(hb, nt));
 }
+
+KernelFn pick_wide(uint32_t hb, bool nt) {
+  switch (hb) {
+    case 0: return nt ? respond_planar_wide_kernel<0, true> : respond_planar_wide_kernel<0, false>;
+    case 1: return nt ? respond_planar_wide_kernel<1, true> : respond_planar_wide_kernel<1, false>;
+    case 2: return nt ? respond_planar_wide_kernel<2, true> : respond_planar_wide_kernel<2, false>;
+    case 3: return nt ? respond_planar_wide_kernel<3, true> : respond_planar_wide_kernel<3, false>;
+    case 4: return nt ? respond_planar_wide_kernel<4, true> : respond_planar_wide_kernel<4, false>;
+    case 5: return nt ? respond_planar_wide_kernel<5, true> : respond_planar_wide_kernel<5, false>;
+    case 6: return nt ? respond_planar_wide_kernel<6, true> : respond_planar_wide_kernel<6, false>;
+    default: return nullptr;
+  }
+}
+
+// LDS of a wide block: everything a CU has but a margin (the kernel has no static LDS)
+constexpr uint32_t kWideLdsBudget = 156u << 10;
 
 }  // namespace
 
@@ -855,6 +1148,74 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
   hipLaunchKernelGGL(planar_init_kernel, dim3(nq * split), dim3(kThreads), 0, stream, q, q_len, q_slot_offset, L.num_slots, colsum,
                      L.num_cols, r, split, range_lo, range_hi);
   hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(kThreads), 0, stream, a);
+  CPIR_HIP_TRY(hipGetLastError());
+  return CPIR_OK;
+}
+
+// The wide pass (respond_planar_wide_kernel): `passes` passes of `batch` (1..CPIR_PLANAR_WIDE_MAX_QUERIES_PER_PASS) queries each, one 8-wave
+// block per CU; a database whose accumulators do not fit beside the fragments is answered in column windows of whole groups of 8 tiles.
+int launch_respond_planar_wide(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
+                               uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, bool nontemporal,
+                               bool xcd_split) {
+  if (L.packing != CPIR_PACK_PLANAR || batch == 0 || batch > CPIR_PLANAR_WIDE_MAX_QUERIES_PER_PASS || passes == 0) return CPIR_ERR_INVALID_ARGUMENT;
+  const uint32_t hb = planar_hi_planes(L.mat_elem_bit_len);
+  KernelFn fn = pick_wide(hb, nontemporal);
+  if (!fn || L.chunk_words != (8 + hb) * 256 || L.rows_padded % 16 != 0) return CPIR_ERR_INVALID_ARGUMENT;
+  const uint64_t ks_total = (L.num_slots + CPIR_PLANAR_SLOTS_PER_TILE - 1) / CPIR_PLANAR_SLOTS_PER_TILE;
+  if (ks_total > 0xffffffffull || ks_total * (L.chunk_words / 16) != L.words_per_row_padded) return CPIR_ERR_INVALID_ARGUMENT;
+
+  PlanarArgs a;
+  a.dtc = dtc;
+  a.q = q;
+  a.r = r;
+  a.q_len = q_len;
+  a.q_slot_offset = q_slot_offset;
+  a.num_slots = L.num_slots;
+  a.num_cols = L.num_cols;
+  a.col_tiles = L.rows_padded / 16;
+  a.tile_groups = (a.col_tiles + kWM - 1) / kWM;  // groups of EIGHT tiles here
+  a.ks_total = (uint32_t)ks_total;
+  a.ks_lo = 0, a.ks_hi = (uint32_t)ks_total;
+  a.q_per_pass = batch;
+  a.passes = passes;
+  a.interleave = 0;
+  a.q_far = 0;
+  a.strided = 0;
+  a.progress = nullptr;
+  a.abort_flag = nullptr;
+  a.poll_ticks = 0;
+  a.q_scalar = (reinterpret_cast<uintptr_t>(q) % 16 != 0 || q_slot_offset % 4 != 0 || (batch * passes > 1 && q_len % 4 != 0)) ? 1u : 0u;
+  a.colsum = dtc + (uint64_t)L.rows_padded * L.words_per_row_padded;
+
+  const uint32_t ns = (batch + 3) / 4;
+  const uint32_t fixed = ns * (8u << 10) + 256u;                                        // fragments + per-step query sums (two parities x 32)
+  const uint32_t per_tg = batch * (kWM * 16) * (uint32_t)sizeof(uint32_t);              // accumulators of one group of 8 tiles
+  const uint32_t max_tg = (kWideLdsBudget - fixed) / per_tg;                            // 8 groups (1 024 columns) for 24 queries
+  if (max_tg == 0) return CPIR_ERR_INVALID_ARGUMENT;
+  const uint32_t windows = (a.tile_groups + max_tg - 1) / max_tg;
+  const uint32_t tg_per_window = (a.tile_groups + windows - 1) / windows;
+
+  // (up to 156 KiB of dynamic LDS: say so once per instantiation; a runtime that does not know the attribute is not an error)
+  static std::atomic<bool> lds_raised[7][2];
+  if (!lds_raised[hb][nontemporal ? 1 : 0].exchange(true, std::memory_order_relaxed)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLdsBudget) != hipSuccess) (void)hipGetLastError();
+  }
+  CPIR_HIP_TRY(hipMemsetAsync(r, 0, (size_t)batch * passes * L.num_cols * sizeof(uint32_t), stream));
+  for (uint32_t w = 0; w < windows; w++) {
+    a.tg_lo = w * tg_per_window;
+    if (a.tg_lo >= a.tile_groups) break;
+    a.tg_n = a.tile_groups - a.tg_lo < tg_per_window ? a.tile_groups - a.tg_lo : tg_per_window;
+    const uint64_t units = (uint64_t)a.tg_n * ks_total;
+    uint64_t grid = (uint64_t)dev->num_cus;  // one block per CU
+    a.nx = (xcd_split && ks_total >= 8 && grid % 8 == 0) ? 8u : 1u;
+    if (grid > units) {
+      grid = units;
+      if (a.nx == 8) grid = (grid / 8) * 8;
+      if (grid == 0) grid = 1, a.nx = 1;
+    }
+    const size_t lds = (size_t)fixed + (size_t)a.tg_n * per_tg;
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(kWThreads), lds, stream, a);
+  }
   CPIR_HIP_TRY(hipGetLastError());
   return CPIR_OK;
 }

@@ -255,7 +255,10 @@ int cpir_op_synth_fill(cpir_device* dev, uint32_t* out, uint64_t count, uint64_t
  *   (order in which one launch walks its passes; -1 = by shard size), "respond.planar_blocks_per_cu" 0..8, "respond.multi_pass_limit_mb"
  *   (unfused batches on databases above this size get one launch per query), "respond.ks_major" 0..3 (which launches of the
  *   matrix-core respond take the step-major kernel: 0 none, 1 -- the default -- single-pass launches, fused batches and queries
- *   beyond 8 MiB, 2 every launch it applies to, 3 as 2 but failing where it does not apply), "respond.host_zero_copy" {0,1}
+ *   beyond 8 MiB, 2 every launch it applies to, 3 as 2 but failing where it does not apply), "respond.wide_min_batch" (fused batches
+ *   of at least this many queries are cut into passes of up to 24 queries that share ONE stream of the database -- the wide pass, one
+ *   8-wave block per CU; default 13, i.e. whatever the step-major kernel's 12 queries per pass cannot take in one pass; 0: never),
+ *   "respond.host_zero_copy" {0,1}
  *   (1, the default: cpir_server_respond serves a caller that finds the server idle without an upload, the kernel reading the
  *   query in place from page-locked host memory; 0: always stage + upload first), "respond.host_fill_timeout_us" 0..1000000
  *   (a lone PAGEABLE query of 2^19+ words: one launch in front of the copy into pinned memory, every wave waiting at most this long

@@ -1,0 +1,164 @@
+"""GPU parity of the WIDE pass (respond_planar_wide_kernel): up to 24 queries answered by one stream of the packed database, one 8-wave
+block per CU, the A row sets walked in a loop, single-buffered fragments.
+
+The reference answers one query at a time (`server.rs:184-190` -> `matrix.rs:328-485`); the property is that every query of a fused
+batch gets exactly the response the oracle computes for it alone, whatever the batch size, the width of the database, the alignment of
+the query buffers or the number of passes in the launch."""
+import numpy as np
+import pytest
+
+from _cases import cf_of, random_db_matrix, random_query
+
+pytestmark = pytest.mark.gpu
+
+
+def _responses(orc, Q, dtc, N, b):
+    return np.stack([orc.row_vector_x_compressed_transposed_matrix(q, dtc, N, b)[0] for q in Q])
+
+
+@pytest.mark.parametrize("b", [4, 8, 9, 10, 11, 12, 13, 14])
+def test_every_batch_size_through_the_wide_pass(b, orc, device):
+    """respond.wide_min_batch = 1 sends EVERY fused pass through the wide kernel (1 .. 24 queries: one to six row sets, the last one
+    partly filled), default 13 only the batches the step-major kernel's three row sets cannot take; every plane count (b = 4 .. 14);
+    N ragged (the last step is guarded), more than one visit per block"""
+    import torch
+
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(2400 + b)
+    stream = torch.cuda.current_stream()
+    N, C = 5 * 512 * 3 + 129, 150  # 16 steps, the last with 129 valid slots; 10 column tiles = 2 groups of 8
+    D = random_db_matrix(rng, N, C, b)
+    dtc = orc.row_wise_compress(orc.transpose(D), b)
+    srv = cp.Server.from_compressed(dtc, N, b, device=device)
+    nq = 50
+    Q = np.stack([random_query(rng, N) for _ in range(nq)])
+    want = _responses(orc, Q, dtc, N, b)
+    Q_dev = torch.from_numpy(Q.view(np.int32)).cuda()
+    try:
+        for wide_min in (1, 13):
+            cp.tuning_set("respond.wide_min_batch", wide_min)
+            for k in list(range(1, 27)) + [31, 32, 33, 47, 48, 49, 50]:
+                R = torch.full((k, C), -1, dtype=torch.int32, device="cuda")
+                srv.respond_batch_device(Q_dev, k, R, stream=stream)
+                torch.cuda.synchronize()
+                assert np.array_equal(R.cpu().numpy().view(np.uint32), want[:k]), (b, wide_min, k)
+        # switched off: the same answers from passes of 12
+        cp.tuning_set("respond.wide_min_batch", 0)
+        R = torch.full((nq, C), -1, dtype=torch.int32, device="cuda")
+        srv.respond_batch_device(Q_dev, nq, R, stream=stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(R.cpu().numpy().view(np.uint32), want)
+    finally:
+        cp.tuning_set("respond.wide_min_batch", 13)
+        srv.close()
+
+
+def test_wide_pass_guarded_queries_shards_and_extreme_words(orc, device):
+    """the guarded paths: query rows that are only 4-byte aligned (N % 4 == 3: every row but the first), a buffer shifted by one word, a
+    shard that starts at an odd slot and ends inside a packing unit; all-ones and all-0x80 query words and maximal database entries
+    (the signed-byte split's corner values)"""
+    import torch
+
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(2424)
+    stream = torch.cuda.current_stream()
+    for b in (9, 12, 6):
+        cf = cf_of(b)
+        N, C = 3 * 1024 * cf + 7, 37
+        D = random_db_matrix(rng, N, C, b)
+        D[5] = (1 << b) - 1
+        D[:, 3] = (1 << b) - 1
+        dtc = orc.row_wise_compress(orc.transpose(D), b)
+        srv = cp.Server.from_compressed(dtc, N, b, device=device)
+        nq = 24
+        Q = np.stack([random_query(rng, N) for _ in range(nq)])
+        Q[1] = 0xFFFFFFFF
+        Q[2] = 0x80808080
+        Q[3] = 0x7F7F7F7F
+        Q[4] = 0
+        want = _responses(orc, Q, dtc, N, b)
+        Q_dev = torch.from_numpy(Q.view(np.int32)).cuda()
+        for k in (13, 17, 24):
+            R = torch.full((k, C), -1, dtype=torch.int32, device="cuda")
+            srv.respond_batch_device(Q_dev, k, R, stream=stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(R.cpu().numpy().view(np.uint32), want[:k]), (b, k)
+        # the whole block of queries shifted by 1..3 words
+        buf = torch.zeros(nq * N + 8, dtype=torch.int32, device="cuda")
+        for shift in (1, 2, 3):
+            buf[shift:shift + nq * N] = Q_dev.reshape(-1)
+            R = torch.full((nq, C), -1, dtype=torch.int32, device="cuda")
+            srv.respond_batch_device(buf[shift:shift + nq * N].view(nq, N), nq, R, stream=stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(R.cpu().numpy().view(np.uint32), want), (b, shift)
+        lo, hi = 1027, N - 5
+        D_dev = torch.from_numpy(np.ascontiguousarray(D[lo:hi]).view(np.int32)).cuda()
+        shard = cp.Server.from_device_matrix(D_dev, hi - lo, C, b, device=device, slot_offset=lo, total_slots=N)
+        dtc_shard = orc.row_wise_compress(orc.transpose(D[lo:hi]), b)
+        want_part = _responses(orc, Q[:, lo:hi], dtc_shard, hi - lo, b)
+        part = torch.full((nq, C), -1, dtype=torch.int32, device="cuda")
+        shard.respond_batch_device(Q_dev, nq, part, stream=stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(part.cpu().numpy().view(np.uint32), want_part), b
+        shard.close()
+        srv.close()
+
+
+def test_wide_pass_over_column_windows(orc, device):
+    """24 queries x 1 024 columns of accumulators fill the CU's LDS: a wider database is answered window by window (whole groups of 8
+    column tiles), each a launch over all steps; 3 100 columns = 194 tiles = 25 groups -> 4 windows at 24 queries, fewer for fewer"""
+    import torch
+
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(3100)
+    stream = torch.cuda.current_stream()
+    for b, N, C in ((9, 2 * 512 + 77, 3100), (6, 700, 1601)):
+        D = random_db_matrix(rng, N, C, b)
+        dtc = orc.row_wise_compress(orc.transpose(D), b)
+        srv = cp.Server.from_compressed(dtc, N, b, device=device)
+        nq = 48
+        Q = np.stack([random_query(rng, N) for _ in range(nq)])
+        want = _responses(orc, Q, dtc, N, b)
+        Q_dev = torch.from_numpy(Q.view(np.int32)).cuda()
+        for k in (13, 14, 16, 20, 24, 25, 36, 48):
+            R = torch.full((k, C), -1, dtype=torch.int32, device="cuda")
+            srv.respond_batch_device(Q_dev, k, R, stream=stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(R.cpu().numpy().view(np.uint32), want[:k]), (b, k)
+        srv.close()
+
+
+def test_wide_pass_on_a_compacted_database_and_a_group(orc, device):
+    """rows that hold nothing are left out of the image (compact.hip): the queries are gathered onto the kept slots in front of the wide
+    pass; a group of shards answers the same batch through its device exchange"""
+    import torch
+
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(777)
+    stream = torch.cuda.current_stream()
+    b, C, N = 9, 61, 21504 * 2 + 333
+    D = random_db_matrix(rng, N, C, b)
+    D[rng.random(N) < 0.2] = 0
+    seed = rng.bytes(32)
+    _, dtc = orc.server_setup_from_matrix(seed, D, b)
+    srv, _ = cp.Server.setup_from_matrix(seed, D, b, device=device)
+    grp, _ = cp.Server.setup_from_matrix(seed, D, b, devices=[device] * 2)
+    try:
+        assert srv.slots_served()[0] < N
+        nq = 30
+        Q = np.stack([random_query(rng, N) for _ in range(nq)])
+        want = _responses(orc, Q, dtc, N, b)
+        Q_dev = torch.from_numpy(Q.view(np.int32)).cuda()
+        for h in (srv, grp):
+            for k in (13, 24, 30):
+                R = torch.full((k, C), -1, dtype=torch.int32, device="cuda")
+                h.respond_batch_device(Q_dev, k, R, stream=stream)
+                torch.cuda.synchronize()
+                assert np.array_equal(R.cpu().numpy().view(np.uint32), want[:k]), k
+    finally:
+        srv.close()
+        grp.close()
