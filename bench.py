@@ -384,8 +384,8 @@ def main() -> int:
     # headline, never as the headline: the headline streams the whole database for every single query
     if world == 1 and not args.headline_only:
         cp.tuning_set("respond.batch_fusion", 1)
-        per_pass = 12 if full_layout.packing == 2 else 4  # planar: the step-major kernel's three row sets of 4 queries
-        nbq = per_pass * 4 if pool >= per_pass * 4 + 16 else qps_step  # 4 full passes a launch where the pool allows it (default: 48 of 64)
+        nbq = 48 if pool >= 64 else qps_step  # 48 queries a launch where the pool allows it (default: 48 of 64)
+        per_pass = cp.respond_batch_pass_width(full_layout, nbq)  # planar: 2 wide passes of 24 (the library says how it cuts the batch)
         rb = torch.zeros((nbq, C), dtype=torch.int32, device="cuda")
 
         def fused_step(k):
@@ -408,8 +408,9 @@ def main() -> int:
             "queries_per_launch": nbq,
             "queries_per_sec": round(1e6 / fused_us, 1),
             "us_per_query": round(fused_us, 2),
-            "note": "cpir_server_respond_batch_device with batch fusion: the queries of a pass share one stream of the packed DB (planar: up to 12 per "
-                    "pass on three row sets of the i8 matrix cores); same results bit for bit",
+            "note": "cpir_server_respond_batch_device with batch fusion: the queries of a pass share one stream of the packed DB (planar: up to 24 per "
+                    "pass -- the wide pass, six row sets of the i8 matrix cores walked by one 8-wave block per CU; 12 per pass up to round 4's "
+                    "step-major kernel alone); same results bit for bit",
         }
         del rb
         cp.tuning_set("respond.batch_fusion", 0)
@@ -1396,7 +1397,7 @@ def setup_kv_and_real_db(cp, device, torch, args, n_keys, arity, value_bytes, q_
                     f"{qps_step} passes a launch) on the server that Server::setup built from the key-value database; `frac` uses the same "
                     "algorithmic bytes as the headline (the reference packing of all N slots)",
         }
-        if pool >= 64:  # the same database with 12 queries per pass (fused batches, 48 a launch)
+        if pool >= 64:  # the same database with fused batches, 48 queries a launch (planar: two wide passes of 24)
             cp.tuning_set("respond.batch_fusion", 1)
             rb = torch.zeros((48, C), dtype=torch.int32, device="cuda")
             for k in range(2):
@@ -1407,7 +1408,8 @@ def setup_kv_and_real_db(cp, device, torch, args, n_keys, arity, value_bytes, q_
                 srv.respond_batch_device(q_pool[16 * (k % 2):16 * (k % 2) + 48], 48, rb, stream=stream)
             e1.record(stream)
             torch.cuda.synchronize()
-            real["fused_12_per_pass_us_per_query"] = round(e0.elapsed_time(e1) * 1e3 / (6 * 48), 2)
+            real["fused_us_per_query"] = round(e0.elapsed_time(e1) * 1e3 / (6 * 48), 2)
+            real["fused_queries_per_pass"] = cp.respond_batch_pass_width(srv.physical_layout, 48)
             cp.tuning_set("respond.batch_fusion", 0)
             del rb
         if not args.no_host_path:

@@ -7,7 +7,7 @@ importing this package never falls back to a CPU implementation.
 from .errors import ChalametPIRError
 from .params import LWE_DIMENSION, SEED_BYTE_LEN
 from .server import (Device, PinnedArray, SeedExpander, Server, dtc_layout_for, encode_kv_database, encoded_num_cols, filter_shape,
-                     find_encoded_db_matrix_element_bit_length, generate_from_seed, host_compress, host_gather, host_gather_variant, mat_x_mat_kernel_name, pack_kernel_name, packed_rhs_offered, packed_rhs_plane_bytes, tuning_reset, tuning_set)
+                     find_encoded_db_matrix_element_bit_length, generate_from_seed, host_compress, host_gather, host_gather_variant, mat_x_mat_kernel_name, pack_kernel_name, packed_rhs_offered, packed_rhs_plane_bytes, respond_batch_pass_width, tuning_reset, tuning_set)
 
 __all__ = ["Server", "Device", "PinnedArray", "SeedExpander", "ChalametPIRError", "SEED_BYTE_LEN", "LWE_DIMENSION", "dtc_layout_for", "encode_kv_database", "encoded_num_cols",
-           "filter_shape", "find_encoded_db_matrix_element_bit_length", "generate_from_seed", "host_compress", "host_gather", "host_gather_variant", "mat_x_mat_kernel_name", "pack_kernel_name", "packed_rhs_offered", "packed_rhs_plane_bytes", "tuning_reset", "tuning_set"]
+           "filter_shape", "find_encoded_db_matrix_element_bit_length", "generate_from_seed", "host_compress", "host_gather", "host_gather_variant", "mat_x_mat_kernel_name", "pack_kernel_name", "packed_rhs_offered", "packed_rhs_plane_bytes", "respond_batch_pass_width", "tuning_reset", "tuning_set"]

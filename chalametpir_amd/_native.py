@@ -101,6 +101,7 @@ SIGNATURES = {
     "cpir_op_synth_fill": (C.c_int, [vp, u32p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, vp]),
     "cpir_respond_kernel_name": (C.c_char_p, [C.POINTER(DtcLayout)]),
     "cpir_pack_kernel_name": (C.c_char_p, [C.POINTER(DtcLayout)]),
+    "cpir_respond_batch_pass_width": (C.c_uint32, [C.POINTER(DtcLayout), C.c_uint32]),
     "cpir_server_setup": (C.c_int, [vp, u8p, u32p, u32p, C.c_uint64, C.c_uint32, C.c_uint32, u32p, C.POINTER(vp)]),
     "cpir_server_setup_kv": (C.c_int, [vp, C.c_uint32, u8p, C.POINTER(KvDb), u8p, C.c_uint32, vp, C.c_size_t, C.POINTER(C.c_size_t),
                                        u8p, C.POINTER(vp)]),

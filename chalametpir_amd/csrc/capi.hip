@@ -347,6 +347,12 @@ int cpir_op_synth_fill(cpir_device* dev, uint32_t* out, uint64_t count, uint64_t
 
 const char* cpir_respond_kernel_name(const cpir_dtc_layout* layout) { return layout ? respond_kernel_name(*layout) : ""; }
 const char* cpir_pack_kernel_name(const cpir_dtc_layout* layout) { return layout ? pack_kernel_name(*layout) : ""; }
+uint32_t cpir_respond_batch_pass_width(const cpir_dtc_layout* layout, uint32_t batch) {
+  if (!layout || batch == 0) return 0;
+  if (layout->packing != CPIR_PACK_PLANAR) return 4;
+  const uint32_t w = respond_planar_pass_width(*layout, batch);
+  return w < batch ? w : batch;
+}
 
 
 int cpir_server_export_compressed(const cpir_server* srv, uint32_t* compressed_out, uint64_t out_words) {

@@ -297,7 +297,11 @@ struct Tuning {
   int host_fill_timeout_us = 2000;  // a lone pageable host query: ONE launch polling the copy's progress, each wave for at most this long (0: off)
   int host_zero_copy = 1;          // a lone host query is read by the kernel in place (page-locked memory), not uploaded first
   int ks_major = 1;                // the step-major matrix-core kernel: 0 never, 1 fused batches + lone launches, 2 wherever it applies
-  int wide_min_batch = 13;         // fused batches of at least this many queries go through the wide pass (up to 24 queries per stream of the database); 0 = never
+  // fused passes of at least this many queries go through the wide pass (up to 24 queries per stream of the database); 0 = never.
+  // Measured at 2^20 keys x 1 kB, us per launch, step-major / wide: 1 query 190.0 / 188.5, 4: 190.8 / 189.9, 5: 204.0 / 192.9, 8: 208.3 /
+  // 197.1, 12: 245.2 / 202.7 (8 kB values: 1436 / 1403, 1427 / 1414, 1523 / 1431, 1562 / 1445, 1748 / 1490): never slower, so everything
+  // beyond one row set takes it; single row sets stay where the in-place host path and the lone launches are
+  int wide_min_batch = 5;
 };
 Tuning g_tuning;
 std::mutex g_tuning_mu;
@@ -494,7 +498,8 @@ int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout
     t = g_tuning;
   }
   // a pass of more queries than the step-major kernel's three row sets: the wide pass (also below that where the tuning asks for it)
-  if (L.packing == CPIR_PACK_PLANAR && (batch > CPIR_PLANAR_MAX_QUERIES_PER_PASS || (t.wide_min_batch > 0 && batch >= (uint32_t)t.wide_min_batch)))
+  if (L.packing == CPIR_PACK_PLANAR &&
+      (batch > CPIR_PLANAR_MAX_QUERIES_PER_PASS || (t.wide_min_batch > 0 && t.ks_major >= 1 && batch >= (uint32_t)t.wide_min_batch)))
     return launch_respond_planar_wide(dev, dtc, L, q, q_len, q_slot_offset, batch, passes, r, stream, t.nontemporal != 0, t.xcd_split != 0);
   if (L.packing == CPIR_PACK_PLANAR)  // the matrix-core path (respond_planar.hip)
     return launch_respond_planar(dev, dtc, L, q, q_len, q_slot_offset, batch, passes, r, stream, t.planar_blocks_per_cu, t.nontemporal != 0,

@@ -65,6 +65,7 @@ struct PlanarArgs {
   const uint32_t* progress;  // host memory: number of 512-slot steps of q in place so far, CPIR_FILL_LINES copies 64 bytes apart (NULL: all of q is in place)
   uint32_t* abort_flag;      // device memory: set when a wave has given up waiting (the launch's results are then void)
   uint64_t poll_ticks;       // ... after this many ticks of the 100 MHz wall clock
+  uint32_t ablate;           // wide pass, diagnosis only (CPIR_WIDE_ABLATE; results are WRONG while non-zero): 1 no rebuild of the fragments, 2 no flush, 4 no MFMAs
 };
 
 template <bool NT>
@@ -862,7 +863,7 @@ respond_planar_wide_kernel(const PlanarArgs a) {
     load_tile(nxt, last ? tg : tg_n, last ? ks : ks_n);  // always issued (the very last unit asks for its own tile again), see above
     const uint32_t Tw = tg * kWM + wave;      // tile of the window (indexes the LDS accumulators)
     const uint32_t T = a.tg_lo * kWM + Tw;    // tile of the image
-    if (T < a.col_tiles) {
+    if (T < a.col_tiles && !(a.ablate & 4u)) {
       v4i hbv[HB > 0 ? 8 : 1];
       if constexpr (HB > 0) {
 #pragma unroll
@@ -911,11 +912,13 @@ respond_planar_wide_kernel(const PlanarArgs a) {
       if (more_visits) {
         __syncthreads();  // everybody is done with this step's fragments (and, at a pass boundary, with accumulating this pass)
         if (pass_ends) {
-          flush_pass(pass, true);  // (nobody accumulates for the next pass before the barrier below)
+          if (!(a.ablate & 2u)) flush_pass(pass, true);  // (nobody accumulates for the next pass before the barrier below)
           pass = npass;
         }
-        if (!g_n) a_finish(raw, par ^ 1);
-        else a_guarded(nks, npass, par ^ 1);
+        if (!(a.ablate & 1u)) {
+          if (!g_n) a_finish(raw, par ^ 1);
+          else a_guarded(nks, npass, par ^ 1);
+        }
         __syncthreads();  // the next step's fragments are complete
         par ^= 1;
         first_of_visit = true;
@@ -933,7 +936,7 @@ respond_planar_wide_kernel(const PlanarArgs a) {
   }
 
   __syncthreads();
-  flush_pass(pass, false);
+  if (!(a.ablate & 2u)) flush_pass(pass, false);
 }
 
 // r[q][c] += 128 * sum_n (q[n] - 0x80808080) over this block's slice of the valid slots, and (slice 0 only) += 0x80808080 * colsum[c]:
@@ -1073,6 +1076,7 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
   a.progress = fill ? fill->progress : nullptr;
   a.abort_flag = fill ? fill->abort_flag : nullptr;
   a.poll_ticks = fill ? (uint64_t)fill->timeout_us * 100 : 0;
+  a.ablate = 0;
   if (fill && (ks_mode != 3 || !fill->progress || !fill->abort_flag)) return CPIR_ERR_INVALID_ARGUMENT;
   a.q_scalar = (reinterpret_cast<uintptr_t>(q) % 16 != 0 || q_slot_offset % 4 != 0 || (batch * passes > 1 && q_len % 4 != 0)) ? 1u : 0u;
 
@@ -1186,6 +1190,11 @@ int launch_respond_planar_wide(const Device* dev, const uint32_t* dtc, const cpi
   a.poll_ticks = 0;
   a.q_scalar = (reinterpret_cast<uintptr_t>(q) % 16 != 0 || q_slot_offset % 4 != 0 || (batch * passes > 1 && q_len % 4 != 0)) ? 1u : 0u;
   a.colsum = dtc + (uint64_t)L.rows_padded * L.words_per_row_padded;
+  static const uint32_t ablate_env = [] {
+    const char* e = getenv("CPIR_WIDE_ABLATE");
+    return e ? (uint32_t)strtoul(e, nullptr, 0) : 0u;
+  }();
+  a.ablate = ablate_env;
 
   const uint32_t ns = (batch + 3) / 4;
   const uint32_t fixed = ns * (8u << 10) + 256u;                                        // fragments + per-step query sums (two parities x 32)

@@ -256,6 +256,11 @@ class PinnedArray:
             pass
 
 
+def respond_batch_pass_width(layout: DtcLayout, batch: int) -> int:
+    """queries per pass a fused batch of `batch` queries is cut into on this layout under the current tuning"""
+    return int(_native.load().cpir_respond_batch_pass_width(C.byref(layout), int(batch)))
+
+
 def pack_kernel_name(layout: DtcLayout) -> str:
     """the kernel Device.transpose_compress runs for this layout, as a kernel trace names it"""
     return _native.load().cpir_pack_kernel_name(C.byref(layout)).decode()

@@ -257,7 +257,7 @@ int cpir_op_synth_fill(cpir_device* dev, uint32_t* out, uint64_t count, uint64_t
  *   matrix-core respond take the step-major kernel: 0 none, 1 -- the default -- single-pass launches, fused batches and queries
  *   beyond 8 MiB, 2 every launch it applies to, 3 as 2 but failing where it does not apply), "respond.wide_min_batch" (fused batches
  *   of at least this many queries are cut into passes of up to 24 queries that share ONE stream of the database -- the wide pass, one
- *   8-wave block per CU; default 13, i.e. whatever the step-major kernel's 12 queries per pass cannot take in one pass; 0: never),
+ *   8-wave block per CU; default 5, i.e. every pass beyond one row set of 4 queries; 0: never -- passes of 12 / 8 as in round 3),
  *   "respond.host_zero_copy" {0,1}
  *   (1, the default: cpir_server_respond serves a caller that finds the server idle without an upload, the kernel reading the
  *   query in place from page-locked host memory; 0: always stage + upload first), "respond.host_fill_timeout_us" 0..1000000
@@ -280,6 +280,10 @@ void cpir_tuning_reset(void);
 const char* cpir_respond_kernel_name(const cpir_dtc_layout* layout);
 /* Name of the kernel cpir_op_transpose_compress runs for this layout (under the current "pack.rows" setting), as a kernel trace shows it. */
 const char* cpir_pack_kernel_name(const cpir_dtc_layout* layout);
+/* Queries per pass a FUSED batch of `batch` queries is cut into on this layout under the current tuning (the queries of a pass share one
+ * stream of the database): planar 24 at most -- as few passes as that allows, all of about the same width -- where the wide pass takes the
+ * batch ("respond.wide_min_batch"), else 12 or 8; other packings 4.  0 for a NULL layout or an empty batch. */
+uint32_t cpir_respond_batch_pass_width(const cpir_dtc_layout* layout, uint32_t batch);
 
 /* ------------------------------------------------------------------------------------------------
  * Server handle: the device-resident replacement of `struct Server` (server.rs:15-21).

@@ -120,6 +120,7 @@ unsafe extern "C" {
     pub fn cpir_tuning_set(key: *const c_char, value: c_int) -> c_int;
     pub fn cpir_tuning_reset();
     pub fn cpir_pack_kernel_name(layout: *const cpir_dtc_layout) -> *const c_char;
+    pub fn cpir_respond_batch_pass_width(layout: *const cpir_dtc_layout, batch: u32) -> u32;
     pub fn cpir_respond_kernel_name(layout: *const cpir_dtc_layout) -> *const c_char;
 
     pub fn cpir_server_setup(dev: *mut cpir_device, seed_mu: *const u8, pub_mat_a: *const u32, d: *const u32, n: u64, c: u32,

@@ -45,7 +45,7 @@ def timed(k, reps):
 
 
 reps = max(3, int(20 * 1.2e9 / (N * C * b / 8)))
-for k in (8, 12, 13, 16, 20, 24, 32, 48, 72, 96):
+for k in (1, 2, 4, 5, 6, 8, 12, 13, 16, 20, 24, 32, 48, 72, 96):
     row = [f"batch {k:3d}:"]
     for wide_min in (0, 13, 1):
         if wide_min == 1 and k > 24:
@@ -54,4 +54,4 @@ for k in (8, 12, 13, 16, 20, 24, 32, 48, 72, 96):
         us, same = timed(k, reps)
         row.append(f"wide_min={wide_min}: {us:8.1f} us = {us / k:6.2f} us/query{'' if same else '  RESPONSES DIFFER'}")
     print("   ".join(row), flush=True)
-cp.tuning_set("respond.wide_min_batch", 13)
+cp.tuning_set("respond.wide_min_batch", 5)

@@ -19,8 +19,9 @@ def _responses(orc, Q, dtc, N, b):
 @pytest.mark.parametrize("b", [4, 8, 9, 10, 11, 12, 13, 14])
 def test_every_batch_size_through_the_wide_pass(b, orc, device):
     """respond.wide_min_batch = 1 sends EVERY fused pass through the wide kernel (1 .. 24 queries: one to six row sets, the last one
-    partly filled), default 13 only the batches the step-major kernel's three row sets cannot take; every plane count (b = 4 .. 14);
-    N ragged (the last step is guarded), more than one visit per block"""
+    partly filled), 5 (the default) every pass beyond one row set, 13 only what the step-major kernel's three row sets cannot take, 0
+    nothing (passes of 12 on the step-major kernel's two and three row sets); every plane count (b = 4 .. 14); N ragged (the last step is
+    guarded), more than one visit per block"""
     import torch
 
     import chalametpir_amd as cp
@@ -36,9 +37,9 @@ def test_every_batch_size_through_the_wide_pass(b, orc, device):
     want = _responses(orc, Q, dtc, N, b)
     Q_dev = torch.from_numpy(Q.view(np.int32)).cuda()
     try:
-        for wide_min in (1, 13):
+        for wide_min in (1, 5, 13, 0):
             cp.tuning_set("respond.wide_min_batch", wide_min)
-            for k in list(range(1, 27)) + [31, 32, 33, 47, 48, 49, 50]:
+            for k in (list(range(1, 27)) + [31, 32, 33, 47, 48, 49, 50] if wide_min in (1, 5) else [4, 5, 7, 8, 9, 11, 12, 13, 24, 25, 37]):
                 R = torch.full((k, C), -1, dtype=torch.int32, device="cuda")
                 srv.respond_batch_device(Q_dev, k, R, stream=stream)
                 torch.cuda.synchronize()
@@ -50,7 +51,7 @@ def test_every_batch_size_through_the_wide_pass(b, orc, device):
         torch.cuda.synchronize()
         assert np.array_equal(R.cpu().numpy().view(np.uint32), want)
     finally:
-        cp.tuning_set("respond.wide_min_batch", 13)
+        cp.tuning_set("respond.wide_min_batch", 5)
         srv.close()
 
 
