@@ -354,31 +354,38 @@ def main() -> int:
     roof["frac_moved"] = round(roof["moved_GBps"] / HBM_PEAK_GBPS, 4)
     roof["read_ceiling_GBps"] = None
     roof["frac_vs_read_ceiling"] = None
-    if rank == 0 and not args.no_read_ceiling:
-        ceil = read_ceiling(min(max(4 * shard_words, 256 << 20), 4 << 30))
-        if ceil:
-            roof["read_ceiling_GBps"] = ceil["read_ceiling_GBps"]
-            roof["frac_vs_read_ceiling"] = round(roof["moved_GBps"] / ceil["read_ceiling_GBps"], 4)
-            roof["read_ceiling_note"] = f"{ceil['kernel']}; {ceil['buffer_bytes'] / 1e9:.2f} GB read once per launch, best of several launch shapes"
-    # HBM traffic per launch cannot be sampled from inside this process (PMC counters need rocprofv3 around it): the last committed
-    # counter pass for this exact workload and packing (scripts/profile_gpu.sh -> profiles/respond_traffic.json) is quoted, with the
-    # commit it was taken at and whether the kernel source has changed since.
-    if world == 1 and not args.headline_only:
-        tr = committed_traffic(args.config, launch_bytes_q, packing)
-        live = None if args.no_live_traffic else live_traffic(args, passes_per_launch)
-        if live:
-            # measured NOW: the same timed loop in two child processes under rocprofv3, one counter each (the pool refuses --pmc next to
-            # other trace domains, and FETCH_SIZE / WRITE_SIZE do not fit one pass), corrected as the guide's HBM section prescribes
-            roof["traffic"] = int(live["bytes_per_launch"])
-            roof["traffic_source"] = live["source"]
-            roof["traffic_over_moved_bytes"] = round(live["bytes_per_launch"] / moved_bytes, 4) if moved_bytes else None
-            if tr:
-                roof["traffic_committed_pass"] = int(tr["traffic_bytes_per_pass"] * passes_per_launch)  # profiles/respond_traffic.json, for comparison
-        elif tr:
-            roof["traffic"] = int(tr["traffic_bytes_per_pass"] * passes_per_launch)
-            roof["traffic_source"] = ("profiles/respond_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes; "
-                                      f"NOT measured in this run) taken at commit {tr.get('git_head', 'unknown')}")
-            roof["traffic_kernel_source_unchanged"] = tr.get("kernel_source_sha256") == kernel_source_sha256()
+    # (a child process; this one waits for it with an idle device, so it runs behind the sections that continue the headline's loop)
+    def measure_read_ceiling():
+        if rank == 0 and not args.no_read_ceiling:
+            ceil = read_ceiling(min(max(4 * shard_words, 256 << 20), 4 << 30))
+            if ceil:
+                roof["read_ceiling_GBps"] = ceil["read_ceiling_GBps"]
+                roof["frac_vs_read_ceiling"] = round(roof["moved_GBps"] / ceil["read_ceiling_GBps"], 4)
+                roof["read_ceiling_note"] = f"{ceil['kernel']}; {ceil['buffer_bytes'] / 1e9:.2f} GB read once per launch, best of several launch shapes"
+
+    # (run AFTER every timed section of this process: a rocprofv3 counter pass leaves the device at the profiling power state for a
+    # while -- the fused batches, which are sensitive to the matrix cores' clock, measured 13.1 us per query right behind the counter
+    # passes and 10.7-11.0 without them in the same build on the same box)
+    def measure_traffic():
+        # HBM traffic per launch cannot be sampled from inside this process (PMC counters need rocprofv3 around it): the last committed
+        # counter pass for this exact workload and packing (scripts/profile_gpu.sh -> profiles/respond_traffic.json) is quoted, with the
+        # commit it was taken at and whether the kernel source has changed since.
+        if world == 1 and not args.headline_only:
+            tr = committed_traffic(args.config, launch_bytes_q, packing)
+            live = None if args.no_live_traffic else live_traffic(args, passes_per_launch)
+            if live:
+                # measured NOW: the same timed loop in two child processes under rocprofv3, one counter each (the pool refuses --pmc next to
+                # other trace domains, and FETCH_SIZE / WRITE_SIZE do not fit one pass), corrected as the guide's HBM section prescribes
+                roof["traffic"] = int(live["bytes_per_launch"])
+                roof["traffic_source"] = live["source"]
+                roof["traffic_over_moved_bytes"] = round(live["bytes_per_launch"] / moved_bytes, 4) if moved_bytes else None
+                if tr:
+                    roof["traffic_committed_pass"] = int(tr["traffic_bytes_per_pass"] * passes_per_launch)  # profiles/respond_traffic.json, for comparison
+            elif tr:
+                roof["traffic"] = int(tr["traffic_bytes_per_pass"] * passes_per_launch)
+                roof["traffic_source"] = ("profiles/respond_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes; "
+                                          f"NOT measured in this run) taken at commit {tr.get('git_head', 'unknown')}")
+                roof["traffic_kernel_source_unchanged"] = tr.get("kernel_source_sha256") == kernel_source_sha256()
 
     # row f3: the same queries answered 4 per pass over the database (fused batch kernel) -- reported beside the
     # headline, never as the headline: the headline streams the whole database for every single query
@@ -392,12 +399,15 @@ def main() -> int:
             off = (16 * k) % (pool - nbq + 1) if pool > nbq else 0
             sharded.respond_partial_device(q_pool[off:off + nbq], rb, batch=nbq, stream=stream)
 
-        for k in range(3):
+        # (a dozen warm-up launches, not three: measured behind a child process that left this one's device idle for a second or two, the
+        # wide pass -- sensitive to the matrix cores' clock -- took 13.1-13.7 us per query after 2 ms of warm-up, 10.7-11.0 straight behind
+        # the headline loop, same build, same box; the read-ceiling child now runs after these sections)
+        for k in range(24):
             fused_step(k)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
-        n_fused_steps = max(4, args.steps // 4)
+        n_fused_steps = max(8, args.steps // 2)
         for k in range(n_fused_steps):
             fused_step(k)
         e1.record(stream)
@@ -432,7 +442,7 @@ def main() -> int:
             "us_per_query": round(lone_us, 2),
             "queries_per_sec": round(1e6 / lone_us, 1),
             "note": "one query per launch, launches back to back on one stream (memset of r + one kernel each; on the planar packing the "
-                    "step-major kernel, which adds the correction terms itself)",
+                    "wide-pass kernel with one row set, which adds the correction terms itself)",
         }
     # also row f3: the same independent passes (one query each, no fusion), but walked in the interleaved order so that concurrent
     # passes share database bytes in L2 / Infinity Cache -- above the HBM roof by construction, hence never the headline
@@ -460,6 +470,7 @@ def main() -> int:
                     "blocks streaming the same tiles for different queries share them on die, so this is not an HBM-bound number",
         }
         cp.tuning_set("respond.interleave_passes", -1)
+    measure_read_ceiling()
     # the C-ABI host path a Rust caller uses: query bytes on the host -> pinned copy -> H2D -> kernel -> D2H -> bytes
     if world == 1 and not args.no_host_path:
         cp.tuning_set("respond.batch_fusion", 1)  # the library's own default: coalesced callers share one stream of the database
@@ -519,6 +530,7 @@ def main() -> int:
             except Exception as exc:  # noqa: BLE001 -- an extra must never cost the headline line
                 log(f"key-value setup / real database section failed: {exc!r}")
                 result["server_setup_kv_error"] = repr(exc)
+    measure_traffic()
 
     if world > 1 and not args.no_setup:
         # The headline must not be hostage to an optional extra: rank 0 prints the respond line NOW, then the sharded setup is timed under
@@ -1400,15 +1412,15 @@ def setup_kv_and_real_db(cp, device, torch, args, n_keys, arity, value_bytes, q_
         if pool >= 64:  # the same database with fused batches, 48 queries a launch (planar: two wide passes of 24)
             cp.tuning_set("respond.batch_fusion", 1)
             rb = torch.zeros((48, C), dtype=torch.int32, device="cuda")
-            for k in range(2):
+            for k in range(12):
                 srv.respond_batch_device(q_pool[16 * (k % 2):16 * (k % 2) + 48], 48, rb, stream=stream)
             torch.cuda.synchronize()
             e0.record(stream)
-            for k in range(6):
+            for k in range(10):
                 srv.respond_batch_device(q_pool[16 * (k % 2):16 * (k % 2) + 48], 48, rb, stream=stream)
             e1.record(stream)
             torch.cuda.synchronize()
-            real["fused_us_per_query"] = round(e0.elapsed_time(e1) * 1e3 / (6 * 48), 2)
+            real["fused_us_per_query"] = round(e0.elapsed_time(e1) * 1e3 / (10 * 48), 2)
             real["fused_queries_per_pass"] = cp.respond_batch_pass_width(srv.physical_layout, 48)
             cp.tuning_set("respond.batch_fusion", 0)
             del rb

@@ -498,8 +498,11 @@ int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout
     t = g_tuning;
   }
   // a pass of more queries than the step-major kernel's three row sets: the wide pass (also below that where the tuning asks for it)
+  // ... and a launch of ONE pass of any width (a lone device query: 190.0 -> 188.5 us at 2^20 keys x 1 kB, 1 436 -> 1 403 with 8 kB values,
+  // 36.9 -> 30.9 on a 1/8 shard); many passes of up to 4 queries stay on the tile-major / step-major kernels (the headline's loop)
   if (L.packing == CPIR_PACK_PLANAR &&
-      (batch > CPIR_PLANAR_MAX_QUERIES_PER_PASS || (t.wide_min_batch > 0 && t.ks_major >= 1 && batch >= (uint32_t)t.wide_min_batch)))
+      (batch > CPIR_PLANAR_MAX_QUERIES_PER_PASS ||
+       (t.wide_min_batch > 0 && t.ks_major >= 1 && (batch >= (uint32_t)t.wide_min_batch || passes == 1))))
     return launch_respond_planar_wide(dev, dtc, L, q, q_len, q_slot_offset, batch, passes, r, stream, t.nontemporal != 0, t.xcd_split != 0);
   if (L.packing == CPIR_PACK_PLANAR)  // the matrix-core path (respond_planar.hip)
     return launch_respond_planar(dev, dtc, L, q, q_len, q_slot_offset, batch, passes, r, stream, t.planar_blocks_per_cu, t.nontemporal != 0,
