@@ -30,6 +30,8 @@
 //     sum_i 2^(8i) (lo_i + 256 hi_i) is lane-local; one u32 atomicAdd per (wave, query, column) and tile group.
 #include "cpir_internal.hpp"
 
+#include <type_traits>
+
 namespace cpir {
 namespace {
 
@@ -865,7 +867,8 @@ respond_planar_wide_kernel(const PlanarArgs a) {
     const uint32_t T = a.tg_lo * kWM + Tw;    // tile of the image
     if (T < a.col_tiles && !(a.ablate & 4u)) {
       v4i hbv[HB > 0 ? 8 : 1];
-      if constexpr (HB > 0) {
+      constexpr bool kPeel = HB <= 4;  // (five and six planes: the peeled set's extra live values spill 12-44 bytes per lane; expanded up front there)
+      if constexpr (HB > 0 && !kPeel) {
 #pragma unroll
         for (int kb = 0; kb < 8; kb++)
 #pragma unroll
@@ -884,11 +887,12 @@ respond_planar_wide_kernel(const PlanarArgs a) {
       // matrix-core issue) before its use.  (With the reads in front of their MFMAs, two by two, a set cost four LDS round trips: 32 us
       // per set and pass at 2^20 keys against 16 us of matrix-core issue.  A second full set of registers -- all eight reads in front
       // of the set -- does not fit: 18 to 39 VGPRs spilled.)  The last set re-reads itself: no condition in the loop.
+      // The FIRST set is peeled off the loop: it expands the tile's bit planes into the high-byte operands k-block by k-block between
+      // its MFMAs (some 80 VALU instructions per tile that otherwise run in front of the loop with the matrix cores idle).
       uint4 f[8];
 #pragma unroll
       for (int kb = 0; kb < 8; kb++) f[kb] = abuf[kb * 64 + lane];
-#pragma unroll 1
-      for (uint32_t s = 0; s < ns; s++) {
+      auto row_set = [&](uint32_t s, auto first) __attribute__((always_inline)) {
         const uint4* const ap = abuf + (s + 1 < ns ? s + 1 : s) * 512 + lane;
         // no branch around the rows of a partly filled last set: they add 0 to the last query's word (their fragments are 0)
         const uint32_t query = 4 * s + grp, qq = query < nq ? query : nq - 1;
@@ -896,6 +900,15 @@ respond_planar_wide_kernel(const PlanarArgs a) {
         v4i acc_lo = v4i{0, 0, 0, 0}, acc_hi = v4i{0, 0, 0, 0};
 #pragma unroll
         for (int kb = 0; kb < 8; kb++) {
+          if constexpr (HB > 0 && decltype(first)::value) {
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+              uint32_t x = 0;
+#pragma unroll
+              for (int p = 0; p < HB; p++) x += ((comp(cur[8 + p], kb >> 1) >> (4 * (kb & 1) + d)) & 0x01010101u) << p;
+              hbv[kb][d] = (int)x;
+            }
+          }
           acc_lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(as_v4i(f[kb]), as_v4i(cur[kb]), acc_lo, 0, 0, 0);
           if constexpr (HB > 0) acc_hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(as_v4i(f[kb]), hbv[kb], acc_hi, 0, 0, 0);
           f[kb] = ap[kb * 64];
@@ -905,7 +918,10 @@ respond_planar_wide_kernel(const PlanarArgs a) {
         for (int i = 0; i < 4; i++) val += ((uint32_t)acc_lo[i] + ((uint32_t)acc_hi[i] << 8)) << (8 * i);
         val += 128u * qsum + base_term;  // 128 * 0x80808080 = 0x40404000 mod 2^32
         atomicAdd(rcol + qq * cpad, query < nq ? val : 0u);  // LDS; this wave owns tile T of the step
-      }
+      };
+      row_set(0u, std::integral_constant<bool, kPeel>{});
+#pragma unroll 1
+      for (uint32_t s = 1; s < ns; s++) row_set(s, std::false_type{});
     }
     first_of_visit = false;
     if (last_of_visit) {
