@@ -110,7 +110,11 @@ uint64_t respond_scratch_words(const cpir_dtc_layout& L, uint32_t batch);
 // One launch = `passes` independent passes over the database, each answering `batch` (1, 2 or 4) queries that share the
 // stream of that pass: q holds passes*batch queries of q_len entries, r passes*batch responses of num_cols entries.
 int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
-                   uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, uint32_t* scratch, hipStream_t stream);
+                   uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, uint32_t* scratch, hipStream_t stream,
+                   const uint32_t* keep = nullptr);
+// keep: the slot map of a compacted image, applied by the kernel itself -- the wide pass only (respond_batch_takes_slot_map says whether every
+// launch of a batch is one); with any other kernel the call fails with CPIR_ERR_INVALID_ARGUMENT and the caller gathers the queries first
+bool respond_batch_takes_slot_map(const cpir_dtc_layout& L, uint32_t batch, bool lone, uint64_t q_len);
 // A launch whose query is still being copied into page-locked host memory while the kernel runs (respond_planar.hip): the host counts
 // the 512-slot steps of q in place so far in *progress (host memory, device-visible address), front to back; the kernel waits for each
 // step it needs, at most timeout_us per wave, and sets *abort_flag (device memory, zeroed by the caller) if a wave gave up.
@@ -146,7 +150,8 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
 constexpr uint32_t CPIR_PLANAR_WIDE_MAX_QUERIES_PER_PASS = 24;
 int launch_respond_planar_wide(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                                uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, bool nontemporal,
-                               bool xcd_split);
+                               bool xcd_split, const uint32_t* keep = nullptr);
+// keep: the slot map of a compacted image (SlotMap::keep_dev) -- the kernel then gathers the query words itself; L is the PHYSICAL layout
 bool respond_batch_fusion();
 uint64_t respond_multi_pass_limit_bytes();
 

@@ -659,6 +659,15 @@ int server_respond_on_device(const Server* srv, const uint32_t* q, uint64_t q_le
   // only the slots with a non-zero row are resident: gather the queries onto them, then an ordinary respond on the compact database
   const SlotMap& m = srv->map;
   if (q_slot_offset + m.n_orig > q_len) return CPIR_ERR_SHARD_RANGE;
+  // Where every launch of the batch is a wide pass, the kernel applies the map itself while it gathers the query words (no pass over the
+  // queries in front of it: 12.0 -> 10.7 us per query for fused batches on the 2^20-key database Server::setup builds).  The decision and
+  // the launches read the tuning separately: a launch that finds itself on another kernel after all refuses the map, and the batch is
+  // answered again the long way.
+  if (respond_batch_takes_slot_map(srv->phys, batch, lone, q_len)) {
+    const int st = lone ? launch_respond(srv->dev, srv->dtc, srv->phys, q, q_len, q_slot_offset, 1, 1, r, scratch, stream, m.keep_dev)
+                        : respond_batched(srv->dev, srv->dtc, srv->phys, q, q_len, q_slot_offset, batch, r, scratch, stream, m.keep_dev);
+    if (st != CPIR_ERR_INVALID_ARGUMENT) return st;
+  }
   uint32_t* own = nullptr;
   if (!qc) {
     CPIR_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&own), (size_t)batch * m.n_pad * 4, stream));
@@ -681,7 +690,8 @@ int server_respond_on_device(const Server* srv, const uint32_t* q, uint64_t q_le
 // Any batch size.  With batch fusion every pass answers 4 queries from one stream of the database (remainder 2 / 1);
 // without it every query is its own pass.  Either way the passes of one kind go into ONE launch.
 int respond_batched(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
-                           uint64_t q_slot_offset, uint32_t batch, uint32_t* r, uint32_t* scratch, hipStream_t stream) {
+                           uint64_t q_slot_offset, uint32_t batch, uint32_t* r, uint32_t* scratch, hipStream_t stream, const uint32_t* keep) {
+  if (keep && (L.packing != CPIR_PACK_PLANAR || !respond_batch_fusion())) return CPIR_ERR_INVALID_ARGUMENT;  // (see server_respond_on_device)
   if (!respond_batch_fusion()) {
     // One launch for all passes saves a kernel fill/drain (~10 us) per query, but blocks of a long multi-pass launch drift
     // apart and lose the L2 sharing of q: measured on MI355X it wins up to 1.3 GB per pass (196 vs 204 us) and loses at
@@ -698,13 +708,13 @@ int respond_batched(const Device* dev, const uint32_t* dtc, const cpir_dtc_layou
     // then the rest -- as one pass if that pass may be as wide, else as passes of 8 and a last one
     const uint32_t W = respond_planar_pass_width(L, batch);
     if (batch >= W) {
-      CPIR_TRY(launch_respond(dev, dtc, L, q, q_len, q_slot_offset, W, batch / W, r, scratch, stream));
+      CPIR_TRY(launch_respond(dev, dtc, L, q, q_len, q_slot_offset, W, batch / W, r, scratch, stream, keep));
       done = batch / W * W;
     }
     while (done < batch) {
       const uint32_t left = batch - done;
       const uint32_t w = left <= respond_planar_pass_width(L, left) ? left : 8u;  // (a single pass of up to 12 is always step-major)
-      CPIR_TRY(launch_respond(dev, dtc, L, q + (uint64_t)done * q_len, q_len, q_slot_offset, w, 1, r + (uint64_t)done * L.num_cols, scratch, stream));
+      CPIR_TRY(launch_respond(dev, dtc, L, q + (uint64_t)done * q_len, q_len, q_slot_offset, w, 1, r + (uint64_t)done * L.num_cols, scratch, stream, keep));
       done += w;
     }
     return CPIR_OK;

@@ -447,6 +447,22 @@ uint32_t respond_planar_pass_width(const cpir_dtc_layout& L, uint32_t batch) {
   return planar_max_queries_per_pass(L, passes12 > 1 ? passes12 : 1, t.interleave_passes, t.ks_major);
 }
 
+// Whether EVERY launch respond_batched (or a lone launch_respond) makes for this batch under the current tuning is a wide pass that can
+// apply a slot map itself -- the same cutting as respond_batched's, walked without launching anything.
+bool respond_batch_takes_slot_map(const cpir_dtc_layout& L, uint32_t batch, bool lone, uint64_t q_len) {
+  Tuning t;
+  {
+    std::lock_guard<std::mutex> lk(g_tuning_mu);
+    t = g_tuning;
+  }
+  if (L.packing != CPIR_PACK_PLANAR || t.ks_major < 1 || t.wide_min_batch <= 0 || !t.nontemporal || q_len >= ((uint64_t)1 << 28) || batch == 0) return false;
+  if (lone || batch == 1) return true;      // one pass of one query
+  if (!t.batch_fusion) return false;        // many passes of one query each: the tile-major kernel
+  const uint32_t W = respond_planar_pass_width(L, batch);
+  if (batch >= W && batch / W > 1 && W <= CPIR_PLANAR_MAX_QUERIES_PER_PASS && W < (uint32_t)t.wide_min_batch) return false;  // several narrow passes
+  return true;  // (everything else is either at least wide_min_batch wide or a launch of one pass)
+}
+
 uint64_t respond_scratch_words(const cpir_dtc_layout&, uint32_t) {
   // the current kernel needs no scratch (partial sums leave through integer atomics); the parameter stays in the ABI so
   // a partial-buffer variant can be swapped in without changing callers
@@ -485,7 +501,8 @@ int launch_respond_read_once(const Device* dev, const uint32_t* dtc, const cpir_
 }
 
 int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
-                   uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, uint32_t* /*scratch*/, hipStream_t stream) {
+                   uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, uint32_t* /*scratch*/, hipStream_t stream,
+                   const uint32_t* keep) {
   if (!dtc || !q || !r || batch == 0 || passes == 0) return CPIR_ERR_INVALID_ARGUMENT;
   // shape invariants every kernel variant relies on (checked on the host before any launch)
   CPIR_TRY(check_layout(L));
@@ -503,7 +520,8 @@ int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout
   if (L.packing == CPIR_PACK_PLANAR &&
       (batch > CPIR_PLANAR_MAX_QUERIES_PER_PASS ||
        (t.wide_min_batch > 0 && t.ks_major >= 1 && (batch >= (uint32_t)t.wide_min_batch || passes == 1))))
-    return launch_respond_planar_wide(dev, dtc, L, q, q_len, q_slot_offset, batch, passes, r, stream, t.nontemporal != 0, t.xcd_split != 0);
+    return launch_respond_planar_wide(dev, dtc, L, q, q_len, q_slot_offset, batch, passes, r, stream, t.nontemporal != 0, t.xcd_split != 0, keep);
+  if (keep) return CPIR_ERR_INVALID_ARGUMENT;  // only the wide pass applies a slot map itself: the caller gathers the queries first
   if (L.packing == CPIR_PACK_PLANAR)  // the matrix-core path (respond_planar.hip)
     return launch_respond_planar(dev, dtc, L, q, q_len, q_slot_offset, batch, passes, r, stream, t.planar_blocks_per_cu, t.nontemporal != 0,
                                  t.xcd_split != 0, t.interleave_passes, t.ks_major);

@@ -67,6 +67,8 @@ struct PlanarArgs {
   const uint32_t* progress;  // host memory: number of 512-slot steps of q in place so far, CPIR_FILL_LINES copies 64 bytes apart (NULL: all of q is in place)
   uint32_t* abort_flag;      // device memory: set when a wave has given up waiting (the launch's results are then void)
   uint64_t poll_ticks;       // ... after this many ticks of the 100 MHz wall clock
+  const uint32_t* keep;      // wide pass: the database holds only the slots keep[0 .. num_slots) of the query (increasing, relative to q_slot_offset;
+                             // compact.hip); NULL: slot n of the database is word q_slot_offset + n of the query
   uint32_t ablate;           // wide pass, diagnosis only (CPIR_WIDE_ABLATE; results are WRONG while non-zero): 1 no rebuild of the fragments, 2 no flush, 4 no MFMAs
 };
 
@@ -682,7 +684,7 @@ constexpr int kWThreads = 512;
 constexpr int kWM = 8;        // column tiles per work unit = waves per block
 constexpr int kWMaxSets = 6;  // row sets of 4 queries
 
-template <int HB, bool NT>
+template <int HB, bool NT, bool MAP>
 __global__ void __launch_bounds__(kWThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 respond_planar_wide_kernel(const PlanarArgs a) {
   constexpr int NL = 8 + HB;
@@ -723,8 +725,15 @@ respond_planar_wide_kernel(const PlanarArgs a) {
   const uint4* const tiles = reinterpret_cast<const uint4*>(a.dtc);
   const uint32_t rr = lane >> 4, l16 = lane & 15;  // as a LOADER of query words: row of the set, 16-byte piece of the wave's 64 slots
 
+  // A slot map (a.keep: only the rows of D that hold something are in the image, compact.hip) is applied HERE, where the query words are
+  // gathered anyway: slot n of the image multiplies word keep[n] of the query.  (As a pass of its own in front of the launch the gather
+  // read and wrote every query once more: 1.8 us per query next to the 10.5 of a pass of 24.)  The four indices of a lane are one 16-byte
+  // load, requested in the visit's first unit; the four word loads per row set follow in the next unit, when the indices have arrived.
+  // (MAP is a template parameter: the index registers and the word loads' addresses cost the plain kernel 24 VGPRs it does not have)
+  constexpr bool mapped = MAP;
   auto guarded_step = [&](uint32_t ks_) __attribute__((always_inline)) {
     const uint64_t slot0 = (uint64_t)ks_ * CPIR_PLANAR_SLOTS_PER_TILE;
+    if (mapped) return slot0 + CPIR_PLANAR_SLOTS_PER_TILE > a.num_slots;  // (word loads: no alignment to ask for)
     return a.q_scalar || slot0 + CPIR_PLANAR_SLOTS_PER_TILE > a.num_slots || a.q_slot_offset + slot0 + CPIR_PLANAR_SLOTS_PER_TILE > a.q_len;
   };
   auto a_issue = [&](uint4(&raw)[kWMaxSets], uint32_t ks_, uint32_t pass_) __attribute__((always_inline)) {
@@ -734,6 +743,25 @@ respond_planar_wide_kernel(const PlanarArgs a) {
       raw[s] = make_uint4(0, 0, 0, 0);
       const uint32_t row = 4 * s + rr;
       if (row < nq) raw[s] = *reinterpret_cast<const uint4*>(a.q + ((uint64_t)pass_ * nq + row) * a.q_len + a.q_slot_offset + base);
+    }
+  };
+  auto idx_issue = [&](uint32_t ks_) __attribute__((always_inline)) {
+    return *reinterpret_cast<const uint4*>(a.keep + (uint64_t)ks_ * CPIR_PLANAR_SLOTS_PER_TILE + wave * 64 + l16 * 4);
+  };
+  // (a row set's base address is uniform, the lane adds a 32-bit word offset -- its row of the set and its slot: the host sends queries
+  // beyond 2^28 words through the gather pass; the rows of a partly filled last set read row 0 of the set and are zeroed)
+  const uint32_t roff = rr * (uint32_t)a.q_len;
+  auto a_issue_mapped = [&](uint4(&raw)[kWMaxSets], const uint4& idx, uint32_t pass_) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < kWMaxSets; s++) {
+      raw[s] = make_uint4(0, 0, 0, 0);
+      if ((uint32_t)(4 * s) < nq) {  // block-uniform
+        const uint32_t* const bs = a.q + ((uint64_t)pass_ * nq + 4 * s) * a.q_len + a.q_slot_offset;
+        const bool valid = 4 * s + rr < nq;
+        const uint32_t o = valid ? roff : 0u;
+        const uint4 v = make_uint4(bs[o + idx.x], bs[o + idx.y], bs[o + idx.z], bs[o + idx.w]);
+        raw[s] = valid ? v : make_uint4(0, 0, 0, 0);
+      }
     }
   };
   auto wave_lds_fence = [] {
@@ -790,8 +818,8 @@ respond_planar_wide_kernel(const PlanarArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const uint64_t n = base + d * 4 + e;
-          const bool ok = n < a.num_slots && a.q_slot_offset + n < a.q_len;
-          const uint32_t x = ok ? qrow[n] : 0u;
+          const bool ok = n < a.num_slots && (mapped || a.q_slot_offset + n < a.q_len);
+          const uint32_t x = ok ? qrow[mapped ? (uint64_t)a.keep[n] : n] : 0u;
           part += x;
           w[e] = ok ? (x ^ 0x80808080u) : 0u;
         }
@@ -808,7 +836,7 @@ respond_planar_wide_kernel(const PlanarArgs a) {
     for (int i = 0; i < NL; i++) dst[i] = load16<NT>(p + i * 64);
   };
   const uint64_t room = a.q_len > a.q_slot_offset ? a.q_len - a.q_slot_offset : 0;
-  const uint64_t nvalid_total = a.num_slots < room ? a.num_slots : room;
+  const uint64_t nvalid_total = (mapped || a.num_slots < room) ? a.num_slots : room;
   auto valid_slots = [&](uint32_t ks_) __attribute__((always_inline)) -> uint32_t {
     const uint64_t lo = (uint64_t)ks_ * CPIR_PLANAR_SLOTS_PER_TILE;
     if (lo >= nvalid_total) return 0u;
@@ -838,10 +866,17 @@ respond_planar_wide_kernel(const PlanarArgs a) {
   uint4 b0[NL], b1[NL];
   uint4 raw[kWMaxSets];
   load_tile(b0, tg, cks);
+  uint4 idx = make_uint4(0, 0, 0, 0);
+  bool idx_pending = false;  // the next visit's indices are requested, its query words are not yet
   if (guarded_step(cks)) {
     a_guarded(cks, 0, 0);
   } else {
-    a_issue(raw, cks, 0);
+    if (mapped) {
+      idx = idx_issue(cks);
+      a_issue_mapped(raw, idx, 0);
+    } else {
+      a_issue(raw, cks, 0);
+    }
     a_finish(raw, 0);
   }
   __syncthreads();
@@ -860,7 +895,18 @@ respond_planar_wide_kernel(const PlanarArgs a) {
     const uint32_t tg_n = last_of_visit ? visit_tg0(nv) : tg + 1, ks_n = last_of_visit ? nks : ks;
     const bool g_n = more_visits && guarded_step(nks);
     // the next visit's query words: requested now, a whole visit ahead of their use (L2 / HBM)
-    if (first_of_visit && more_visits && !g_n) a_issue(raw, nks, npass);
+    if (more_visits && !g_n) {
+      if (!mapped) {
+        if (first_of_visit) a_issue(raw, nks, npass);
+      } else if (first_of_visit) {
+        idx = idx_issue(nks);
+        idx_pending = true;
+        if (last_of_visit) a_issue_mapped(raw, idx, npass), idx_pending = false;  // (a visit of one unit: no later unit to do it in)
+      } else if (idx_pending) {
+        a_issue_mapped(raw, idx, npass);
+        idx_pending = false;
+      }
+    }
     if (first_of_visit && threadIdx.x < 32) qs[(par ^ 1) * 32 + threadIdx.x] = 0;  // the next step's sums start from zero
     load_tile(nxt, last ? tg : tg_n, last ? ks : ks_n);  // always issued (the very last unit asks for its own tile again), see above
     const uint32_t Tw = tg * kWM + wave;      // tile of the window (indexes the LDS accumulators)
@@ -1021,15 +1067,20 @@ KernelFn pick_ks(uint32_t hb, uint32_t batch, bool nt) {
   return batch <= 4 ? pick_ks_hb<1>(hb, nt) : (batch <= 8 ? pick_ks_hb<2>(hb, nt) : pick_ks_hb<3>(hb, nt));
 }
 
-KernelFn pick_wide(uint32_t hb, bool nt) {
+template <int HB>
+KernelFn pick_wide_hb(bool nt, bool map) {
+  if (map) return nt ? respond_planar_wide_kernel<HB, true, true> : nullptr;  // (a slot map with cached loads: not built; the caller gathers first)
+  return nt ? respond_planar_wide_kernel<HB, true, false> : respond_planar_wide_kernel<HB, false, false>;
+}
+KernelFn pick_wide(uint32_t hb, bool nt, bool map) {
   switch (hb) {
-    case 0: return nt ? respond_planar_wide_kernel<0, true> : respond_planar_wide_kernel<0, false>;
-    case 1: return nt ? respond_planar_wide_kernel<1, true> : respond_planar_wide_kernel<1, false>;
-    case 2: return nt ? respond_planar_wide_kernel<2, true> : respond_planar_wide_kernel<2, false>;
-    case 3: return nt ? respond_planar_wide_kernel<3, true> : respond_planar_wide_kernel<3, false>;
-    case 4: return nt ? respond_planar_wide_kernel<4, true> : respond_planar_wide_kernel<4, false>;
-    case 5: return nt ? respond_planar_wide_kernel<5, true> : respond_planar_wide_kernel<5, false>;
-    case 6: return nt ? respond_planar_wide_kernel<6, true> : respond_planar_wide_kernel<6, false>;
+    case 0: return pick_wide_hb<0>(nt, map);
+    case 1: return pick_wide_hb<1>(nt, map);
+    case 2: return pick_wide_hb<2>(nt, map);
+    case 3: return pick_wide_hb<3>(nt, map);
+    case 4: return pick_wide_hb<4>(nt, map);
+    case 5: return pick_wide_hb<5>(nt, map);
+    case 6: return pick_wide_hb<6>(nt, map);
     default: return nullptr;
   }
 }
@@ -1093,6 +1144,7 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
   a.abort_flag = fill ? fill->abort_flag : nullptr;
   a.poll_ticks = fill ? (uint64_t)fill->timeout_us * 100 : 0;
   a.ablate = 0;
+  a.keep = nullptr;
   if (fill && (ks_mode != 3 || !fill->progress || !fill->abort_flag)) return CPIR_ERR_INVALID_ARGUMENT;
   a.q_scalar = (reinterpret_cast<uintptr_t>(q) % 16 != 0 || q_slot_offset % 4 != 0 || (batch * passes > 1 && q_len % 4 != 0)) ? 1u : 0u;
 
@@ -1176,10 +1228,11 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
 // block per CU; a database whose accumulators do not fit beside the fragments is answered in column windows of whole groups of 8 tiles.
 int launch_respond_planar_wide(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                                uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, bool nontemporal,
-                               bool xcd_split) {
+                               bool xcd_split, const uint32_t* keep) {
   if (L.packing != CPIR_PACK_PLANAR || batch == 0 || batch > CPIR_PLANAR_WIDE_MAX_QUERIES_PER_PASS || passes == 0) return CPIR_ERR_INVALID_ARGUMENT;
   const uint32_t hb = planar_hi_planes(L.mat_elem_bit_len);
-  KernelFn fn = pick_wide(hb, nontemporal);
+  KernelFn fn = pick_wide(hb, nontemporal, keep != nullptr);
+  if (keep && q_len >= ((uint64_t)1 << 28)) return CPIR_ERR_INVALID_ARGUMENT;  // (32-bit word offsets inside a row set, see the kernel)
   if (!fn || L.chunk_words != (8 + hb) * 256 || L.rows_padded % 16 != 0) return CPIR_ERR_INVALID_ARGUMENT;
   const uint64_t ks_total = (L.num_slots + CPIR_PLANAR_SLOTS_PER_TILE - 1) / CPIR_PLANAR_SLOTS_PER_TILE;
   if (ks_total > 0xffffffffull || ks_total * (L.chunk_words / 16) != L.words_per_row_padded) return CPIR_ERR_INVALID_ARGUMENT;
@@ -1211,6 +1264,8 @@ int launch_respond_planar_wide(const Device* dev, const uint32_t* dtc, const cpi
     return e ? (uint32_t)strtoul(e, nullptr, 0) : 0u;
   }();
   a.ablate = ablate_env;
+  a.keep = keep;  // (device memory, at least L.num_slots entries, 16-byte aligned; the caller has checked that the slots it names lie inside q)
+  if (keep && reinterpret_cast<uintptr_t>(keep) % 16 != 0) return CPIR_ERR_INVALID_ARGUMENT;
 
   const uint32_t ns = (batch + 3) / 4;
   const uint32_t fixed = ns * (8u << 10) + 256u;                                        // fragments + per-step query sums (two parities x 32)
@@ -1221,8 +1276,8 @@ int launch_respond_planar_wide(const Device* dev, const uint32_t* dtc, const cpi
   const uint32_t tg_per_window = (a.tile_groups + windows - 1) / windows;
 
   // (up to 156 KiB of dynamic LDS: say so once per instantiation; a runtime that does not know the attribute is not an error)
-  static std::atomic<bool> lds_raised[7][2];
-  if (!lds_raised[hb][nontemporal ? 1 : 0].exchange(true, std::memory_order_relaxed)) {
+  static std::atomic<bool> lds_raised[7][2][2];
+  if (!lds_raised[hb][nontemporal ? 1 : 0][keep ? 1 : 0].exchange(true, std::memory_order_relaxed)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLdsBudget) != hipSuccess) (void)hipGetLastError();
   }
   CPIR_HIP_TRY(hipMemsetAsync(r, 0, (size_t)batch * passes * L.num_cols * sizeof(uint32_t), stream));

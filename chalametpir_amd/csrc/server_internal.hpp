@@ -193,7 +193,7 @@ void server_destroy(Server* srv);
 // any batch size on device pointers: with batch fusion every pass answers up to 12 queries (8 where the tile-major kernel runs) from one stream of the database, without it
 // every query is its own pass; either way the passes of one kind go into ONE launch
 int respond_batched(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len, uint64_t q_slot_offset,
-                    uint32_t batch, uint32_t* r, uint32_t* scratch, hipStream_t stream);
+                    uint32_t batch, uint32_t* r, uint32_t* scratch, hipStream_t stream, const uint32_t* keep = nullptr);
 // The same for a SERVER: `batch` queries of q_len entries on the device, this server's slots starting at q_slot_offset of each.  With a
 // slot map the queries are first gathered onto the kept slots (into qc, batch x map.n_pad words, or a stream-ordered allocation when qc
 // is NULL).  lone: batch == 1 answered as cpir_server_respond_device does (one launch, no batching logic).

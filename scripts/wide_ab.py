@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Fused batches at a BASELINE shape: passes of 12 through the step-major kernel (respond.wide_min_batch = 0) against the wide pass (up to
 24 queries per stream of the database), microseconds per query from events, responses compared with each other.
-   python scripts/wide_ab.py [N C b]          (default: 2^20 keys x 1 kB = 1179648 x 940, b = 9)"""
+   python scripts/wide_ab.py [N C b [HOLES]]   (default: 2^20 keys x 1 kB = 1179648 x 940, b = 9; HOLES: fraction of the rows set to zero --
+                                                a real encoded database has 0.111 -- which the server then leaves out of its image)"""
 import os
 import sys
 
@@ -16,8 +17,13 @@ dev = cp.Device(0)
 stream = torch.cuda.current_stream()
 D = torch.empty((N, C), dtype=torch.int32, device="cuda")
 dev.synth_fill(D, N * C, 0xD, mask=(1 << b) - 1, stream=stream)
+if len(sys.argv) >= 5 and float(sys.argv[4]) > 0:
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    D[torch.rand(N, device="cuda", generator=g) < float(sys.argv[4])] = 0
 srv = cp.Server.from_device_matrix(D, N, C, b, device=dev, stream=stream)
 torch.cuda.synchronize()
+print("slots served:", srv.slots_served(), flush=True)
 del D
 NQ = 96
 q = torch.empty((NQ, N), dtype=torch.int32, device="cuda")
