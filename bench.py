@@ -898,21 +898,25 @@ def host_path_timing(server, q_pool, N, torch, full=True):
     qs = [q_pool[i].cpu().numpy().view(np.uint32) for i in range(min(16, q_pool.shape[0]))]
     for q in qs[:4]:
         server.respond_array(q)
-    t0 = time.perf_counter()
     n1 = 64
-    for i in range(n1):
-        server.respond_array(qs[i % len(qs)])
-    lat = (time.perf_counter() - t0) / n1
+
+    def closed_loop(get):  # mean of n1 calls back to back (the figure a closed-loop caller sees) and their median (one stall in 64 calls
+        ts = []            # -- a helper thread losing its core for a few ms -- moves the mean by 50 us and the median not at all)
+        t_start = time.perf_counter()
+        for i in range(n1):
+            t_a = time.perf_counter()
+            server.respond_array(get(i))
+            ts.append(time.perf_counter() - t_a)
+        return (time.perf_counter() - t_start) / n1, float(np.median(ts))
+
+    lat, lat_med = closed_loop(lambda i: qs[i % len(qs)])
     # the same single caller with its query in page-locked memory (cpir_host_alloc): DMA straight from the caller's buffer
     pins = [cp.PinnedArray(N) for _ in range(16)]
     for i, p in enumerate(pins):
         p.array[:] = qs[i % len(qs)]
     for _ in range(3):
         server.respond_array(pins[0].array)
-    t0 = time.perf_counter()
-    for i in range(n1):
-        server.respond_array(pins[0].array)
-    lat_pinned = (time.perf_counter() - t0) / n1
+    lat_pinned, lat_pinned_med = closed_loop(lambda i: pins[0].array)
     # the same with the in-place read switched off (upload first, as concurrent callers do): what the zero-copy path saves
     cp.tuning_set("respond.host_zero_copy", 0)
     try:
@@ -941,6 +945,8 @@ def host_path_timing(server, q_pool, N, torch, full=True):
         out = {
             "one_caller_us_per_query": round(lat * 1e6, 1),
             "one_caller_pinned_query_us_per_query": round(lat_pinned * 1e6, 1),
+            "one_caller_median_us": round(lat_med * 1e6, 1),
+            "one_caller_pinned_query_median_us": round(lat_pinned_med * 1e6, 1),
             "one_caller_pinned_query_upload_first_us_per_query": round(lat_pinned_upload * 1e6, 1),
             "eight_callers_queries_per_sec": round(throughput(8, 48, False), 1),
             "eight_callers_pinned_queries_per_sec": round(throughput(8, 48, True), 1),
@@ -953,6 +959,8 @@ def host_path_timing(server, q_pool, N, torch, full=True):
         "one_caller_us_per_query": round(lat * 1e6, 1),
         "one_caller_queries_per_sec": round(1.0 / lat, 1),
         "one_caller_pinned_query_us_per_query": round(lat_pinned * 1e6, 1),
+        "one_caller_median_us": round(lat_med * 1e6, 1),
+        "one_caller_pinned_query_median_us": round(lat_pinned_med * 1e6, 1),
         "one_caller_pinned_query_upload_first_us_per_query": round(lat_pinned_upload * 1e6, 1),
         "four_callers_queries_per_sec": round(throughput(4, 64, False), 1),
         "four_callers_pinned_queries_per_sec": round(throughput(4, 64, True), 1),
