@@ -237,9 +237,9 @@ uint64_t cpir_respond_scratch_words(const cpir_dtc_layout* layout);
 int cpir_op_respond(cpir_device* dev, const uint32_t* dtc, const cpir_dtc_layout* layout, const uint32_t* q,
                     uint64_t q_len, uint64_t q_slot_offset, uint32_t* r, uint32_t* scratch, void* stream);
 /* Same contraction for `batch` queries (q: batch x q_len, r: batch x C, row-major): with "respond.batch_fusion" on (the default) the
- * queries share streams of the database -- on the planar packing up to 12 per pass (three sets of 16 A rows on the i8 matrix cores,
- * 4 queries each; 8 where the tile-major kernel runs the launch), any batch size in as few passes as that allows; off: one pass each,
- * all in one launch.  Semantically `batch` independent cpir_op_respond calls, bit for bit. */
+ * queries share streams of the database -- on the planar packing up to 24 per pass (six sets of 16 A rows on the i8 matrix cores,
+ * 4 queries each: the wide pass; cpir_respond_batch_pass_width says how a batch is cut), any batch size in as few passes as that
+ * allows; off: one pass each, all in one launch.  Semantically `batch` independent cpir_op_respond calls, bit for bit. */
 uint64_t cpir_respond_batch_scratch_words(const cpir_dtc_layout* layout, uint32_t batch);
 int cpir_op_respond_batch(cpir_device* dev, const uint32_t* dtc, const cpir_dtc_layout* layout, const uint32_t* q,
                           uint64_t q_len, uint64_t q_slot_offset, uint32_t batch, uint32_t* r, uint32_t* scratch,
