@@ -150,7 +150,7 @@ struct Server {
     uint32_t* partials = nullptr;      // root: shards x kBatchCap x C
     hipEvent_t in_ev = nullptr, done_ev = nullptr;  // root: the queries are ready / the table has been summed (it may be overwritten)
   };
-  static constexpr uint32_t kBatchCap = 32;  // queries per round of a device-resident group call (larger batches go round by round)
+  static constexpr uint32_t kBatchCap = 48;  // queries per round of a device-resident group call: two wide passes of 24 per shard (larger batches go round by round)
   static constexpr int kGroupCtx = 4;  // concurrent callers served at once; further callers wait
   GroupDevCtx gdev[kGroupCtx];
   uint32_t gdev_next = 0;

@@ -163,3 +163,31 @@ def test_wide_pass_on_a_compacted_database_and_a_group(orc, device):
     finally:
         srv.close()
         grp.close()
+
+
+def test_wide_pass_large_batches_and_their_remainders(orc, device):
+    """batches far beyond one launch's passes: as few passes as 24 queries each allow, all of the same width, and what is left over as
+    a launch of its own -- 241 = 10 x 22 + 21, 1 009 = 42 x 24 + 1 (a remainder of ONE query), 100 = 5 x 20; the responses are those of
+    100 distinct queries repeated"""
+    import torch
+
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(1009)
+    stream = torch.cuda.current_stream()
+    b, N, C = 9, 2048 + 300, 70
+    D = random_db_matrix(rng, N, C, b)
+    dtc = orc.row_wise_compress(orc.transpose(D), b)
+    srv = cp.Server.from_compressed(dtc, N, b, device=device)
+    base = np.stack([random_query(rng, N) for _ in range(100)])
+    want = _responses(orc, base, dtc, N, b)
+    layout = srv.physical_layout
+    assert [cp.respond_batch_pass_width(layout, k) for k in (1, 4, 5, 24, 25, 32, 48, 100, 241, 1009)] == [1, 4, 5, 24, 13, 16, 24, 20, 22, 24]
+    for k in (100, 241, 1009):
+        idx = np.arange(k) % 100
+        Q_dev = torch.from_numpy(base[idx].view(np.int32)).cuda()
+        R = torch.full((k, C), -1, dtype=torch.int32, device="cuda")
+        srv.respond_batch_device(Q_dev, k, R, stream=stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(R.cpu().numpy().view(np.uint32), want[idx]), k
+    srv.close()
