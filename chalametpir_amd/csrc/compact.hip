@@ -69,6 +69,35 @@ __global__ void __launch_bounds__(kThreads) gather_query_kernel(const uint32_t* 
   }
 }
 
+// The same two questions asked of a database that arrives in the REFERENCE's compressed form (C rows of W words, cf fields of 32 / cf bits
+// a word; cpir_server_from_compressed): word w of the OR over all rows tells which of its cf slots hold something ...
+__global__ void __launch_bounds__(kThreads) or_rows_kernel(const uint32_t* __restrict__ src, uint64_t W, uint32_t C, uint32_t* __restrict__ ored) {
+  for (uint64_t w = (uint64_t)blockIdx.x * kThreads + threadIdx.x; w < W; w += (uint64_t)gridDim.x * kThreads) {
+    uint32_t v = 0;
+    for (uint32_t c = 0; c < C; c++) v |= src[(uint64_t)c * W + w];
+    ored[w] = v;
+  }
+}
+
+// ... and the compressed matrix of the kept slots alone: field j of word wc of row c is the field of slot keep[cf * wc + j] (0 beyond the kept slots)
+__global__ void __launch_bounds__(kThreads) gather_compressed_kernel(const uint32_t* __restrict__ src, uint64_t W, const uint32_t* __restrict__ keep,
+                                                                      uint64_t n_kept, uint32_t C, uint32_t cf, uint64_t Wc, uint32_t* __restrict__ out) {
+  const uint32_t S = 32 / cf;
+  const uint32_t slot_mask = S == 32 ? 0xFFFFFFFFu : ((1u << S) - 1u);
+  const uint64_t total = (uint64_t)C * Wc;
+  for (uint64_t t = (uint64_t)blockIdx.x * kThreads + threadIdx.x; t < total; t += (uint64_t)gridDim.x * kThreads) {
+    const uint64_t c = t / Wc, wc = t % Wc;
+    uint32_t v = 0;
+    for (uint32_t j = 0; j < cf; j++) {
+      const uint64_t i = wc * cf + j;
+      if (i >= n_kept) break;
+      const uint32_t n = keep[i];
+      v |= ((src[c * W + n / cf] >> ((n % cf) * S)) & slot_mask) << (j * S);
+    }
+    out[t] = v;
+  }
+}
+
 __global__ void __launch_bounds__(kThreads) rank_fill_kernel(const uint32_t* __restrict__ keep, uint64_t n_kept, uint32_t* __restrict__ rank) {
   for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < n_kept; i += (uint64_t)gridDim.x * kThreads) rank[keep[i]] = (uint32_t)i;
 }
@@ -148,6 +177,13 @@ int build_slot_map(const Device* dev, const uint32_t* D_dev, uint64_t ldd, uint6
   if (e == hipSuccess) e = e2;
   CPIR_HIP_TRY(e);
   if (or_of_entries_host) *or_of_entries_host = ored;
+  return slot_map_from_flags(flags, N, stream, map);
+}
+
+// flags[n] != 0: slot n holds something.  Fills `map` if the tuning mode says the empty slots are worth skipping; synchronises `stream`.
+int slot_map_from_flags(const std::vector<uint8_t>& flags, uint64_t N, hipStream_t stream, SlotMap* map) {
+  const int mode = compact_slots_mode();
+  hipError_t e = hipSuccess;
   uint64_t kept = 0;
   for (uint64_t n = 0; n < N; n++) kept += flags[n];
   const uint64_t zeros = N - kept;
@@ -172,6 +208,37 @@ int build_slot_map(const Device* dev, const uint32_t* D_dev, uint64_t ldd, uint6
   map->keep_bits.assign((size_t)(N + 7) / 8 + 8, 0);
   for (uint64_t n = 0; n < N; n++)
     if (flags[n]) map->keep_bits[(size_t)(n >> 3)] |= (uint8_t)(1u << (n & 7));
+  return CPIR_OK;
+}
+
+// The slot map of a database in the reference's compressed form on the device (C x W words, cf fields of 32 / cf bits a word, b of them
+// significant).  Synchronises `stream`; map->n_kept == 0 afterwards means "serve every slot".
+int build_slot_map_from_compressed(const Device* dev, const uint32_t* src_dev, uint64_t W, uint64_t N, uint32_t C, uint32_t b, uint32_t cf,
+                                   hipStream_t stream, SlotMap* map) {
+  map->reset();
+  if (compact_slots_mode() == 0 || N == 0 || N >= 0xFFFFFFF0ull || cf == 0 || cf > 32) return CPIR_OK;
+  uint32_t* ored_dev = nullptr;
+  CPIR_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&ored_dev), (size_t)W * 4, stream));
+  hipLaunchKernelGGL(or_rows_kernel, dim3(grid_for_items(dev, W)), dim3(kThreads), 0, stream, src_dev, W, C, ored_dev);
+  hipError_t e = hipGetLastError();
+  std::vector<uint32_t> ored((size_t)W);
+  if (e == hipSuccess) e = hipMemcpyAsync(ored.data(), ored_dev, (size_t)W * 4, hipMemcpyDeviceToHost, stream);
+  const hipError_t e2 = hipStreamSynchronize(stream);
+  (void)hipFreeAsync(ored_dev, stream);
+  if (e == hipSuccess) e = e2;
+  CPIR_HIP_TRY(e);
+  const uint32_t S = 32 / cf, mask = (b >= 32) ? 0xFFFFFFFFu : ((1u << b) - 1u);
+  std::vector<uint8_t> flags((size_t)N);
+  for (uint64_t n = 0; n < N; n++) flags[(size_t)n] = ((ored[(size_t)(n / cf)] >> ((n % cf) * S)) & mask) != 0 ? 1 : 0;
+  return slot_map_from_flags(flags, N, stream, map);
+}
+
+int launch_gather_compressed(const Device* dev, const uint32_t* src_dev, uint64_t W, const SlotMap& map, uint32_t C, uint32_t cf, uint64_t Wc,
+                             uint32_t* out, hipStream_t stream) {
+  if (!src_dev || !out || !map.keep_dev || cf == 0) return CPIR_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(gather_compressed_kernel, dim3(grid_for_items(dev, (uint64_t)C * Wc)), dim3(kThreads), 0, stream, src_dev, W, map.keep_dev,
+                     map.n_kept, C, cf, Wc, out);
+  CPIR_HIP_TRY(hipGetLastError());
   return CPIR_OK;
 }
 

@@ -184,6 +184,11 @@ int compact_slots_mode();  // tuning "layout.compact_slots": 0 never, 1 (default
 void set_compact_slots_mode(int m);
 int build_slot_map(const Device* dev, const uint32_t* D_dev, uint64_t ldd, uint64_t N, uint32_t C, uint32_t b, hipStream_t stream, SlotMap* map,
                    uint32_t* or_of_entries_host);
+int slot_map_from_flags(const std::vector<uint8_t>& flags, uint64_t N, hipStream_t stream, SlotMap* map);
+int build_slot_map_from_compressed(const Device* dev, const uint32_t* src_dev, uint64_t W, uint64_t N, uint32_t C, uint32_t b, uint32_t cf,
+                                   hipStream_t stream, SlotMap* map);  // (cpir_server_from_compressed: the database arrives in the reference's form)
+int launch_gather_compressed(const Device* dev, const uint32_t* src_dev, uint64_t W, const SlotMap& map, uint32_t C, uint32_t cf, uint64_t Wc,
+                             uint32_t* out, hipStream_t stream);
 int launch_gather_rows(const Device* dev, const uint32_t* D_dev, uint64_t ldd, const SlotMap& map, uint32_t C, uint32_t* out, hipStream_t stream);
 int launch_gather_query(const Device* dev, const uint32_t* q, uint64_t q_len, uint64_t q_slot_offset, const SlotMap& map, uint32_t batch,
                         uint32_t* out, hipStream_t stream);

@@ -719,12 +719,28 @@ int cpir_server_from_compressed(cpir_device* dev, const uint32_t* compressed, ui
   CPIR_HIP_TRY(CPIR_HIP_MALLOC(&src.p, src_bytes));
   Server* srv = server_new(dev, L, 0, N);
   auto fail = [&](int st) { server_destroy(srv); return st; };
-  hipError_t e = CPIR_HIP_MALLOC(&srv->dtc, (size_t)L.total_words * 4);
-  if (e != hipSuccess) { set_last_hip_error(e, "hipMalloc(dtc)", __FILE__, __LINE__); return fail(CPIR_ERR_OUT_OF_DEVICE_MEMORY); }
-  e = hipMemcpyAsync(src.p, compressed, src_bytes, hipMemcpyHostToDevice, dev->stream);
+  hipError_t e = hipMemcpyAsync(src.p, compressed, src_bytes, hipMemcpyHostToDevice, dev->stream);
   if (e != hipSuccess) { set_last_hip_error(e, "hipMemcpyAsync", __FILE__, __LINE__); return fail(CPIR_ERR_HIP); }
-  int st = launch_dtc_import(dev, (const uint32_t*)src.p, L, srv->dtc, dev->stream);
+  // an imported database is served without its empty rows like one that was set up here (compact.hip): the OR over the compressed rows
+  // says which slots hold something, the kept slots' fields are gathered into a compressed matrix of their own, and THAT is imported
+  SlotMap map;
+  int st = build_slot_map_from_compressed(dev, (const uint32_t*)src.p, L.words_per_row, N, C, b, L.compression_factor, dev->stream, &map);
   if (st != CPIR_OK) return fail(st);
+  cpir_dtc_layout P = L;
+  DevBuf compact;
+  if (map.active()) {
+    st = dtc_layout_for_packing(map.n_kept, C, b, L.packing, &P);
+    if (st != CPIR_OK) return fail(st);
+    e = CPIR_HIP_MALLOC(&compact.p, (size_t)C * P.words_per_row * 4);
+    if (e != hipSuccess) { set_last_hip_error(e, "hipMalloc(compact compressed matrix)", __FILE__, __LINE__); return fail(CPIR_ERR_OUT_OF_DEVICE_MEMORY); }
+    st = launch_gather_compressed(dev, (const uint32_t*)src.p, L.words_per_row, map, C, L.compression_factor, P.words_per_row, (uint32_t*)compact.p, dev->stream);
+    if (st != CPIR_OK) return fail(st);
+  }
+  e = CPIR_HIP_MALLOC(&srv->dtc, (size_t)P.total_words * 4);
+  if (e != hipSuccess) { set_last_hip_error(e, "hipMalloc(dtc)", __FILE__, __LINE__); return fail(CPIR_ERR_OUT_OF_DEVICE_MEMORY); }
+  st = launch_dtc_import(dev, map.active() ? (const uint32_t*)compact.p : (const uint32_t*)src.p, P, srv->dtc, dev->stream);
+  if (st != CPIR_OK) return fail(st);
+  server_set_physical(srv, P, &map);
   e = hipStreamSynchronize(dev->stream);
   if (e != hipSuccess) { set_last_hip_error(e, "hipStreamSynchronize", __FILE__, __LINE__); return fail(CPIR_ERR_HIP); }
   *out = static_cast<cpir_server*>(srv);

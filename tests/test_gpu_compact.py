@@ -302,3 +302,44 @@ def test_key_value_setup_serves_exactly_the_owned_slots(arity, orc, device):
     q = random_query(rng, N)
     assert np.array_equal(srv.respond_array(q), orc.row_vector_x_compressed_transposed_matrix(q, want_dtc, N, b)[0])
     srv.close()
+
+
+@pytest.mark.parametrize("b,pattern", [(9, "random"), (10, "runs"), (6, "alternate"), (13, "random")])
+def test_import_of_a_compressed_database_leaves_the_empty_rows_out_too(b, pattern, orc, device):
+    """cpir_server_from_compressed (the database arrives in the reference's compressed form, `matrix.rs:98-205`): which slots hold something
+    is read off the OR of the compressed rows, the kept slots' fields are gathered into a compressed matrix of their own and that is
+    imported -- same map, same image, same answers as the server that was set up from the matrix; dirty bits beyond the b significant bits
+    of a field (and beyond the cf fields of a word) neither keep a row nor survive the export"""
+    import torch
+
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(7100 + b)
+    cf = cf_of(b)
+    stream = torch.cuda.current_stream()
+    for N, C in ((cf * 1024 * 2 + 7, 29), (3000, 5)):
+        D, kept = holey_matrix(rng, N, C, b, pattern=pattern)
+        want_dtc = oracle_dtc(orc, D, b)
+        dirty = want_dtc.copy()
+        S = 32 // cf
+        if S > b:  # bits above the field inside its slot
+            dirty |= np.uint32(1 << (S - 1))
+        if cf * S < 32:  # bits above the last slot of a word
+            dirty |= np.uint32(1 << 31)
+        for src in (want_dtc, dirty):
+            srv = cp.Server.from_compressed(src, N, b, device=device)
+            assert srv.slots_served() == (kept.size, N) and np.array_equal(srv.kept_slots(), kept)
+            assert np.array_equal(srv.export_compressed(), want_dtc)
+            Q = np.stack([random_query(rng, N) for _ in range(14)])
+            want = np.stack([orc.row_vector_x_compressed_transposed_matrix(q, want_dtc, N, b)[0] for q in Q])
+            assert np.array_equal(srv.respond_array(Q[0]), want[0])
+            R = torch.full((14, C), -1, dtype=torch.int32, device="cuda")
+            srv.respond_batch_device(dev(Q), 14, R, stream=stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(host(R), want)
+            srv.close()
+    cp.tuning_set("layout.compact_slots", 0)
+    srv = cp.Server.from_compressed(want_dtc, N, b, device=device)
+    assert srv.slots_served() == (N, N) and np.array_equal(srv.respond_array(Q[1]), want[1])
+    srv.close()
+    cp.tuning_set("layout.compact_slots", 1)
