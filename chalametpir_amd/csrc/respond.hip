@@ -455,7 +455,8 @@ bool respond_batch_takes_slot_map(const cpir_dtc_layout& L, uint32_t batch, bool
     std::lock_guard<std::mutex> lk(g_tuning_mu);
     t = g_tuning;
   }
-  if (L.packing != CPIR_PACK_PLANAR || t.ks_major < 1 || t.wide_min_batch <= 0 || !t.nontemporal || q_len >= ((uint64_t)1 << 28) || batch == 0) return false;
+  // (ks_major other than the default 1 is a diagnosis setting that sends single-pass launches to the step-major kernel: the long way then)
+  if (L.packing != CPIR_PACK_PLANAR || t.ks_major != 1 || t.wide_min_batch <= 0 || !t.nontemporal || q_len >= ((uint64_t)1 << 28) || batch == 0) return false;
   if (lone || batch == 1) return true;      // one pass of one query
   if (!t.batch_fusion) return false;        // many passes of one query each: the tile-major kernel
   const uint32_t W = respond_planar_pass_width(L, batch);
@@ -519,7 +520,7 @@ int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout
   // 36.9 -> 30.9 on a 1/8 shard); many passes of up to 4 queries stay on the tile-major / step-major kernels (the headline's loop)
   if (L.packing == CPIR_PACK_PLANAR &&
       (batch > CPIR_PLANAR_MAX_QUERIES_PER_PASS ||
-       (t.wide_min_batch > 0 && t.ks_major >= 1 && (batch >= (uint32_t)t.wide_min_batch || passes == 1))))
+       (t.wide_min_batch > 0 && t.ks_major >= 1 && (batch >= (uint32_t)t.wide_min_batch || (passes == 1 && t.ks_major == 1)))))
     return launch_respond_planar_wide(dev, dtc, L, q, q_len, q_slot_offset, batch, passes, r, stream, t.nontemporal != 0, t.xcd_split != 0, keep);
   if (keep) return CPIR_ERR_INVALID_ARGUMENT;  // only the wide pass applies a slot map itself: the caller gathers the queries first
   if (L.packing == CPIR_PACK_PLANAR)  // the matrix-core path (respond_planar.hip)

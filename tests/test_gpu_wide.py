@@ -191,3 +191,49 @@ def test_wide_pass_large_batches_and_their_remainders(orc, device):
         torch.cuda.synchronize()
         assert np.array_equal(R.cpu().numpy().view(np.uint32), want[idx]), k
     srv.close()
+
+
+def test_wide_pass_random_shapes(orc, device):
+    """seeded random shapes through the wide pass: bit length, slots around the block count of the one-block-per-CU grid (fewer steps
+    than blocks, ragged last steps), columns around the 8-tile groups, shard windows that start at odd slots, query blocks shifted off
+    their 16-byte alignment, any batch size up to 30, with and without rows left out of the image -- against the oracle"""
+    import torch
+
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(2424_1)
+    stream = torch.cuda.current_stream()
+    for trial in range(36):
+        b = int(rng.choice([4, 6, 8, 9, 9, 10, 12, 14]))
+        cf = cf_of(b)
+        steps = int(rng.choice([1, 2, 3, 7, 31, 200, 257, 300]))
+        N = max(cf, steps * 512 - int(rng.integers(0, 512)))
+        C = int(rng.choice([1, 3, 16, 17, 127, 128, 129, 260]))
+        if N * C > 6_000_000:
+            C = max(1, 6_000_000 // N)
+        D = random_db_matrix(rng, N, C, b)
+        holes = trial % 3 == 0
+        if holes:
+            D[rng.random(N) < 0.2] = 0
+        lo = int(rng.integers(0, max(1, N // 3)))
+        hi = N - int(rng.integers(0, max(1, N // 5)))
+        if rng.integers(0, 3) == 0:
+            lo, hi = 0, N
+        dtc = orc.row_wise_compress(orc.transpose(D[lo:hi]), b)
+        D_dev = torch.from_numpy(np.ascontiguousarray(D[lo:hi]).view(np.int32)).cuda()
+        srv = cp.Server.from_device_matrix(D_dev, hi - lo, C, b, device=device, slot_offset=lo, total_slots=N)
+        k = int(rng.integers(1, 31))
+        Q = np.stack([random_query(rng, N) for _ in range(k)])
+        want = np.stack([orc.row_vector_x_compressed_transposed_matrix(q[lo:hi], dtc, hi - lo, b)[0] for q in Q])
+        shift = int(rng.integers(0, 4))
+        buf = torch.zeros(k * N + 8, dtype=torch.int32, device="cuda")
+        buf[shift:shift + k * N] = torch.from_numpy(Q.view(np.int32)).cuda().reshape(-1)
+        R = torch.full((k, C), -1, dtype=torch.int32, device="cuda")
+        srv.respond_batch_device(buf[shift:shift + k * N].view(k, N), k, R, stream=stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(R.cpu().numpy().view(np.uint32), want), (trial, b, N, C, lo, hi, shift, k, holes)
+        r = torch.full((C,), -1, dtype=torch.int32, device="cuda")
+        srv.respond_device(buf[shift:shift + N], r, stream=stream)  # one query, one pass: the wide kernel with one row set
+        torch.cuda.synchronize()
+        assert np.array_equal(r.cpu().numpy().view(np.uint32), want[0]), (trial, "lone")
+        srv.close()
