@@ -704,8 +704,9 @@ int respond_batched(const Device* dev, const uint32_t* dtc, const cpir_dtc_layou
   }
   uint32_t done = 0;
   if (L.packing == CPIR_PACK_PLANAR) {
-    // the matrix-core kernels take any 1..W queries per pass (W = 12 where the step-major kernel runs the launch, else 8): passes of W,
-    // then the rest -- as one pass if that pass may be as wide, else as passes of 8 and a last one
+    // the matrix-core kernels take any 1..W queries per pass (W up to 24: the wide pass, as few passes as that allows, all of about the same
+    // width; with it switched off 12 where the step-major kernel runs the launch, else 8): passes of W, then the rest -- as one pass if
+    // that pass may be as wide, else as passes of 8 and a last one
     const uint32_t W = respond_planar_pass_width(L, batch);
     if (batch >= W) {
       CPIR_TRY(launch_respond(dev, dtc, L, q, q_len, q_slot_offset, W, batch / W, r, scratch, stream, keep));
@@ -713,7 +714,7 @@ int respond_batched(const Device* dev, const uint32_t* dtc, const cpir_dtc_layou
     }
     while (done < batch) {
       const uint32_t left = batch - done;
-      const uint32_t w = left <= respond_planar_pass_width(L, left) ? left : 8u;  // (a single pass of up to 12 is always step-major)
+      const uint32_t w = left <= respond_planar_pass_width(L, left) ? left : 8u;  // (what is left fits one pass -- a launch of one pass is a wide pass whatever its width; 8s and a last one with the wide pass off)
       CPIR_TRY(launch_respond(dev, dtc, L, q + (uint64_t)done * q_len, q_len, q_slot_offset, w, 1, r + (uint64_t)done * L.num_cols, scratch, stream, keep));
       done += w;
     }

@@ -430,8 +430,9 @@ bool respond_batch_fusion() {
   return g_tuning.batch_fusion != 0;
 }
 
-// queries per pass for a fused batch of `batch` queries on a planar image: 12 where passes of 12 would be taken by the step-major kernel
-// (a batch of up to 12 is ONE pass, which always is; larger batches on databases beyond the interleaving size too), else 8
+// queries per pass for a fused batch of `batch` queries on a planar image: what the wide pass makes of it (below); with the wide pass
+// switched off 12 where passes of 12 would be taken by the step-major kernel (a batch of up to 12 is ONE pass, which always is; larger
+// batches on databases beyond the interleaving size too), else 8
 uint32_t respond_planar_pass_width(const cpir_dtc_layout& L, uint32_t batch) {
   Tuning t;
   {

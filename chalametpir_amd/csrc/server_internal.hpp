@@ -190,7 +190,7 @@ void device_retain(Device* d);
 void device_release(Device* d);
 Server* server_new(Device* dev, const cpir_dtc_layout& L, uint64_t slot_offset, uint64_t total_slots);
 void server_destroy(Server* srv);
-// any batch size on device pointers: with batch fusion every pass answers up to 12 queries (8 where the tile-major kernel runs) from one stream of the database, without it
+// any batch size on device pointers: with batch fusion every pass answers up to 24 queries (the wide pass; 12 / 8 with it switched off) from one stream of the database, without it
 // every query is its own pass; either way the passes of one kind go into ONE launch
 int respond_batched(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len, uint64_t q_slot_offset,
                     uint32_t batch, uint32_t* r, uint32_t* scratch, hipStream_t stream, const uint32_t* keep = nullptr);
