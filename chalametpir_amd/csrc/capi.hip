@@ -349,7 +349,7 @@ const char* cpir_respond_kernel_name(const cpir_dtc_layout* layout) { return lay
 const char* cpir_pack_kernel_name(const cpir_dtc_layout* layout) { return layout ? pack_kernel_name(*layout) : ""; }
 uint32_t cpir_respond_batch_pass_width(const cpir_dtc_layout* layout, uint32_t batch) {
   if (!layout || batch == 0) return 0;
-  if (layout->packing != CPIR_PACK_PLANAR) return 4;
+  if (layout->packing != CPIR_PACK_PLANAR) return batch >= 4 ? 4 : (batch >= 2 ? 2 : 1);  // (passes of 4, then 2, then 1)
   const uint32_t w = respond_planar_pass_width(*layout, batch);
   return w < batch ? w : batch;
 }

@@ -282,7 +282,7 @@ const char* cpir_respond_kernel_name(const cpir_dtc_layout* layout);
 const char* cpir_pack_kernel_name(const cpir_dtc_layout* layout);
 /* Queries per pass a FUSED batch of `batch` queries is cut into on this layout under the current tuning (the queries of a pass share one
  * stream of the database): planar 24 at most -- as few passes as that allows, all of about the same width -- where the wide pass takes the
- * batch ("respond.wide_min_batch"), else 12 or 8; other packings 4.  0 for a NULL layout or an empty batch. */
+ * batch ("respond.wide_min_batch"), else 12 or 8; other packings 4 (then 2, then 1).  0 for a NULL layout or an empty batch. */
 uint32_t cpir_respond_batch_pass_width(const cpir_dtc_layout* layout, uint32_t batch);
 
 /* ------------------------------------------------------------------------------------------------

@@ -261,3 +261,30 @@ def test_host_gather_variants_agree(native):
             hi = int(rng.integers(lo, n + 1))
             assert np.array_equal(cp.host_compress(src[:n], keep, lo, hi), src[lo:hi][keep[lo:hi]]), (n, lo, hi)
     assert cp.host_compress(src[:64], np.zeros(64, dtype=bool)).size == 0 and np.array_equal(cp.host_compress(src[:64], np.ones(64, dtype=bool)), src[:64])
+
+
+def test_how_a_fused_batch_is_cut_into_passes():
+    """cpir_respond_batch_pass_width (host-side arithmetic, no GPU): on the planar packing as few passes as 24 queries each allow, all of
+    about the same width; with the wide pass switched off passes of 12 (8 where interleaved tile-major passes take the launch); never
+    more than the batch; other packings 4; every cut covers the batch with passes of at most that width plus a remainder below it"""
+    import chalametpir_amd as cp
+
+    try:
+        planar = cp.dtc_layout_for(1179648, 940, 9)
+        assert int(planar.packing) == 2
+        widths = {k: cp.respond_batch_pass_width(planar, k) for k in (1, 4, 5, 12, 13, 24, 25, 32, 47, 48, 49, 72, 96, 100, 241, 1009)}
+        assert widths == {1: 1, 4: 4, 5: 5, 12: 12, 13: 13, 24: 24, 25: 13, 32: 16, 47: 24, 48: 24, 49: 17, 72: 24, 96: 24, 100: 20, 241: 22, 1009: 24}
+        for k, w in widths.items():
+            assert 1 <= w <= min(k, 24) and (k // w) * w + (k % w) == k and -(-k // w) <= -(-k // 24) + 1
+        cp.tuning_set("respond.wide_min_batch", 0)
+        assert [cp.respond_batch_pass_width(planar, k) for k in (5, 12, 13, 48)] == [5, 12, 12, 12]
+        small = cp.dtc_layout_for(147456, 940, 9)  # a 1/8 shard: many passes go interleaved through the tile-major kernel, 8 a pass
+        assert cp.respond_batch_pass_width(small, 48) == 8 and cp.respond_batch_pass_width(small, 12) == 12
+        cp.tuning_set("respond.wide_min_batch", 5)
+        assert cp.respond_batch_pass_width(small, 48) == 24
+        cp.tuning_set("layout.planar", 0)
+        other = cp.dtc_layout_for(1179648, 940, 9)
+        assert int(other.packing) != 2 and cp.respond_batch_pass_width(other, 48) == 4 and cp.respond_batch_pass_width(other, 3) == 2
+        assert cp.respond_batch_pass_width(planar, 0) == 0
+    finally:
+        cp.tuning_reset()
