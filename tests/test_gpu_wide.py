@@ -116,10 +116,13 @@ def test_wide_pass_over_column_windows(orc, device):
 
     rng = np.random.default_rng(3100)
     stream = torch.cuda.current_stream()
-    for b, N, C in ((9, 2 * 512 + 77, 3100), (6, 700, 1601)):
+    for b, N, C, holes in ((9, 2 * 512 + 77, 3100, False), (6, 700, 1601, False), (9, 3 * 512 + 5, 2100, True)):
         D = random_db_matrix(rng, N, C, b)
+        if holes:  # ... and with rows left out of the image: the slot map applied in the kernel, window by window
+            D[rng.random(N) < 0.25] = 0
         dtc = orc.row_wise_compress(orc.transpose(D), b)
         srv = cp.Server.from_compressed(dtc, N, b, device=device)
+        assert (srv.slots_served()[0] < N) == holes
         nq = 48
         Q = np.stack([random_query(rng, N) for _ in range(nq)])
         want = _responses(orc, Q, dtc, N, b)
