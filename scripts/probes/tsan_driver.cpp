@@ -2,7 +2,9 @@
 // host side of every translation unit with -fsanitize=thread into chalametpir_amd/lib/tsan/).  Drives, through the C ABI, what the
 // multi-threaded parts do: servers created and destroyed next to each other, lone pageable / page-locked callers (polled launch, in-place
 // read), bursts of concurrent callers (arenas, staging helpers), clones, the in-process group (worker threads), Server::setup (XOF
-// thread, background disposal).  Answers are compared with the first answer to the same query.  Run on the GPU box:
+// thread, background disposal); since round 4 also databases with empty rows (the slot map: built on import, applied by the staging helpers'
+// compress jobs for a lone caller and by the kernel for the arenas) and device-resident batches on a group from two threads (peer
+// exchange contexts).  Answers are compared with the first answer to the same query.  Run on the GPU box:
 //   TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0" chalametpir_amd/lib/tsan/tsan_driver
 // Reports whose stacks lie wholly inside the HIP runtime are the runtime's business (it is not instrumented); the ones to read name
 // cpir:: frames.
@@ -13,6 +15,8 @@
 #include <cstring>
 #include <thread>
 #include <vector>
+
+#include <hip/hip_runtime_api.h>
 
 #include "chalamet_hip.h"
 
@@ -47,6 +51,12 @@ static void exercise(cpir_device* dev, const Shape& sh, int round) {
   const uint64_t W = (sh.N + cf - 1) / cf;
   std::vector<uint32_t> dtc((size_t)sh.C * W);
   fill(dtc.data(), dtc.size(), 7 + round, 0xFFFFFFFFu);
+  if (round % 2 == 1) {  // every sixth slot holds nothing: the server leaves those out of its image and every path goes through the slot map
+    const uint32_t S = 32 / cf, slot_mask = S == 32 ? 0xFFFFFFFFu : ((1u << S) - 1u);
+    for (uint64_t n = 0; n < sh.N; n++)
+      if (mix(n * 31 + round) % 6 == 0)
+        for (uint32_t c = 0; c < sh.C; c++) dtc[(size_t)c * W + n / cf] &= ~(slot_mask << ((n % cf) * S));
+  }
   cpir_server* srv = nullptr;
   CK(cpir_server_from_compressed(dev, dtc.data(), sh.C, sh.N, sh.b, &srv));
   const int kQ = 4;
@@ -96,6 +106,9 @@ static void exercise_setup_and_group(cpir_device* dev, int round) {
   const uint32_t C = 20, b = 9;
   std::vector<uint32_t> D((size_t)N * C), hint1((size_t)CPIR_LWE_DIMENSION * C), hint2(hint1.size());
   fill(D.data(), D.size(), 99 + round, (1u << b) - 1);
+  if (round % 2 == 1)  // rows that hold nothing: both servers compact
+    for (uint64_t n = 0; n < N; n++)
+      if (mix(n + 17) % 5 == 0) memset(&D[(size_t)n * C], 0, (size_t)C * 4);
   uint8_t seed[CPIR_SEED_BYTE_LEN];
   for (int i = 0; i < CPIR_SEED_BYTE_LEN; i++) seed[i] = (uint8_t)(i * 7 + round);
   cpir_server *one = nullptr, *grp = nullptr;
@@ -116,6 +129,30 @@ static void exercise_setup_and_group(cpir_device* dev, int round) {
       }
     });
   for (auto& t : ts) t.join();
+  {  // device-resident batches on the group from two threads at once (each call takes the next exchange context)
+    const uint32_t kB = 5;
+    uint32_t *q_dev = nullptr, *r_dev = nullptr;
+    if (hipMalloc((void**)&q_dev, (size_t)kB * N * 4) != hipSuccess || hipMalloc((void**)&r_dev, (size_t)2 * kB * C * 4) != hipSuccess) exit(1);
+    for (uint32_t i = 0; i < kB; i++)
+      if (hipMemcpy(q_dev + (size_t)i * N, q.data(), N * 4, hipMemcpyHostToDevice) != hipSuccess) exit(1);
+    std::vector<std::thread> ds;
+    for (int t = 0; t < 2; t++)
+      ds.emplace_back([&, t] {
+        hipStream_t st;
+        if (hipStreamCreate(&st) != hipSuccess) exit(1);
+        std::vector<uint32_t> r((size_t)kB * C);
+        for (int k = 0; k < 3; k++) {
+          CK(cpir_server_respond_batch_device(grp, q_dev, kB, r_dev + (size_t)t * kB * C, nullptr, st));
+          if (hipMemcpyAsync(r.data(), r_dev + (size_t)t * kB * C, r.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) exit(1);
+          for (uint32_t i = 0; i < kB; i++)
+            if (memcmp(r.data() + (size_t)i * C, r1.data(), 4 * C) != 0) g_bad++;
+        }
+        (void)hipStreamDestroy(st);
+      });
+    for (auto& t : ds) t.join();
+    (void)hipFree(q_dev);
+    (void)hipFree(r_dev);
+  }
   cpir_server_release(grp);
   cpir_server_release(one);
 }
