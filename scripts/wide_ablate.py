@@ -27,7 +27,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     out = []
     for k in (16, 24, 48):
         r = torch.empty((k, C), dtype=torch.int32, device="cuda")
-        for _ in range(2):
+        for _ in range(24):  # (the clocks of a device that has just idled take a few milliseconds to settle)
             srv.respond_batch_device(q[:k], k, r, stream=stream)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
