@@ -30,7 +30,9 @@
 //     sum_i 2^(8i) (lo_i + 256 hi_i) is lane-local; one u32 atomicAdd per (wave, query, column) and tile group.
 #include "cpir_internal.hpp"
 
+#include <algorithm>
 #include <type_traits>
+#include <vector>
 
 namespace cpir {
 namespace {
@@ -69,6 +71,7 @@ struct PlanarArgs {
   uint64_t poll_ticks;       // ... after this many ticks of the 100 MHz wall clock
   const uint32_t* keep;      // wide pass: the database holds only the slots keep[0 .. num_slots) of the query (increasing, relative to q_slot_offset;
                              // compact.hip); NULL: slot n of the database is word q_slot_offset + n of the query
+  uint64_t* trace;           // step-major kernel, diagnosis only (CPIR_KS_TRACE): per block 4 words -- wall clock at entry, after the first fragments, at the end; visits
   uint32_t ablate;           // wide pass, diagnosis only (CPIR_WIDE_ABLATE; results are WRONG while non-zero): 1 no rebuild of the fragments, 2 no flush, 4 no MFMAs
 };
 
@@ -353,6 +356,7 @@ respond_planar_ks_kernel(const PlanarArgs a) {
   const uint32_t tail_visits = se > sb ? (uint32_t)((se - 1) / TG - sb / TG + 1) : 0;
   const uint32_t n_visits = rounds + tail_visits;
   if (n_visits == 0) return;  // block-uniform: an idle block takes part in nothing
+  if (a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 4 + 0] = wall_clock64(), a.trace[blockIdx.x * 4 + 3] = n_visits;
   // (the 64-bit divisions once, not per unit; plain scalars, no structs: selecting between structs captured by reference sends them
   // through scratch memory)
   const uint32_t tail_ks = tail0 + (uint32_t)(sb / TG), tail_tg0 = (uint32_t)(sb % TG);
@@ -553,6 +557,7 @@ respond_planar_ks_kernel(const PlanarArgs a) {
     a_finish(raw0, 0);
   }
   __syncthreads();
+  if (a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 4 + 1] = wall_clock64();
 
   int par = 0;
   // The NEXT visit's query words are requested in the first unit of the current visit; they are turned into fragments in the same
@@ -662,6 +667,7 @@ respond_planar_ks_kernel(const PlanarArgs a) {
   // ---- the last pass ----
   __syncthreads();
   flush_pass(pass, false);
+  if (a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 4 + 2] = wall_clock64();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
@@ -1145,6 +1151,7 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
   a.poll_ticks = fill ? (uint64_t)fill->timeout_us * 100 : 0;
   a.ablate = 0;
   a.keep = nullptr;
+  a.trace = nullptr;
   if (fill && (ks_mode != 3 || !fill->progress || !fill->abort_flag)) return CPIR_ERR_INVALID_ARGUMENT;
   a.q_scalar = (reinterpret_cast<uintptr_t>(q) % 16 != 0 || q_slot_offset % 4 != 0 || (batch * passes > 1 && q_len % 4 != 0)) ? 1u : 0u;
 
@@ -1204,7 +1211,40 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
       a.tg_n = a.tile_groups - a.tg_lo < tg_per_window ? a.tile_groups - a.tg_lo : tg_per_window;
       const uint64_t grid = grid_for_units(a.tg_n, &a.nx);
       const size_t racc_bytes = (size_t)batch * a.tg_n * (kM * 16) * sizeof(uint32_t);
+      // diagnosis (CPIR_KS_TRACE=1; launches in the in-place order only, i.e. the lone host caller's -- NOT the polled one, whose host side
+      // must keep running while the kernel does -- or respond.ks_major = 3): when each block started, had its first fragments, ended;
+      // printed per launch, which is synchronised for it
+      static const bool trace_env = getenv("CPIR_KS_TRACE") != nullptr;
+      static uint64_t* trace_dev = nullptr;
+      const bool tracing = trace_env && ks_mode == 3 && !fill && windows == 1 && grid <= 4096;
+      if (tracing) {
+        if (!trace_dev && hipMalloc(reinterpret_cast<void**>(&trace_dev), 4096 * 4 * sizeof(uint64_t)) != hipSuccess) trace_dev = nullptr;
+        if (trace_dev) (void)hipMemsetAsync(trace_dev, 0, 4096 * 4 * sizeof(uint64_t), stream);
+        a.trace = trace_dev;
+      }
       hipLaunchKernelGGL(fn_ks, dim3((unsigned)grid), dim3(kThreads), racc_bytes, stream, a);
+      if (tracing && trace_dev) {
+        std::vector<uint64_t> t((size_t)grid * 4);
+        if (hipMemcpyAsync(t.data(), trace_dev, t.size() * 8, hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess) {
+          uint64_t t0 = ~0ull;
+          for (uint64_t b2 = 0; b2 < grid; b2++)
+            if (t[b2 * 4] && t[b2 * 4] < t0) t0 = t[b2 * 4];
+          std::vector<double> st, ff, en;
+          for (uint64_t b2 = 0; b2 < grid; b2++)
+            if (t[b2 * 4]) st.push_back((t[b2 * 4] - t0) * 0.01), ff.push_back((t[b2 * 4 + 1] - t0) * 0.01), en.push_back((t[b2 * 4 + 2] - t0) * 0.01);
+          auto q3 = [](std::vector<double> v2, double* lo, double* med, double* hi) {
+            std::sort(v2.begin(), v2.end());
+            *lo = v2.front(), *med = v2[v2.size() / 2], *hi = v2.back();
+          };
+          if (!st.empty()) {
+            double a0, a1, a2, b0, b1, b2_, c0, c1, c2;
+            q3(st, &a0, &a1, &a2), q3(ff, &b0, &b1, &b2_), q3(en, &c0, &c1, &c2);
+            fprintf(stderr, "[ks trace] blocks %zu  start %.1f/%.1f/%.1f  first fragments %.1f/%.1f/%.1f  end %.1f/%.1f/%.1f us (min/median/max after the first block's start)\n",
+                    st.size(), a0, a1, a2, b0, b1, b2_, c0, c1, c2);
+          }
+        }
+        a.trace = nullptr;
+      }
     }
     CPIR_HIP_TRY(hipGetLastError());
     return CPIR_OK;
@@ -1264,6 +1304,7 @@ int launch_respond_planar_wide(const Device* dev, const uint32_t* dtc, const cpi
     return e ? (uint32_t)strtoul(e, nullptr, 0) : 0u;
   }();
   a.ablate = ablate_env;
+  a.trace = nullptr;
   a.keep = keep;  // (device memory, at least L.num_slots entries, 16-byte aligned; the caller has checked that the slots it names lie inside q)
   if (keep && reinterpret_cast<uintptr_t>(keep) % 16 != 0) return CPIR_ERR_INVALID_ARGUMENT;
 
