@@ -721,6 +721,7 @@ respond_planar_wide_kernel(const PlanarArgs a) {
   const uint64_t sb = units * j / nb, se = units * (j + 1) / nb;
   const uint32_t n_visits = se > sb ? (uint32_t)((se - 1) / TG - sb / TG + 1) : 0;
   if (n_visits == 0) return;  // block-uniform: an idle block takes part in nothing
+  if (a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 4 + 0] = wall_clock64(), a.trace[blockIdx.x * 4 + 3] = n_visits;
   const uint32_t first_ks = kb0 + (uint32_t)(sb / TG), first_tg0 = (uint32_t)(sb % TG), last_tg1 = (uint32_t)((se - 1) % TG) + 1;
   auto visit_ks = [=](uint32_t v) { return first_ks + v; };
   auto visit_tg0 = [=](uint32_t v) { return v == 0 ? first_tg0 : 0u; };
@@ -1005,6 +1006,7 @@ respond_planar_wide_kernel(const PlanarArgs a) {
 
   __syncthreads();
   if (!(a.ablate & 2u)) flush_pass(pass, false);
+  if (a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 4 + 2] = wall_clock64();
 }
 
 // r[q][c] += 128 * sum_n (q[n] - 0x80808080) over this block's slice of the valid slots, and (slice 0 only) += 0x80808080 * colsum[c]:
@@ -1335,7 +1337,39 @@ int launch_respond_planar_wide(const Device* dev, const uint32_t* dtc, const cpi
       if (grid == 0) grid = 1, a.nx = 1;
     }
     const size_t lds = (size_t)fixed + (size_t)a.tg_n * per_tg;
+    static const bool trace_env = getenv("CPIR_KS_TRACE") != nullptr;  // (diagnosis, as for the step-major kernel: per XCD here)
+    static uint64_t* trace_dev = nullptr;
+    const bool tracing = trace_env && windows == 1 && grid <= 4096;
+    if (tracing) {
+      if (!trace_dev && hipMalloc(reinterpret_cast<void**>(&trace_dev), 4096 * 4 * sizeof(uint64_t)) != hipSuccess) trace_dev = nullptr;
+      if (trace_dev) (void)hipMemsetAsync(trace_dev, 0, 4096 * 4 * sizeof(uint64_t), stream);
+      a.trace = trace_dev;
+    }
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(kWThreads), lds, stream, a);
+    if (tracing && trace_dev) {
+      std::vector<uint64_t> t((size_t)grid * 4);
+      if (hipMemcpyAsync(t.data(), trace_dev, t.size() * 8, hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess) {
+        uint64_t t0 = ~0ull;
+        for (uint64_t b2 = 0; b2 < grid; b2++)
+          if (t[b2 * 4] && t[b2 * 4] < t0) t0 = t[b2 * 4];
+        double sum[8] = {0}, mx[8] = {0}, mn[8];
+        int cnt[8] = {0};
+        for (int x = 0; x < 8; x++) mn[x] = 1e30;
+        for (uint64_t b2 = 0; b2 < grid; b2++)
+          if (t[b2 * 4]) {
+            const double e = (t[b2 * 4 + 2] - t0) * 0.01;
+            const int x = (int)(b2 % 8);
+            sum[x] += e, cnt[x]++;
+            if (e > mx[x]) mx[x] = e;
+            if (e < mn[x]) mn[x] = e;
+          }
+        fprintf(stderr, "[wide trace] batch %u passes %u, block ends per XCD (min/mean/max us):", batch, passes);
+        for (int x = 0; x < 8; x++)
+          if (cnt[x]) fprintf(stderr, "  %d: %.0f/%.0f/%.0f", x, mn[x], sum[x] / cnt[x], mx[x]);
+        fprintf(stderr, "\n");
+      }
+      a.trace = nullptr;
+    }
   }
   CPIR_HIP_TRY(hipGetLastError());
   return CPIR_OK;
