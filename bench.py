@@ -311,7 +311,7 @@ def main() -> int:
         "algorithmic_bytes_per_query": full_bytes,
         "roofline": {
             "bound": "hbm",
-            "kernel": "respond_planar_kernel" if full_layout.packing == 2 else "respond_kernel",
+            "kernel": "respond_planar_wide_kernel" if full_layout.packing == 2 else "respond_kernel",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",

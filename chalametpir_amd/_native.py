@@ -172,6 +172,23 @@ def _preload_torch_hip_runtime() -> None:
         C.CDLL(path, mode=C.RTLD_GLOBAL)
 
 
+def use_library(path: str) -> None:
+    """Tuning scripts only: bind another build of the library (the -DCPIR_DIAG one, `make -C chalametpir_amd/csrc diag`) instead of the
+    release library.  Must be called before anything has loaded the library; the package, the tests and bench.py never call it."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("the library is already loaded")
+    LIB_PATH = os.path.abspath(path)
+
+
+def use_diag_build() -> str:
+    """Tuning scripts only: build (if need be) and bind the diagnosis build of the library; returns its path."""
+    path = os.path.join(_PKG, "lib", "diag", "libchalamet_hip.so")
+    subprocess.run(["make", "-C", CSRC_DIR, "-s", "diag"], check=True)
+    use_library(path)
+    return path
+
+
 def load():
     """dlopen libchalamet_hip.so and type every entry point.  Raises if the library is not built: fail loudly."""
     global _lib

@@ -104,6 +104,15 @@ struct DeviceGuard {
 // what torch.cuda.current_stream().cuda_stream is when no stream context is active -- never "some other stream".
 inline hipStream_t pick_stream(const Device*, void* stream) { return reinterpret_cast<hipStream_t>(stream); }
 
+// Diagnosis code (per-block timing traces, switches that skip part of a kernel's work to time the rest) exists only in a build with
+// -DCPIR_DIAG (`make diag`: lib/diag/libchalamet_hip.so, for scripts/wide_ablate.py and the pmc_*.sh passes).  The release library has no
+// code path that skips work or that a variable of the environment could switch on: Server::respond has no mode in which it lies.
+#ifdef CPIR_DIAG
+#define CPIR_DIAG_ONLY(...) __VA_ARGS__
+#else
+#define CPIR_DIAG_ONLY(...)
+#endif
+
 // ---- kernel launchers (defined in the .hip files) ---------------------------------------------
 // respond.hip
 uint64_t respond_scratch_words(const cpir_dtc_layout& L, uint32_t batch);
@@ -112,8 +121,8 @@ uint64_t respond_scratch_words(const cpir_dtc_layout& L, uint32_t batch);
 int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                    uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, uint32_t* scratch, hipStream_t stream,
                    const uint32_t* keep = nullptr);
-// keep: the slot map of a compacted image, applied by the kernel itself -- the wide pass only (respond_batch_takes_slot_map says whether every
-// launch of a batch is one); with any other kernel the call fails with CPIR_ERR_INVALID_ARGUMENT and the caller gathers the queries first
+// keep: the slot map of a compacted image, applied by the kernel itself -- the wide kernel only (respond_batch_takes_slot_map says whether the
+// launches of a batch are); with any other kernel the call fails with CPIR_ERR_INVALID_ARGUMENT and the caller gathers the queries first
 bool respond_batch_takes_slot_map(const cpir_dtc_layout& L, uint32_t batch, bool lone, uint64_t q_len);
 // A launch whose query is still being copied into page-locked host memory while the kernel runs (respond_planar.hip): the host counts
 // the 512-slot steps of q in place so far in *progress (host memory, device-visible address), front to back; the kernel waits for each
@@ -134,24 +143,24 @@ int launch_respond_read_once(const Device* dev, const uint32_t* dtc, const cpir_
 uint32_t respond_host_fill_timeout_us();  // tuning "respond.host_fill_timeout_us"; 0 = never launch in front of the copy
 bool respond_read_once_applicable(const cpir_dtc_layout& L);  // planar packing, LDS room for one response, respond.host_zero_copy on
 const char* respond_kernel_name(const cpir_dtc_layout& L);
-// respond_planar.hip (CPIR_PACK_PLANAR: the MFMA path); same contract as launch_respond, batch up to CPIR_PLANAR_MAX_QUERIES_PER_PASS
-constexpr uint32_t CPIR_PLANAR_MAX_QUERIES_PER_PASS = 12;  // step-major kernel: three A row sets of 4 queries; the tile-major kernel takes 8
-uint32_t planar_max_queries_per_pass(const cpir_dtc_layout& L, uint32_t passes, int interleave, int ks_mode);
-uint32_t respond_planar_pass_width(const cpir_dtc_layout& L, uint32_t batch);  // respond.hip: the above under the current tuning, for a batch
-int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
-                          uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, int blocks_per_cu,
-                          bool nontemporal, bool xcd_split, int interleave, int ks_mode, bool r_prezeroed = false, uint64_t step_lo = 0,
-                          uint64_t step_hi = 0, const PlanarHostFill* fill = nullptr);
-// ks_mode: 0 = the tile-major kernel only; 1 = the step-major kernel for fused batches (2+ queries per pass: 26 against
-// 32 us per query at 8 per pass) and for single-pass launches (a lone query: 192 against 201 us), the tile-major kernel for one query per
-// pass over many passes; 2 = the step-major kernel wherever it applies; 3 = the
-// step-major kernel or fail: the caller needs every query word read exactly once (a query read in place from page-locked host memory).  r_prezeroed: the caller has zeroed r already.
-// the wide pass: one 8-wave block per CU, up to 24 queries (six A row sets, looped) per stream of the database; slice order only
+// respond_planar.hip (CPIR_PACK_PLANAR: the MFMA path); same contract as launch_respond
+// the step-major kernel: one A row set (up to 4 queries per pass), slice order; reads every query word once per column window.  in_place:
+// launched as the in-place host path needs it (whole steps round-robin over the blocks, far-mode fragment schedule; one column window or
+// CPIR_ERR_INVALID_ARGUMENT); r_prezeroed: the caller has zeroed r already; [step_lo, step_hi): see launch_respond_read_once.
+constexpr uint32_t CPIR_PLANAR_KS_MAX_QUERIES_PER_PASS = 4;
+int launch_respond_planar_ks(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
+                             uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, int blocks_per_cu,
+                             bool nontemporal, bool xcd_split, bool in_place, bool r_prezeroed, uint64_t step_lo, uint64_t step_hi,
+                             const PlanarHostFill* fill);
+uint32_t respond_planar_pass_width(const cpir_dtc_layout& L, uint32_t batch);  // respond.hip: queries per pass of a fused batch under the current tuning
+// the wide kernel: one 8-wave block per CU, up to 24 queries (six A row sets, looped) per stream of the database, any number of passes
 constexpr uint32_t CPIR_PLANAR_WIDE_MAX_QUERIES_PER_PASS = 24;
 int launch_respond_planar_wide(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                                uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, bool nontemporal,
-                               bool xcd_split, const uint32_t* keep = nullptr);
+                               bool xcd_split, int interleave, const uint32_t* keep = nullptr);
+// interleave: order of the passes of one launch -- 0 slice order, 1 interleaved, -1 by the image's size (planar_passes_interleaved)
 // keep: the slot map of a compacted image (SlotMap::keep_dev) -- the kernel then gathers the query words itself; L is the PHYSICAL layout
+bool planar_passes_interleaved(const cpir_dtc_layout& L, uint32_t passes, int interleave);
 bool respond_batch_fusion();
 uint64_t respond_multi_pass_limit_bytes();
 
@@ -226,8 +235,10 @@ bool mfma_matmul_enabled();
 void set_mfma_matmul(bool on);
 int mfma_pipeline();
 void set_mfma_pipeline(int on);
+#ifdef CPIR_DIAG
 int mfma_ablate();
 void set_mfma_ablate(int bits);
+#endif
 
 // synth.hip
 int launch_synth_fill(const Device* dev, uint32_t* out, uint64_t count, uint64_t seed, uint64_t index0, uint32_t mask,

@@ -691,33 +691,28 @@ int server_respond_on_device(const Server* srv, const uint32_t* q, uint64_t q_le
 // without it every query is its own pass.  Either way the passes of one kind go into ONE launch.
 int respond_batched(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                            uint64_t q_slot_offset, uint32_t batch, uint32_t* r, uint32_t* scratch, hipStream_t stream, const uint32_t* keep) {
-  if (keep && (L.packing != CPIR_PACK_PLANAR || !respond_batch_fusion())) return CPIR_ERR_INVALID_ARGUMENT;  // (see server_respond_on_device)
+  if (keep && L.packing != CPIR_PACK_PLANAR) return CPIR_ERR_INVALID_ARGUMENT;  // (see server_respond_on_device)
   if (!respond_batch_fusion()) {
     // One launch for all passes saves a kernel fill/drain (~10 us) per query, but blocks of a long multi-pass launch drift
     // apart and lose the L2 sharing of q: measured on MI355X it wins up to 1.3 GB per pass (196 vs 204 us) and loses at
     // 5 GB and above (806 vs 770 us), so very large databases get one launch per query.
     // (the matrix-core kernel keeps one launch at every size: 1 440 vs 1 505 us per query at 9.8 GB, 790 vs 799 at 5 GB)
-    if (L.packing == CPIR_PACK_PLANAR || L.total_words * 4 <= respond_multi_pass_limit_bytes()) return launch_respond(dev, dtc, L, q, q_len, q_slot_offset, 1, batch, r, scratch, stream);
+    if (L.packing == CPIR_PACK_PLANAR || L.total_words * 4 <= respond_multi_pass_limit_bytes()) return launch_respond(dev, dtc, L, q, q_len, q_slot_offset, 1, batch, r, scratch, stream, keep);
     for (uint32_t i = 0; i < batch; i++)
       CPIR_TRY(launch_respond(dev, dtc, L, q + (uint64_t)i * q_len, q_len, q_slot_offset, 1, 1, r + (uint64_t)i * L.num_cols, scratch, stream));
     return CPIR_OK;
   }
   uint32_t done = 0;
   if (L.packing == CPIR_PACK_PLANAR) {
-    // the matrix-core kernels take any 1..W queries per pass (W up to 24: the wide pass, as few passes as that allows, all of about the same
-    // width; with it switched off 12 where the step-major kernel runs the launch, else 8): passes of W, then the rest -- as one pass if
-    // that pass may be as wide, else as passes of 8 and a last one
+    // the matrix-core kernels take any 1..W queries per pass (W up to 24 on the wide kernel -- as few passes as that allows, all of about
+    // the same width; 4 where the tuning sends fused passes to the step-major kernel): passes of W in one launch, then the rest as one pass
     const uint32_t W = respond_planar_pass_width(L, batch);
     if (batch >= W) {
       CPIR_TRY(launch_respond(dev, dtc, L, q, q_len, q_slot_offset, W, batch / W, r, scratch, stream, keep));
       done = batch / W * W;
     }
-    while (done < batch) {
-      const uint32_t left = batch - done;
-      const uint32_t w = left <= respond_planar_pass_width(L, left) ? left : 8u;  // (what is left fits one pass -- a launch of one pass is a wide pass whatever its width; 8s and a last one with the wide pass off)
-      CPIR_TRY(launch_respond(dev, dtc, L, q + (uint64_t)done * q_len, q_len, q_slot_offset, w, 1, r + (uint64_t)done * L.num_cols, scratch, stream, keep));
-      done += w;
-    }
+    if (done < batch)
+      CPIR_TRY(launch_respond(dev, dtc, L, q + (uint64_t)done * q_len, q_len, q_slot_offset, batch - done, 1, r + (uint64_t)done * L.num_cols, scratch, stream, keep));
     return CPIR_OK;
   }
   for (uint32_t width : {4u, 2u, 1u}) {

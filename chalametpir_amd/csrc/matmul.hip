@@ -263,9 +263,11 @@ void set_mfma_matmul(bool on) { g_use_mfma.store(on ? 1 : 0); }
 static std::atomic<int> g_mfma_pipeline{1};
 int mfma_pipeline() { return g_mfma_pipeline.load(); }
 void set_mfma_pipeline(int on) { g_mfma_pipeline.store(on); }
+#ifdef CPIR_DIAG
 static std::atomic<int> g_mfma_ablate{0};
 int mfma_ablate() { return g_mfma_ablate.load(); }
 void set_mfma_ablate(int bits) { g_mfma_ablate.store(bits); }
+#endif
 
 const char* mat_x_mat_kernel_name(uint32_t rhs_max_bits) {
   if (rhs_max_bits > 16) return "mat_x_mat_u32_kernel";

@@ -156,7 +156,7 @@ struct MfmaArgs {
   uint32_t RT, CT, KS;  // row tiles of 128, column tiles of 128, k-steps of 64
   uint32_t S;           // K sub-ranges per XCD range
   uint32_t nx;          // K axis split by blockIdx % nx (8, or 1 for tiny grids)
-  uint32_t ablate;      // diagnosis only (results are garbage): 1 no MFMA, 2 no A conversion / LDS writes, 4 no A loads, 8 no D DMA
+  CPIR_DIAG_ONLY(uint32_t ablate;)  // a diagnosis build only (results are garbage): 1 no MFMA, 2 no A conversion / LDS writes, 4 no A loads, 8 no D DMA
   // Right-hand side straight from a planar respond image (pipelined kernel only; `planes` is NULL then): the low-byte operand pieces ARE
   // the first 8 KiB of every super-tile of the image ([column tile][step of 512 slots][(8 + HB) KiB]), the high-byte pieces come from the
   // plane pack.hip writes next to it ([column tile][k-block of 64][1 KiB]).  Slots and columns past the end hold field 0 there (bytes
@@ -293,11 +293,11 @@ __global__ void __launch_bounds__(kMT) __attribute__((amdgpu_waves_per_eu(2, 2))
       const uint32_t buf = (ks - k0) & 1;
       const bool more = ks + 1 < k1;
       if (more) {
-        if (!(a.ablate & 4)) load_a(ks + 1);
-        if (!(a.ablate & 8)) dma_b(ks + 1, buf ^ 1);  // that buffer was last read in the previous iteration, which ended with a barrier
+        CPIR_DIAG_ONLY(if (!(a.ablate & 4))) load_a(ks + 1);
+        CPIR_DIAG_ONLY(if (!(a.ablate & 8))) dma_b(ks + 1, buf ^ 1);  // that buffer was last read in the previous iteration, which ended with a barrier
       }
-      if (!(a.ablate & 1)) mfma_step(buf);
-      if (more && !(a.ablate & 2)) store_a(ks + 1, buf ^ 1);
+      CPIR_DIAG_ONLY(if (!(a.ablate & 1))) mfma_step(buf);
+      if (more CPIR_DIAG_ONLY(&& !(a.ablate & 2))) store_a(ks + 1, buf ^ 1);
       __syncthreads();
     }
 
@@ -956,7 +956,7 @@ static int launch_product(const Device* dev, MfmaArgs& a, const uint32_t* colsum
   const uint64_t ks_per_x = (a.KS + a.nx - 1) / a.nx;
   while (S > 1 && ks_per_x / S < 8) S /= 2;  // a unit shorter than 8 k-steps is all prologue and flush
   a.S = (uint32_t)(S ? S : 1);
-  a.ablate = (uint32_t)mfma_ablate();
+  CPIR_DIAG_ONLY(a.ablate = (uint32_t)mfma_ablate();)
 
   // the hand-pipelined kernel addresses a row tile of A with 32-bit byte offsets
   const bool pipe = mfma_pipe_addressable(lda, inner);

@@ -292,16 +292,14 @@ struct Tuning {
   int xcd_split = 1;       // split the chunk axis by blockIdx % 8
   int batch_fusion = 1;    // respond_batch: 1 = passes of 4/2/1 queries share one DB stream, 0 = one pass per query
   int interleave_passes = -1;  // order of the passes of one launch: 0 slice order, 1 interleaved, -1 by shard size
-  int planar_blocks_per_cu = 0;  // the matrix-core kernel (respond_planar.hip): 0 = by pass order (2 streaming, 3 sharing)
+  int planar_blocks_per_cu = 0;  // the step-major matrix-core kernel: 0 = one block per CU (measured best), 1 / 2 to force
   int multi_pass_limit_mb = 2560;  // unfused batches: databases above this size get one launch per query
   int host_fill_timeout_us = 2000;  // a lone pageable host query: ONE launch polling the copy's progress, each wave for at most this long (0: off)
   int host_zero_copy = 1;          // a lone host query is read by the kernel in place (page-locked memory), not uploaded first
-  int ks_major = 1;                // the step-major matrix-core kernel: 0 never, 1 fused batches + lone launches, 2 wherever it applies
-  // fused passes of at least this many queries go through the wide pass (up to 24 queries per stream of the database); 0 = never.
-  // Measured at 2^20 keys x 1 kB, us per launch, step-major / wide: 1 query 190.0 / 188.5, 4: 190.8 / 189.9, 5: 204.0 / 192.9, 8: 208.3 /
-  // 197.1, 12: 245.2 / 202.7 (8 kB values: 1436 / 1403, 1427 / 1414, 1523 / 1431, 1562 / 1445, 1748 / 1490): never slower, so everything
-  // beyond one row set takes it; single row sets stay where the in-place host path and the lone launches are
-  int wide_min_batch = 5;
+  // planar packing, device-resident queries: 1 = the wide kernel takes every launch (the step-major kernel serves the in-place host path
+  // only); 2 = the step-major kernel wherever it applies (passes of up to 4 queries in slice order: tests and A/B runs); 3 = as 2, launched
+  // as the in-place host path launches it (strided steps, far-mode fragment schedule: diagnosis)
+  int ks_major = 1;
 };
 Tuning g_tuning;
 std::mutex g_tuning_mu;
@@ -380,11 +378,8 @@ extern "C" int cpir_tuning_set(const char* key, int value) {
   } else if (!strcmp(key, "respond.host_zero_copy")) {
     g_tuning.host_zero_copy = value ? 1 : 0;
   } else if (!strcmp(key, "respond.ks_major")) {
-    if (value < 0 || value > 3) return CPIR_ERR_INVALID_ARGUMENT;  // 3: as the in-place host path launches it (diagnosis)
+    if (value < 1 || value > 3) return CPIR_ERR_INVALID_ARGUMENT;
     g_tuning.ks_major = value;
-  } else if (!strcmp(key, "respond.wide_min_batch")) {
-    if (value < 0 || value > 1000000) return CPIR_ERR_INVALID_ARGUMENT;
-    g_tuning.wide_min_batch = value;
   } else if (!strcmp(key, "layout.dense")) {
     set_default_dense(value != 0);
   } else if (!strcmp(key, "layout.planar")) {
@@ -399,8 +394,10 @@ extern "C" int cpir_tuning_set(const char* key, int value) {
     set_mfma_matmul(value != 0);
   } else if (!strcmp(key, "matmul.pipeline")) {
     set_mfma_pipeline(value != 0);
-  } else if (!strcmp(key, "matmul.ablate")) {
+#ifdef CPIR_DIAG
+  } else if (!strcmp(key, "matmul.ablate")) {  // (a diagnosis build only: the release library has no switch that skips work)
     set_mfma_ablate(value);
+#endif
   } else {
     return CPIR_ERR_INVALID_ARGUMENT;
   }
@@ -415,7 +412,7 @@ extern "C" void cpir_tuning_reset(void) {
   set_default_planar(true);
   set_mfma_matmul(true);
   set_mfma_pipeline(1);
-  set_mfma_ablate(0);
+  CPIR_DIAG_ONLY(set_mfma_ablate(0);)
   set_pack_rows_mode(-1);
   set_compact_slots_mode(1);
 }
@@ -430,39 +427,27 @@ bool respond_batch_fusion() {
   return g_tuning.batch_fusion != 0;
 }
 
-// queries per pass for a fused batch of `batch` queries on a planar image: what the wide pass makes of it (below); with the wide pass
-// switched off 12 where passes of 12 would be taken by the step-major kernel (a batch of up to 12 is ONE pass, which always is; larger
-// batches on databases beyond the interleaving size too), else 8
+// queries per pass for a fused batch of `batch` queries on a planar image: as few passes as 24 queries each allow (the wide kernel), all of
+// (almost) the same width -- 32 queries are two passes of 16, not 24 + 8; passes of 4 where the tuning sends fused passes to the
+// step-major kernel
 uint32_t respond_planar_pass_width(const cpir_dtc_layout& L, uint32_t batch) {
   Tuning t;
   {
     std::lock_guard<std::mutex> lk(g_tuning_mu);
     t = g_tuning;
   }
-  // the wide pass: as few passes as 24 queries each allow, all of (almost) the same width -- 32 queries are two passes of 16, not 24 + 8
-  if (t.wide_min_batch > 0 && batch >= (uint32_t)t.wide_min_batch && t.ks_major >= 1) {
-    const uint32_t passes = (batch + CPIR_PLANAR_WIDE_MAX_QUERIES_PER_PASS - 1) / CPIR_PLANAR_WIDE_MAX_QUERIES_PER_PASS;
-    return (batch + passes - 1) / passes;
-  }
-  const uint32_t passes12 = batch / CPIR_PLANAR_MAX_QUERIES_PER_PASS;
-  return planar_max_queries_per_pass(L, passes12 > 1 ? passes12 : 1, t.interleave_passes, t.ks_major);
+  if (batch == 0) return 0;
+  if (t.ks_major >= 2) return batch < CPIR_PLANAR_KS_MAX_QUERIES_PER_PASS ? batch : CPIR_PLANAR_KS_MAX_QUERIES_PER_PASS;
+  const uint32_t passes = (batch + CPIR_PLANAR_WIDE_MAX_QUERIES_PER_PASS - 1) / CPIR_PLANAR_WIDE_MAX_QUERIES_PER_PASS;
+  return (batch + passes - 1) / passes;
 }
 
-// Whether EVERY launch respond_batched (or a lone launch_respond) makes for this batch under the current tuning is a wide pass that can
-// apply a slot map itself -- the same cutting as respond_batched's, walked without launching anything.
+// Whether the launches respond_batched (or a lone launch_respond) makes for a batch under the current tuning can apply a slot map
+// themselves: the wide kernel can (32-bit word offsets inside a row set: queries below 2^28 words), the step-major kernel and the VALU
+// kernels cannot -- the caller then gathers the queries first.
 bool respond_batch_takes_slot_map(const cpir_dtc_layout& L, uint32_t batch, bool lone, uint64_t q_len) {
-  Tuning t;
-  {
-    std::lock_guard<std::mutex> lk(g_tuning_mu);
-    t = g_tuning;
-  }
-  // (ks_major other than the default 1 is a diagnosis setting that sends single-pass launches to the step-major kernel: the long way then)
-  if (L.packing != CPIR_PACK_PLANAR || t.ks_major != 1 || t.wide_min_batch <= 0 || !t.nontemporal || q_len >= ((uint64_t)1 << 28) || batch == 0) return false;
-  if (lone || batch == 1) return true;      // one pass of one query
-  if (!t.batch_fusion) return false;        // many passes of one query each: the tile-major kernel
-  const uint32_t W = respond_planar_pass_width(L, batch);
-  if (batch >= W && batch / W > 1 && W <= CPIR_PLANAR_MAX_QUERIES_PER_PASS && W < (uint32_t)t.wide_min_batch) return false;  // several narrow passes
-  return true;  // (everything else is either at least wide_min_batch wide or a launch of one pass)
+  std::lock_guard<std::mutex> lk(g_tuning_mu);
+  return L.packing == CPIR_PACK_PLANAR && g_tuning.ks_major == 1 && q_len < ((uint64_t)1 << 28) && batch != 0;
 }
 
 uint64_t respond_scratch_words(const cpir_dtc_layout&, uint32_t) {
@@ -472,7 +457,7 @@ uint64_t respond_scratch_words(const cpir_dtc_layout&, uint32_t) {
 }
 
 const char* respond_kernel_name(const cpir_dtc_layout& L) {
-  return L.packing == CPIR_PACK_PLANAR ? "respond_planar_kernel" : "respond_kernel";
+  return L.packing == CPIR_PACK_PLANAR ? "respond_planar_wide_kernel" : "respond_kernel";
 }
 
 uint32_t respond_host_fill_timeout_us() {
@@ -498,8 +483,8 @@ int launch_respond_read_once(const Device* dev, const uint32_t* dtc, const cpir_
     std::lock_guard<std::mutex> lk(g_tuning_mu);
     t = g_tuning;
   }
-  return launch_respond_planar(dev, dtc, L, q, q_len, q_slot_offset, 1, 1, r_prezeroed, stream, t.planar_blocks_per_cu, t.nontemporal != 0,
-                               t.xcd_split != 0, 0, 3, true, step_lo, step_hi, fill);
+  return launch_respond_planar_ks(dev, dtc, L, q, q_len, q_slot_offset, 1, 1, r_prezeroed, stream, t.planar_blocks_per_cu, t.nontemporal != 0,
+                                  t.xcd_split != 0, true, true, step_lo, step_hi, fill);
 }
 
 int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
@@ -516,17 +501,21 @@ int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout
     std::lock_guard<std::mutex> lk(g_tuning_mu);
     t = g_tuning;
   }
-  // a pass of more queries than the step-major kernel's three row sets: the wide pass (also below that where the tuning asks for it)
-  // ... and a launch of ONE pass of any width (a lone device query: 190.0 -> 188.5 us at 2^20 keys x 1 kB, 1 436 -> 1 403 with 8 kB values,
-  // 36.9 -> 30.9 on a 1/8 shard); many passes of up to 4 queries stay on the tile-major / step-major kernels (the headline's loop)
-  if (L.packing == CPIR_PACK_PLANAR &&
-      (batch > CPIR_PLANAR_MAX_QUERIES_PER_PASS ||
-       (t.wide_min_batch > 0 && t.ks_major >= 1 && (batch >= (uint32_t)t.wide_min_batch || (passes == 1 && t.ks_major == 1)))))
-    return launch_respond_planar_wide(dev, dtc, L, q, q_len, q_slot_offset, batch, passes, r, stream, t.nontemporal != 0, t.xcd_split != 0, keep);
-  if (keep) return CPIR_ERR_INVALID_ARGUMENT;  // only the wide pass applies a slot map itself: the caller gathers the queries first
-  if (L.packing == CPIR_PACK_PLANAR)  // the matrix-core path (respond_planar.hip)
-    return launch_respond_planar(dev, dtc, L, q, q_len, q_slot_offset, batch, passes, r, stream, t.planar_blocks_per_cu, t.nontemporal != 0,
-                                 t.xcd_split != 0, t.interleave_passes, t.ks_major);
+  if (L.packing == CPIR_PACK_PLANAR) {  // the matrix-core path (respond_planar.hip)
+    // the step-major kernel where the tuning asks for it and it applies (one row set, slice order, no slot map); else the wide kernel:
+    // 1 .. 24 queries per pass, any number of passes in either order.  Measured at 2^20 keys x 1 kB, 32 passes of one query a launch
+    // (scripts/families_ab.py): tile-major kernel of rounds 1-4 / wide, slice order 184.8-185.1 / 181.2-184.1 us per query; interleaved
+    // on 1/8 of the slots 11.1-11.4 / 8.2, on 1/2 50.0 / 34.3
+    const bool ks = t.ks_major >= 2 && batch <= CPIR_PLANAR_KS_MAX_QUERIES_PER_PASS && !keep && !planar_passes_interleaved(L, passes, t.interleave_passes);
+    if (ks) {
+      const int st = launch_respond_planar_ks(dev, dtc, L, q, q_len, q_slot_offset, batch, passes, r, stream, t.planar_blocks_per_cu,
+                                              t.nontemporal != 0, t.xcd_split != 0, t.ks_major == 3, false, 0, 0, nullptr);
+      if (st != CPIR_ERR_INVALID_ARGUMENT || t.ks_major != 3) return st;  // (in-place order: one column window or nothing -- the wide kernel then)
+    }
+    return launch_respond_planar_wide(dev, dtc, L, q, q_len, q_slot_offset, batch, passes, r, stream, t.nontemporal != 0, t.xcd_split != 0,
+                                      t.interleave_passes, keep);
+  }
+  if (keep) return CPIR_ERR_INVALID_ARGUMENT;  // only the wide kernel applies a slot map itself: the caller gathers the queries first
   if (L.words_per_row_padded / L.chunk_words > 0xffffffffull) return CPIR_ERR_INVALID_ARGUMENT;
   Picked k;
   if (batch == 1) k = pick_kernel<1>(L, t.rows_per_unit, t.nontemporal);

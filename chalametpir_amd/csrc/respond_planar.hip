@@ -20,14 +20,20 @@
 //
 // Roofline: HBM read, exactly b bits per field (1.6 % fewer bytes than dense64 at b = 9, 15.6 % fewer than the reference packing).
 //
-//   * work unit of a block = 4 column tiles (64 columns, one per wave) x one super-tile step (512 slots); the step's A fragments
-//     (8 KiB) are built once per block from q (L2 / Infinity Cache hits; each wave gathers two of the eight k-blocks), shared
-//     through double-buffered LDS and read back just in time, one ds_read_b128 per MFMA pair;
-//   * a wave's tile step is 8 + HB fully coalesced 1 KiB wave-loads (`nt`), issued one step ahead of the MFMAs that consume them;
-//   * persistent grid, units split evenly over the blocks, one barrier per step; the slot axis is first split 8 ways by
-//     blockIdx % 8 as in respond.hip so that an XCD's L2 holds one eighth of q;
+// Two kernels walk the same packed image with the same arithmetic and give the same responses bit for bit:
+//   * respond_planar_wide_kernel -- every device-resident launch: 1 .. 24 queries per pass (one to six A row sets walked in a loop), any
+//     number of passes per launch in slice or interleaved order, a slot map applied while the query words are gathered.  One 8-wave block
+//     per CU; a work unit is a 512-slot step x 8 column tiles (one per wave); the step's A fragments are built once per block and step;
+//     the responses accumulate in LDS and leave through one pass of u32 atomics per pass.  It adds the two correction terms itself.
+//   * respond_planar_ks_kernel -- the lone HOST query: up to 4 queries per pass (one row set), every query word read exactly once, in
+//     strided order, optionally while the host is still copying the query in (polled fill count).  4-wave blocks, one per CU.
+// (Rounds 1-4 also had a tile-major kernel with an init kernel in front and two / three row sets of the step-major one; the wide kernel is
+// faster than each of them wherever they were dispatched -- scripts/families_ab.py, profiles/r5_families_ab.txt -- and they are gone.)
+//   * a wave's tile step is 8 + HB fully coalesced 1 KiB wave-loads (`nt` when streaming), issued one unit ahead of the MFMAs that consume them;
+//   * persistent grid, units split evenly over the blocks; the slot axis is first split 8 ways by blockIdx % 8 so that an XCD's L2 holds
+//     one eighth of q;
 //   * the accumulator tile has the column on the lane and (query, byte) in the register index, so the recombination
-//     sum_i 2^(8i) (lo_i + 256 hi_i) is lane-local; one u32 atomicAdd per (wave, query, column) and tile group.
+//     sum_i 2^(8i) (lo_i + 256 hi_i) is lane-local.
 #include "cpir_internal.hpp"
 
 #include <algorithm>
@@ -58,10 +64,10 @@ struct PlanarArgs {
   uint32_t ks_total;       // super-tile steps along the slots: ceil(N / 512)
   uint32_t ks_lo, ks_hi;   // this launch covers steps [ks_lo, ks_hi) only (the whole axis unless a host query is being pipelined)
   uint32_t nx;             // slot-axis split by blockIdx % nx (8 or 1)
-  uint32_t q_per_pass;     // queries answered per pass (1..8): rows 4*i .. 4*i+3 of A row set i / 4 belong to query i
+  uint32_t q_per_pass;     // queries answered per pass: rows 4*i .. 4*i+3 of A row set i / 4 belong to query i
   uint32_t passes;         // independent passes over the database in this launch
   uint32_t q_scalar;       // q not 16-byte loadable -> guarded scalar loads everywhere
-  uint32_t interleave;     // order of the passes of one launch (see the kernel)
+  uint32_t interleave;     // wide pass: order of the passes of one launch (see the kernel)
   uint32_t q_far;          // step-major kernel: q sits behind the host link -> a whole step of units between requesting and using it
   const uint32_t* colsum;  // step-major kernel: per-column field sums behind the tiles (NULL: this launch does not cover step 0)
   // step-major kernel, q read in place from host memory that is still being FILLED while the kernel runs (a lone pageable host query):
@@ -71,8 +77,10 @@ struct PlanarArgs {
   uint64_t poll_ticks;       // ... after this many ticks of the 100 MHz wall clock
   const uint32_t* keep;      // wide pass: the database holds only the slots keep[0 .. num_slots) of the query (increasing, relative to q_slot_offset;
                              // compact.hip); NULL: slot n of the database is word q_slot_offset + n of the query
-  uint64_t* trace;           // step-major kernel, diagnosis only (CPIR_KS_TRACE): per block 4 words -- wall clock at entry, after the first fragments, at the end; visits
-  uint32_t ablate;           // wide pass, diagnosis only (CPIR_WIDE_ABLATE; results are WRONG while non-zero): 1 no rebuild of the fragments, 2 no flush, 4 no MFMAs
+#ifdef CPIR_DIAG  // (a diagnosis build only: the release library has neither field nor any code that reads them)
+  uint64_t* trace;           // CPIR_KS_TRACE: per block 4 words -- wall clock at entry, after the first fragments, at the end; visits
+  uint32_t ablate;           // wide pass, CPIR_WIDE_ABLATE (results are WRONG while non-zero): 1 no rebuild of the fragments, 2 no flush, 4 no MFMAs
+#endif
 };
 
 template <bool NT>
@@ -96,234 +104,22 @@ __device__ __forceinline__ uint32_t gather_limb(uint32_t x, uint32_t y, uint32_t
 
 __device__ __forceinline__ uint32_t comp(const uint4& u, int i) { return i == 0 ? u.x : (i == 1 ? u.y : (i == 2 ? u.z : u.w)); }
 
-// One step of a block: wave w multiplies column tile 4*tg + w by the step's A fragments (shared through LDS), with the loads of
-// its NEXT tile and the block's next A fragments issued first.  P = parity of the step (register / LDS double buffering).
-// NS = sets of 16 A rows: one set answers up to 4 queries per pass, two sets up to 8 (twice the MFMAs on the same stream); the step-major
-// kernel below also runs with three (up to 12 queries per pass).
-template <int HB, int NS, bool NT>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NS == 1 ? 3 : 2, NS == 1 ? 3 : 2)))
-respond_planar_kernel(const PlanarArgs a) {
-  constexpr int NL = 8 + HB;     // 16-byte loads per lane and tile step
-  constexpr int ST16 = NL * 64;  // uint4 per super-tile
-  __shared__ uint4 abuf[2][NS][8][64];  // A fragments of a step: [parity][row set][k-block][lane]
-
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const uint32_t cl = lane & 15;   // B / C operand: column inside the tile;  A operand: row = 4 * query + byte
-  const uint32_t grp = lane >> 4;  // A / B operand: 16-slot group inside a k-block;  C operand: query (rows 4*grp .. 4*grp+3)
-
-  // ---- static partition of the (tile group, step) units over the BLOCKS of the persistent grid (block-uniform) -------
-  const uint32_t nx = a.nx;
-  const uint32_t xcd = blockIdx.x % nx;
-  const uint32_t j = blockIdx.x / nx;
-  const uint32_t nb = gridDim.x / nx;  // host guarantees gridDim.x % nx == 0
-  const uint32_t ks_len = a.ks_hi - a.ks_lo;
-  const uint32_t kb0 = a.ks_lo + (uint32_t)(((uint64_t)ks_len * xcd) / nx);
-  const uint32_t ke0 = a.ks_lo + (uint32_t)(((uint64_t)ks_len * (xcd + 1)) / nx);
-  const uint32_t span = ke0 - kb0;
-  if (span == 0) return;
-  const uint64_t units = (uint64_t)a.tile_groups * span;
-  // Two orders of the passes of one launch (same arithmetic; as respond.hip):
-  //   slice order:       a block keeps its slice [sb, se) of the units and walks it once per pass;
-  //   interleaved order: the passes are laid end to end and the whole (pass, unit) space is split evenly, so different blocks
-  //                      stream the same tiles for different queries at about the same time (pays when the shard fits the
-  //                      256 MiB Infinity Cache).
-  uint64_t sb, se, u0, total;  // a pass covers units [sb, se) for this block; it starts at unit u0 of pass pass0 and does `total` steps
-  uint32_t pass0;
-  if (a.interleave) {
-    const uint64_t all = units * a.passes;
-    const uint64_t ib = all * j / nb, ie = all * (j + 1) / nb;
-    sb = 0, se = units, total = ie - ib;
-    pass0 = (uint32_t)(ib / units), u0 = ib % units;
-  } else {
-    sb = units * j / nb, se = units * (j + 1) / nb;
-    total = (se - sb) * a.passes;
-    pass0 = 0, u0 = sb;
-  }
-  if (total == 0) return;
-  const uint32_t tgs = (uint32_t)(sb / span), kss = kb0 + (uint32_t)(sb % span);  // where a pass starts for this block
-  const uint32_t tg0 = (uint32_t)(u0 / span), ks0 = kb0 + (uint32_t)(u0 % span);  // where this block starts
-
-  const uint32_t nq = a.q_per_pass;
-  bool arow[NS];     // does this lane's A row of set s belong to a query?
-  uint32_t qi[NS];   // which one (query 0 for unused rows: they load the same cache lines and store zeros)
-#pragma unroll
-  for (int s = 0; s < NS; s++) {
-    arow[s] = 4 * s + (cl >> 2) < nq;
-    qi[s] = arow[s] ? 4 * s + (cl >> 2) : 0;
-  }
-  const uint32_t limb = cl & 3;
-  const uint32_t sel01 = limb | ((4 + limb) << 8);
-  const uint4* const tiles = reinterpret_cast<const uint4*>(a.dtc);
-
-  // (tile group, step, pass) of the current step and of the next one
-  uint32_t tg = tg0, ks = ks0, pass = pass0;
-  uint64_t u = u0;  // unit inside the pass
-
-  // ---- A fragments of a step -> abuf[par]: wave w builds k-blocks 2w and 2w+1 ---------------------------------------------
-  // Split in two so that the (L2-hit) query loads are ISSUED before the step's database loads and CONSUMED after the MFMAs of the
-  // previous step: vmcnt retires in issue order, so waiting for the query words never waits for the HBM stream behind them.
-  // Every lane loads (lanes whose A row is unused read query 0's words again -- same cache lines -- and store zeros): no
-  // divergent branch around the loads.
-  auto guarded_step = [&](uint32_t ks_) {  // block-uniform: does this step reach past the end of the shard / of q, or is q unaligned?
-    const uint64_t slot0 = (uint64_t)ks_ * CPIR_PLANAR_SLOTS_PER_TILE;
-    return a.q_scalar || slot0 + CPIR_PLANAR_SLOTS_PER_TILE > a.num_slots ||
-           a.q_slot_offset + slot0 + CPIR_PLANAR_SLOTS_PER_TILE > a.q_len;
-  };
-  auto a_issue = [&](uint4(&raw)[NS][2][4], uint32_t ks_, uint32_t pass_) {
-    const uint64_t base = (uint64_t)ks_ * CPIR_PLANAR_SLOTS_PER_TILE + (2 * wave) * 64 + grp * 16;
-#pragma unroll
-    for (int s = 0; s < NS; s++) {
-      const uint32_t* qrow = a.q + ((uint64_t)pass_ * nq + qi[s]) * a.q_len + a.q_slot_offset;
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const uint4* src = reinterpret_cast<const uint4*>(qrow + base + h * 64);
-#pragma unroll
-        for (int d = 0; d < 4; d++) raw[s][h][d] = src[d];
-      }
-    }
-  };
-  auto a_finish = [&](const uint4(&raw)[NS][2][4], int par) {
-#pragma unroll
-    for (int s = 0; s < NS; s++)
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        uint32_t o[4];
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-          const uint4& t = raw[s][h][d];
-          const uint32_t v = gather_limb(t.x, t.y, t.z, t.w, sel01) ^ 0x80808080u;
-          o[d] = arow[s] ? v : 0u;
-        }
-        abuf[par][s][2 * wave + h][lane] = make_uint4(o[0], o[1], o[2], o[3]);
-      }
-  };
-  // the rare guarded step: scalar, bounds-checked loads.  Slots past the end of the shard or of the query take part with
-  // qs = 0 (byte 0x00), exactly as planar_init_kernel counts them.
-  auto a_guarded = [&](uint32_t ks_, uint32_t pass_, int par) {
-    const uint64_t slot0 = (uint64_t)ks_ * CPIR_PLANAR_SLOTS_PER_TILE;
-    for (int s = 0; s < NS; s++) {
-      const uint32_t* qrow = a.q + ((uint64_t)pass_ * nq + qi[s]) * a.q_len + a.q_slot_offset;
-      for (int h = 0; h < 2; h++) {
-        const int kb = 2 * wave + h;
-        const uint64_t base = slot0 + kb * 64 + grp * 16;
-        uint32_t o[4];
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-          uint32_t w[4];
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            const uint64_t n = base + d * 4 + e;
-            const bool ok = n < a.num_slots && a.q_slot_offset + n < a.q_len;
-            w[e] = ok ? (qrow[n] ^ 0x80808080u) : 0u;
-          }
-          o[d] = arow[s] ? gather_limb(w[0], w[1], w[2], w[3], sel01) : 0u;
-        }
-        abuf[par][s][kb][lane] = make_uint4(o[0], o[1], o[2], o[3]);
-      }
-    }
-  };
-
-  v4i acc_lo[NS], acc_hi[NS];
-#pragma unroll
-  for (int s = 0; s < NS; s++) acc_lo[s] = v4i{0, 0, 0, 0}, acc_hi[s] = v4i{0, 0, 0, 0};
-  uint4 b0[NL], b1[NL];
-
-  auto load_tile = [&](uint4(&dst)[NL], uint32_t tg_, uint32_t ks_) {
-    // the idle wave of a ragged last tile group re-reads the first super-tile of the image (L2-hot) instead of branching
-    // around the loads; its MFMAs and its flush are skipped
-    const uint32_t T = tg_ * kM + wave;
-    const uint4* p = tiles + (T < a.col_tiles ? ((uint64_t)T * a.ks_total + ks_) * ST16 : 0) + lane;
-#pragma unroll
-    for (int i = 0; i < NL; i++) dst[i] = load16<NT>(p + i * 64);
-  };
-
-  auto flush = [&](uint32_t tg_, uint32_t pass_) {
-    const uint32_t T = tg_ * kM + wave;
-#pragma unroll
-    for (int s = 0; s < NS; s++) {
-      if (T < a.col_tiles) {
-        uint32_t v = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) v += ((uint32_t)acc_lo[s][i] + ((uint32_t)acc_hi[s][i] << 8)) << (8 * i);
-        const uint32_t col = T * 16 + cl, query = 4 * s + grp;
-        if (query < nq && col < a.num_cols) atomicAdd(a.r + ((uint64_t)pass_ * nq + query) * a.num_cols + col, v);
-      }
-      acc_lo[s] = v4i{0, 0, 0, 0}, acc_hi[s] = v4i{0, 0, 0, 0};
-    }
-  };
-
-  auto step = [&](uint4(&cur)[NL], uint4(&nxt)[NL], int par, bool last) {
-    // where the next step is
-    uint32_t tg_n = tg, ks_n = ks + 1, pass_n = pass;
-    const bool pass_end = (u + 1 == se);
-    if (pass_end) tg_n = tgs, ks_n = kss, pass_n = pass + 1;
-    else if (ks_n == ke0) ks_n = kb0, tg_n = tg + 1;
-    uint4 raw[NS][2][4];
-    const bool g_n = guarded_step(ks_n);
-    if (!last) {
-      if (!g_n) a_issue(raw, ks_n, pass_n);
-      load_tile(nxt, tg_n, ks_n);
-    }
-    if (tg * kM + wave < a.col_tiles) {
-#pragma unroll
-      for (int kb = 0; kb < 8; kb++) {
-        v4i hb;
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-          uint32_t x = 0;
-#pragma unroll
-          for (int p = 0; p < HB; p++) x += ((comp(cur[8 + p], kb >> 1) >> (4 * (kb & 1) + d)) & 0x01010101u) << p;
-          hb[d] = (int)x;
-        }
-#pragma unroll
-        for (int s = 0; s < NS; s++) {
-          const uint4 au = abuf[par][s][kb][lane];
-          const v4i af = as_v4i(au);
-          acc_lo[s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, as_v4i(cur[kb]), acc_lo[s], 0, 0, 0);
-          if constexpr (HB > 0) acc_hi[s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, hb, acc_hi[s], 0, 0, 0);
-        }
-      }
-    }
-    if (!last) {
-      if (!g_n) a_finish(raw, par ^ 1);
-      else a_guarded(ks_n, pass_n, par ^ 1);
-    }
-    if (pass_end || tg_n != tg || last) flush(tg, pass);
-    __syncthreads();  // A fragments of the next step are in LDS; everybody is done with this step's
-    tg = tg_n, ks = ks_n, pass = pass_n;
-    u = pass_end ? sb : u + 1;
-  };
-
-  // prologue: first tile and first A fragments
-  load_tile(b0, tg0, ks0);
-  a_guarded(ks0, pass0, 0);
-  __syncthreads();
-  uint64_t i = 0;
-  for (; i + 2 <= total; i += 2) {
-    step(b0, b1, 0, false);
-    step(b1, b0, 1, i + 2 == total);
-  }
-  if (i < total) step(b0, b1, 0, true);
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------------
-// The same contraction walked STEP-MAJOR: a block owns a contiguous range of (step, tile group) units ordered by step first, so
-//   * the A fragments of a 512-slot step are built ONCE per block and step and serve every tile group of that step (the kernel above
-//     rebuilds them for every unit: at 2^20 keys each word of q is gathered 15 times, with 8 kB values 115 times) -- every word of q is
-//     read by (almost) exactly one block, which is what lets a lone host query be read straight from page-locked HOST memory (zero-copy:
-//     the 83 us upload of a 4.7 MB query disappears behind the 190 us stream instead of preceding it);
-//   * one barrier per STEP instead of one per unit (the waves of a block run free between the steps);
+// The STEP-MAJOR kernel of the lone host query: a block owns (512-slot step, group of 4 column tiles) units ordered by step first, so
+//   * the A fragments of a step are built ONCE per block and step and serve every tile group of that step -- every word of q is read by
+//     (almost) exactly one block, which is what lets a lone host query be read straight from page-locked HOST memory (zero-copy: the
+//     83 us upload of a 4.7 MB query disappears behind the 190 us stream instead of preceding it);
+//   * one barrier per STEP (the waves of a block run free between the steps);
 //   * the responses accumulate in LDS (one u32 per query and padded column) and leave through one pass of u32 atomics per block;
-//   * the two correction terms of the signed-byte split are added here, not by planar_init_kernel (which would read q a second time):
-//     while a wave gathers its share of a step's query words it also sums them, and every (step, tile group) unit adds
-//     128 * (sum of the step's valid query words) - 0x40404000 * (valid slots of the step) to each of its 64 columns -- every unit
-//     is visited exactly once, so every column receives the whole per-query term; the units of step 0 add 0x80808080 * colsum[column].
-// Same arithmetic, same packed image, same results bit for bit.  Used for the slice pass order (every pass its own stream from HBM);
-// the interleaved order of the multi-GPU shards stays on the kernel above.
-template <int HB, int NS, bool NT>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))  // two blocks a CU is the grid; at 3 it spills
+//   * the two correction terms of the signed-byte split are added here: while a wave gathers its share of a step's query words it also
+//     sums them, and every (step, tile group) unit adds 128 * (sum of the step's valid query words) - 0x40404000 * (valid slots of the
+//     step) to each of its 64 columns -- every unit is visited exactly once, so every column receives the whole per-query term; the
+//     units of step 0 add 0x80808080 * colsum[column].
+// One row set (up to 4 queries per pass), slice order only; everything device-resident runs on the wide kernel below.
+template <int HB, bool NT>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 respond_planar_ks_kernel(const PlanarArgs a) {
+  constexpr int NS = 1;          // sets of 16 A rows: one set answers up to 4 queries per pass (wider passes: the wide kernel)
   constexpr int NL = 8 + HB;     // 16-byte loads per lane and tile step
   constexpr int ST16 = NL * 64;  // uint4 per super-tile
   __shared__ uint4 abuf[2][NS][8][64];     // A fragments of a step: [parity][row set][k-block][lane]
@@ -356,7 +152,7 @@ respond_planar_ks_kernel(const PlanarArgs a) {
   const uint32_t tail_visits = se > sb ? (uint32_t)((se - 1) / TG - sb / TG + 1) : 0;
   const uint32_t n_visits = rounds + tail_visits;
   if (n_visits == 0) return;  // block-uniform: an idle block takes part in nothing
-  if (a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 4 + 0] = wall_clock64(), a.trace[blockIdx.x * 4 + 3] = n_visits;
+  CPIR_DIAG_ONLY(if (a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 4 + 0] = wall_clock64(), a.trace[blockIdx.x * 4 + 3] = n_visits;)
   // (the 64-bit divisions once, not per unit; plain scalars, no structs: selecting between structs captured by reference sends them
   // through scratch memory)
   const uint32_t tail_ks = tail0 + (uint32_t)(sb / TG), tail_tg0 = (uint32_t)(sb % TG);
@@ -517,16 +313,9 @@ respond_planar_ks_kernel(const PlanarArgs a) {
   // ---- the passes of the launch as ONE pipeline --------------------------------------------------------------------------------------
   // A pass ends where the next begins: the last unit of a pass prefetches the next pass's first tile (the same tile -- every pass walks the
   // same visits) and its last visit builds the next pass's first fragments, exactly as for the next visit inside a pass; the pass's
-  // responses leave at the boundary, between two barriers, while those requests are in flight (round 3 drained the pipeline, flushed and
-  // ran a prologue for every pass: 26.4 us per query for passes of 8 at 2^20 keys, 25.3 now).  With THREE row sets a pass answers 12
-  // queries: 18.8 us per query at 2^20 keys (two column windows of 8 / 7 tile groups, so that two blocks still share a CU's LDS), 134 with
-  // 8 kB values (194 with 8 per pass), 70.5 at 2^22 keys (97.5); 233 VGPR, no scratch.
-  // What the flush itself costs: 512 blocks x 7 680 words -- a fused pass of 8 -- leave as 3.9 M u32 atomics in one burst: 10 us even with
-  // words of their own per block, 19.7 us when every block walks the words in the same order, 11.5 us when each starts at an offset of its
-  // own (scripts/probes/atomic_flush_probe.hip); in the kernel the pass takes 1-2 us per query less without it.  Tried and dropped: a
-  // double-sized accumulator whose finished half is trickled out during the NEXT pass, two atomics per thread and unit -- 27.0-27.4 us per
-  // query: the halves need 93 KiB of LDS, i.e. one block per CU (28.0 us on its own against 25.2 with two), and the trickled atomics sit
-  // in the wave's vector-memory queue between the tile prefetch and its wait, which, counted in issue order, then covers them too.
+  // responses leave at the boundary, between two barriers, while those requests are in flight.
+  // What the flush costs: the blocks' words leave as u32 atomics in one burst; every block starts its round over the words at an offset of
+  // its own (19.7 us for a pass of 8 when every block walks them in the same order, 11.5 us with the offsets: scripts/probes/atomic_flush_probe.hip).
   const uint32_t rtotal = nq * cpad;
   for (uint32_t i = threadIdx.x; i < rtotal; i += kThreads) racc[i] = 0;
   uint32_t pass = 0;
@@ -557,7 +346,7 @@ respond_planar_ks_kernel(const PlanarArgs a) {
     a_finish(raw0, 0);
   }
   __syncthreads();
-  if (a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 4 + 1] = wall_clock64();
+  CPIR_DIAG_ONLY(if (a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 4 + 1] = wall_clock64();)
 
   int par = 0;
   // The NEXT visit's query words are requested in the first unit of the current visit; they are turned into fragments in the same
@@ -667,7 +456,7 @@ respond_planar_ks_kernel(const PlanarArgs a) {
   // ---- the last pass ----
   __syncthreads();
   flush_pass(pass, false);
-  if (a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 4 + 2] = wall_clock64();
+  CPIR_DIAG_ONLY(if (a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 4 + 2] = wall_clock64();)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
@@ -716,16 +505,41 @@ respond_planar_wide_kernel(const PlanarArgs a) {
   const uint32_t kb0 = a.ks_lo + (uint32_t)(((uint64_t)ks_len * xcd) / nx);
   const uint32_t ke0 = a.ks_lo + (uint32_t)(((uint64_t)ks_len * (xcd + 1)) / nx);
   const uint32_t TG = a.tg_n;
-  // visits (step, first tile group, one past the last): units u = (step kb0 + u / TG, tile group u % TG) split evenly over the blocks
+  // A pass is a sequence of VISITS (step, first tile group, one past the last): units u = (step kb0 + u / TG, tile group u % TG), u in [s0, s1).
+  // Two orders of the passes of one launch (same arithmetic):
+  //   slice order:       the units are split evenly over the blocks; a block walks ITS slice [s0, s1) once per pass -- every pass is a stream
+  //                      of the database from HBM of its own;
+  //   interleaved order: the passes are laid end to end and the whole (pass, unit) space is split evenly, so that different blocks walk
+  //                      the same tiles for different passes at about the same time and share them on die (pays where the image is small
+  //                      enough to stay there: the shards of a multi-GPU server).  A block then takes part in the passes [p_first, p_last]:
+  //                      the tail of the first, whole ones, the head of the last.
   const uint64_t units = (uint64_t)TG * (ke0 - kb0);
-  const uint64_t sb = units * j / nb, se = units * (j + 1) / nb;
-  const uint32_t n_visits = se > sb ? (uint32_t)((se - 1) / TG - sb / TG + 1) : 0;
-  if (n_visits == 0) return;  // block-uniform: an idle block takes part in nothing
-  if (a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 4 + 0] = wall_clock64(), a.trace[blockIdx.x * 4 + 3] = n_visits;
-  const uint32_t first_ks = kb0 + (uint32_t)(sb / TG), first_tg0 = (uint32_t)(sb % TG), last_tg1 = (uint32_t)((se - 1) % TG) + 1;
-  auto visit_ks = [=](uint32_t v) { return first_ks + v; };
-  auto visit_tg0 = [=](uint32_t v) { return v == 0 ? first_tg0 : 0u; };
-  auto visit_tg1 = [=](uint32_t v) { return v + 1 == n_visits ? last_tg1 : TG; };
+  uint64_t r0, r1;  // this block's range: of the units (slice order) or of the (pass, unit) space (interleaved)
+  uint32_t p_first = 0, p_last = a.passes - 1;
+  if (a.interleave) {
+    const uint64_t all = units * a.passes;
+    r0 = all * j / nb, r1 = all * (j + 1) / nb;
+    if (r1 > r0) p_first = (uint32_t)(r0 / units), p_last = (uint32_t)((r1 - 1) / units);
+  } else {
+    r0 = units * j / nb, r1 = units * (j + 1) / nb;
+  }
+  if (r1 <= r0) return;  // block-uniform: an idle block takes part in nothing
+  CPIR_DIAG_ONLY(if (a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 4 + 0] = wall_clock64(), a.trace[blockIdx.x * 4 + 3] = (uint32_t)(r1 - r0);)
+  // the visits of pass p for this block, as plain scalars (block-uniform; 64-bit divisions once per pass, not per unit)
+  uint32_t c_nv, c_ks0, c_tg0, c_tg1;  // current pass: number of visits, step of visit 0, first tile group of visit 0, end of the last visit
+  uint32_t n_nv, n_ks0, n_tg0, n_tg1;  // the pass after it (what the last visit of a pass prefetches and builds for)
+  auto pass_visits = [&](uint32_t p, uint32_t& nv_, uint32_t& ks0_, uint32_t& tg0_, uint32_t& tg1_) __attribute__((always_inline)) {
+    uint64_t s0 = r0, s1 = r1;
+    if (a.interleave) {
+      s0 = p == p_first ? r0 - (uint64_t)p_first * units : 0;
+      s1 = p == p_last ? r1 - (uint64_t)p_last * units : units;
+    }
+    nv_ = (uint32_t)((s1 - 1) / TG - s0 / TG + 1);
+    ks0_ = kb0 + (uint32_t)(s0 / TG), tg0_ = (uint32_t)(s0 % TG), tg1_ = (uint32_t)((s1 - 1) % TG) + 1;
+  };
+  pass_visits(p_first, c_nv, c_ks0, c_tg0, c_tg1);
+  n_nv = c_nv, n_ks0 = c_ks0, n_tg0 = c_tg0, n_tg1 = c_tg1;
+  if (a.interleave && p_first < p_last) pass_visits(p_first + 1, n_nv, n_ks0, n_tg0, n_tg1);
 
   const uint32_t limb = cl & 3;
   const uint32_t sel01 = limb | ((4 + limb) << 8);
@@ -866,23 +680,23 @@ respond_planar_wide_kernel(const PlanarArgs a) {
     }
   };
 
-  // prologue: the first tile, the fragments of the first visit's step of pass 0
-  uint32_t pass = 0, v = 0;
-  uint32_t cks = visit_ks(0), ctg1 = visit_tg1(0);
-  uint32_t tg = visit_tg0(0);
+  // prologue: the first tile, the fragments of the first visit's step of the block's first pass
+  uint32_t pass = p_first, v = 0;
+  uint32_t cks = c_ks0, ctg1 = c_nv == 1 ? c_tg1 : TG;
+  uint32_t tg = c_tg0;
   uint4 b0[NL], b1[NL];
   uint4 raw[kWMaxSets];
   load_tile(b0, tg, cks);
   uint4 idx = make_uint4(0, 0, 0, 0);
   bool idx_pending = false;  // the next visit's indices are requested, its query words are not yet
   if (guarded_step(cks)) {
-    a_guarded(cks, 0, 0);
+    a_guarded(cks, pass, 0);
   } else {
     if (mapped) {
       idx = idx_issue(cks);
-      a_issue_mapped(raw, idx, 0);
+      a_issue_mapped(raw, idx, pass);
     } else {
-      a_issue(raw, cks, 0);
+      a_issue(raw, cks, pass);
     }
     a_finish(raw, 0);
   }
@@ -894,12 +708,12 @@ respond_planar_wide_kernel(const PlanarArgs a) {
   auto unit = [&](uint4(&cur)[NL], uint4(&nxt)[NL]) __attribute__((always_inline)) {
     const uint32_t ks = cks;
     const bool last_of_visit = tg + 1 == ctg1;
-    const bool pass_ends = v + 1 == n_visits;
-    const bool more_visits = !pass_ends || pass + 1 < a.passes;
+    const bool pass_ends = v + 1 == c_nv;
+    const bool more_visits = !pass_ends || pass < p_last;
     const uint32_t nv = pass_ends ? 0u : v + 1, npass = pass_ends ? pass + 1 : pass;
-    const uint32_t nks = visit_ks(nv);
+    const uint32_t nks = pass_ends ? n_ks0 : c_ks0 + nv;  // (unused values when nothing follows)
     const bool last = last_of_visit && !more_visits;
-    const uint32_t tg_n = last_of_visit ? visit_tg0(nv) : tg + 1, ks_n = last_of_visit ? nks : ks;
+    const uint32_t tg_n = last_of_visit ? (pass_ends ? n_tg0 : 0u) : tg + 1, ks_n = last_of_visit ? nks : ks;
     const bool g_n = more_visits && guarded_step(nks);
     // the next visit's query words: requested now, a whole visit ahead of their use (L2 / HBM)
     if (more_visits && !g_n) {
@@ -918,7 +732,7 @@ respond_planar_wide_kernel(const PlanarArgs a) {
     load_tile(nxt, last ? tg : tg_n, last ? ks : ks_n);  // always issued (the very last unit asks for its own tile again), see above
     const uint32_t Tw = tg * kWM + wave;      // tile of the window (indexes the LDS accumulators)
     const uint32_t T = a.tg_lo * kWM + Tw;    // tile of the image
-    if (T < a.col_tiles && !(a.ablate & 4u)) {
+    if (T < a.col_tiles CPIR_DIAG_ONLY(&& !(a.ablate & 4u))) {
       v4i hbv[HB > 0 ? 8 : 1];
       constexpr bool kPeel = HB <= 4;  // (five and six planes: the peeled set's extra live values spill 12-44 bytes per lane; expanded up front there)
       if constexpr (HB > 0 && !kPeel) {
@@ -981,17 +795,20 @@ respond_planar_wide_kernel(const PlanarArgs a) {
       if (more_visits) {
         __syncthreads();  // everybody is done with this step's fragments (and, at a pass boundary, with accumulating this pass)
         if (pass_ends) {
-          if (!(a.ablate & 2u)) flush_pass(pass, true);  // (nobody accumulates for the next pass before the barrier below)
+          CPIR_DIAG_ONLY(if (!(a.ablate & 2u)))
+          flush_pass(pass, true);  // (nobody accumulates for the next pass before the barrier below)
           pass = npass;
+          c_nv = n_nv, c_ks0 = n_ks0, c_tg0 = n_tg0, c_tg1 = n_tg1;
+          if (a.interleave && pass < p_last) pass_visits(pass + 1, n_nv, n_ks0, n_tg0, n_tg1);  // (slice order: every pass walks the same visits)
         }
-        if (!(a.ablate & 1u)) {
+        CPIR_DIAG_ONLY(if (!(a.ablate & 1u))) {
           if (!g_n) a_finish(raw, par ^ 1);
           else a_guarded(nks, npass, par ^ 1);
         }
         __syncthreads();  // the next step's fragments are complete
         par ^= 1;
         first_of_visit = true;
-        v = nv, cks = nks, ctg1 = visit_tg1(v);
+        v = nv, cks = nks, ctg1 = v + 1 == c_nv ? c_tg1 : TG;
       } else {
         done = true;
       }
@@ -1005,79 +822,85 @@ respond_planar_wide_kernel(const PlanarArgs a) {
   }
 
   __syncthreads();
-  if (!(a.ablate & 2u)) flush_pass(pass, false);
-  if (a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 4 + 2] = wall_clock64();
+  CPIR_DIAG_ONLY(if (!(a.ablate & 2u)))
+  flush_pass(pass, false);
+  CPIR_DIAG_ONLY(if (a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 4 + 2] = wall_clock64();)
 }
 
-// r[q][c] += 128 * sum_n (q[n] - 0x80808080) over this block's slice of the valid slots, and (slice 0 only) += 0x80808080 * colsum[c]:
-// the two correction terms of the signed-byte split (top of the file).  r was zeroed on the stream before; all updates are u32
-// atomic adds, so their order against the main kernel's does not matter.
-__global__ void __launch_bounds__(kThreads) planar_init_kernel(const uint32_t* __restrict__ q, uint64_t q_len, uint64_t q_slot_offset,
-                                                                uint64_t num_slots, const uint32_t* __restrict__ colsum,
-                                                                uint32_t num_cols, uint32_t* __restrict__ r, uint32_t split,
-                                                                uint64_t range_lo, uint64_t range_hi) {
-  __shared__ uint32_t sm[kThreads / 64];
-  const uint32_t qi = blockIdx.x / split, s = blockIdx.x % split;
-  const uint64_t room = q_len > q_slot_offset ? q_len - q_slot_offset : 0;
-  const uint64_t nvalid = num_slots < room ? num_slots : room;
-  // the valid slots of [range_lo, range_hi): this launch's part of the slot axis (colsum == NULL: its column term was added before)
-  const uint64_t a0 = range_lo < nvalid ? range_lo : nvalid, a1 = range_hi < nvalid ? range_hi : nvalid;
-  const uint64_t lo = a0 + (a1 - a0) * s / split, hi = a0 + (a1 - a0) * (s + 1) / split;
-  const uint32_t* src = q + (uint64_t)qi * q_len + q_slot_offset;
-  uint32_t sum = 0;
-#pragma unroll 8
-  for (uint64_t n = lo + threadIdx.x; n < hi; n += kThreads) sum += src[n];
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = sum;
-  __syncthreads();
-  sum = sm[0] + sm[1] + sm[2] + sm[3];
-  const uint32_t k = 128u * sum - 0x40404000u * (uint32_t)(hi - lo);  // 128 * 0x80808080 = 0x40404000 mod 2^32
-  for (uint32_t c = threadIdx.x; c < num_cols; c += kThreads) {
-    const uint32_t v = k + ((s == 0 && colsum) ? 0x80808080u * colsum[c] : 0u);
-    atomicAdd(r + (uint64_t)qi * num_cols + c, v);
-  }
+#ifdef CPIR_DIAG
+// per-block timing trace of a launch (CPIR_KS_TRACE=1, diagnosis build only): 4 words per block -- wall clock at entry, behind the first
+// fragments, at the end; visits.  The launch is synchronised for it.
+uint64_t* diag_trace_begin(hipStream_t stream) {
+  static uint64_t* trace_dev = nullptr;
+  if (!trace_dev && hipMalloc(reinterpret_cast<void**>(&trace_dev), 4096 * 4 * sizeof(uint64_t)) != hipSuccess) trace_dev = nullptr;
+  if (trace_dev) (void)hipMemsetAsync(trace_dev, 0, 4096 * 4 * sizeof(uint64_t), stream);
+  return trace_dev;
 }
+bool diag_trace_fetch(const uint64_t* trace_dev, uint64_t grid, hipStream_t stream, std::vector<uint64_t>& t, uint64_t* t0) {
+  t.assign((size_t)grid * 4, 0);
+  if (hipMemcpyAsync(t.data(), trace_dev, t.size() * 8, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return false;
+  *t0 = ~0ull;
+  for (uint64_t b = 0; b < grid; b++)
+    if (t[b * 4] && t[b * 4] < *t0) *t0 = t[b * 4];
+  return true;
+}
+void diag_trace_print_blocks(const uint64_t* trace_dev, uint64_t grid, hipStream_t stream) {
+  std::vector<uint64_t> t;
+  uint64_t t0;
+  if (!diag_trace_fetch(trace_dev, grid, stream, t, &t0)) return;
+  std::vector<double> st, ff, en;
+  for (uint64_t b = 0; b < grid; b++)
+    if (t[b * 4]) st.push_back((t[b * 4] - t0) * 0.01), ff.push_back((t[b * 4 + 1] - t0) * 0.01), en.push_back((t[b * 4 + 2] - t0) * 0.01);
+  if (st.empty()) return;
+  auto q3 = [](std::vector<double> v, double* lo, double* med, double* hi) {
+    std::sort(v.begin(), v.end());
+    *lo = v.front(), *med = v[v.size() / 2], *hi = v.back();
+  };
+  double a0, a1, a2, b0, b1, b2, c0, c1, c2;
+  q3(st, &a0, &a1, &a2), q3(ff, &b0, &b1, &b2), q3(en, &c0, &c1, &c2);
+  fprintf(stderr, "[ks trace] blocks %zu  start %.1f/%.1f/%.1f  first fragments %.1f/%.1f/%.1f  end %.1f/%.1f/%.1f us (min/median/max after the first block's start)\n",
+          st.size(), a0, a1, a2, b0, b1, b2, c0, c1, c2);
+}
+void diag_trace_print_xcds(const uint64_t* trace_dev, uint64_t grid, uint32_t batch, uint32_t passes, hipStream_t stream) {
+  std::vector<uint64_t> t;
+  uint64_t t0;
+  if (!diag_trace_fetch(trace_dev, grid, stream, t, &t0)) return;
+  double sum[8] = {0}, mx[8] = {0}, mn[8];
+  int cnt[8] = {0};
+  for (int x = 0; x < 8; x++) mn[x] = 1e30;
+  for (uint64_t b = 0; b < grid; b++)
+    if (t[b * 4]) {
+      const double e = (t[b * 4 + 2] - t0) * 0.01;
+      const int x = (int)(b % 8);
+      sum[x] += e, cnt[x]++;
+      if (e > mx[x]) mx[x] = e;
+      if (e < mn[x]) mn[x] = e;
+    }
+  fprintf(stderr, "[wide trace] batch %u passes %u, block ends per XCD (min/mean/max us):", batch, passes);
+  for (int x = 0; x < 8; x++)
+    if (cnt[x]) fprintf(stderr, "  %d: %.0f/%.0f/%.0f", x, mn[x], sum[x] / cnt[x], mx[x]);
+  fprintf(stderr, "\n");
+}
+#endif
 
 using KernelFn = void (*)(const PlanarArgs);
 
-template <int NS>
-KernelFn pick_hb(uint32_t hb, bool nt) {
+KernelFn pick_ks(uint32_t hb, bool nt) {
   switch (hb) {
-    case 0: return nt ? respond_planar_kernel<0, NS, true> : respond_planar_kernel<0, NS, false>;  // b <= 8: the byte alone
-    case 1: return nt ? respond_planar_kernel<1, NS, true> : respond_planar_kernel<1, NS, false>;
-    case 2: return nt ? respond_planar_kernel<2, NS, true> : respond_planar_kernel<2, NS, false>;
-    case 3: return nt ? respond_planar_kernel<3, NS, true> : respond_planar_kernel<3, NS, false>;
-    case 4: return nt ? respond_planar_kernel<4, NS, true> : respond_planar_kernel<4, NS, false>;
-    case 5: return nt ? respond_planar_kernel<5, NS, true> : respond_planar_kernel<5, NS, false>;
-    case 6: return nt ? respond_planar_kernel<6, NS, true> : respond_planar_kernel<6, NS, false>;
+    case 0: return nt ? respond_planar_ks_kernel<0, true> : respond_planar_ks_kernel<0, false>;  // b <= 8: the byte alone
+    case 1: return nt ? respond_planar_ks_kernel<1, true> : respond_planar_ks_kernel<1, false>;
+    case 2: return nt ? respond_planar_ks_kernel<2, true> : respond_planar_ks_kernel<2, false>;
+    case 3: return nt ? respond_planar_ks_kernel<3, true> : respond_planar_ks_kernel<3, false>;
+    case 4: return nt ? respond_planar_ks_kernel<4, true> : respond_planar_ks_kernel<4, false>;
+    case 5: return nt ? respond_planar_ks_kernel<5, true> : respond_planar_ks_kernel<5, false>;
+    case 6: return nt ? respond_planar_ks_kernel<6, true> : respond_planar_ks_kernel<6, false>;
     default: return nullptr;
   }
-}
-
-KernelFn pick(uint32_t hb, uint32_t batch, bool nt) { return batch <= 4 ? pick_hb<1>(hb, nt) : pick_hb<2>(hb, nt); }
-
-template <int NS>
-KernelFn pick_ks_hb(uint32_t hb, bool nt) {
-  switch (hb) {
-    case 0: return nt ? respond_planar_ks_kernel<0, NS, true> : respond_planar_ks_kernel<0, NS, false>;
-    case 1: return nt ? respond_planar_ks_kernel<1, NS, true> : respond_planar_ks_kernel<1, NS, false>;
-    case 2: return nt ? respond_planar_ks_kernel<2, NS, true> : respond_planar_ks_kernel<2, NS, false>;
-    case 3: return nt ? respond_planar_ks_kernel<3, NS, true> : respond_planar_ks_kernel<3, NS, false>;
-    case 4: return nt ? respond_planar_ks_kernel<4, NS, true> : respond_planar_ks_kernel<4, NS, false>;
-    case 5: return nt ? respond_planar_ks_kernel<5, NS, true> : respond_planar_ks_kernel<5, NS, false>;
-    case 6: return nt ? respond_planar_ks_kernel<6, NS, true> : respond_planar_ks_kernel<6, NS, false>;
-    default: return nullptr;
-  }
-}
-
-KernelFn pick_ks(uint32_t hb, uint32_t batch, bool nt) {
-  return batch <= 4 ? pick_ks_hb<1>(hb, nt) : (batch <= 8 ? pick_ks_hb<2>(hb, nt) : pick_ks_hb<3>(hb, nt));
 }
 
 template <int HB>
 KernelFn pick_wide_hb(bool nt, bool map) {
-  if (map) return nt ? respond_planar_wide_kernel<HB, true, true> : nullptr;  // (a slot map with cached loads: not built; the caller gathers first)
+  if (map) return nt ? respond_planar_wide_kernel<HB, true, true> : respond_planar_wide_kernel<HB, false, true>;
   return nt ? respond_planar_wide_kernel<HB, true, false> : respond_planar_wide_kernel<HB, false, false>;
 }
 KernelFn pick_wide(uint32_t hb, bool nt, bool map) {
@@ -1098,29 +921,25 @@ constexpr uint32_t kWideLdsBudget = 156u << 10;
 
 }  // namespace
 
-// How many queries one pass over the image can answer in a launch of `passes` passes under the current dispatch rules: 12 where the
-// step-major kernel takes the launch (three row sets of 4 queries), 8 where the tile-major kernel does (interleaved passes of small shards,
-// or the step-major kernel switched off).
-uint32_t planar_max_queries_per_pass(const cpir_dtc_layout& L, uint32_t passes, int interleave, int ks_mode) {
-  const bool inter = passes > 1 && (interleave == 1 || (interleave < 0 && L.total_words * 4 <= (960ull << 20)));
-  return (ks_mode >= 1 && !inter) ? CPIR_PLANAR_MAX_QUERIES_PER_PASS : 8u;
+// Order of the passes of one launch: interleaved where the image is small enough for concurrent passes to share its bytes on die, slice
+// order for HBM-sized streams.  Measured on MI355X, us per query, one query per pass, 32 passes a launch (scripts/families_ab.py, round 5):
+//   1/8 of the 2^20-key DB (157 MB): slice + nt 23.8, interleaved + cached loads 8.2;  1/4 (313 MB): 47.5 / 17.2;
+//   1/2 (626 MB): 95.3 / 34.3;  whole (1.25 GB): 184.1 / 68.6 -- above the HBM roof, i.e. on-die reuse, never the headline
+bool planar_passes_interleaved(const cpir_dtc_layout& L, uint32_t passes, int interleave) {
+  return passes > 1 && (interleave == 1 || (interleave < 0 && L.total_words * 4 <= (960ull << 20)));
 }
 
-int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
-                          uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, int blocks_per_cu,
-                          bool nontemporal, bool xcd_split, int interleave, int ks_mode, bool r_prezeroed, uint64_t step_lo, uint64_t step_hi,
-                          const PlanarHostFill* fill) {
+// The step-major kernel: `passes` passes of `batch` (1..CPIR_PLANAR_KS_MAX_QUERIES_PER_PASS) queries each, slice order.  It reads every query
+// word exactly once per column window, which is what the in-place host path needs (in_place: whole steps round-robin over the blocks, so
+// that the grid consumes q front to back, and the far-mode fragment schedule; `fill`: q is still being copied in while the kernel runs).
+int launch_respond_planar_ks(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
+                             uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, int blocks_per_cu,
+                             bool nontemporal, bool xcd_split, bool in_place, bool r_prezeroed, uint64_t step_lo, uint64_t step_hi,
+                             const PlanarHostFill* fill) {
   // shape invariants the kernel relies on (layout already checked by the caller)
-  if (L.packing != CPIR_PACK_PLANAR || batch == 0 || batch > CPIR_PLANAR_MAX_QUERIES_PER_PASS || passes == 0) return CPIR_ERR_INVALID_ARGUMENT;
+  if (L.packing != CPIR_PACK_PLANAR || batch == 0 || batch > CPIR_PLANAR_KS_MAX_QUERIES_PER_PASS || passes == 0) return CPIR_ERR_INVALID_ARGUMENT;
   const uint32_t hb = planar_hi_planes(L.mat_elem_bit_len);
-  // order of the passes: interleaved where the shard is small enough for concurrent passes to share its bytes on die (same rule
-  // as respond.hip), slice order for HBM-sized streams.  Measured on MI355X, us per query, one query per pass, 32 passes:
-  //   1/8 of the 2^20-key DB (157 MB): slice+nt 24.6, interleaved+nt 16.9, interleaved+cached loads 12.6
-  //   1/2 (629 MB): 95.7 / 74.1 / 51.7;  whole (1.26 GB): 186.5 / 154.6 / 107.2 -- above the HBM roof, i.e. on-die reuse
-  const bool inter = passes > 1 && (interleave == 1 || (interleave < 0 && L.total_words * 4 <= (960ull << 20)));
-  // `nt` loads keep a once-per-query stream out of the caches; passes that are meant to share bytes on die use plain loads
-  const bool nt = nontemporal && !inter;
-  KernelFn fn = pick(hb, batch > 8 ? 8 : batch, nt);  // (batch > 8 never reaches it: checked below)
+  KernelFn fn = pick_ks(hb, nontemporal);
   if (!fn || L.chunk_words != (8 + hb) * 256 || L.rows_padded % 16 != 0) return CPIR_ERR_INVALID_ARGUMENT;
   const uint64_t ks_total = (L.num_slots + CPIR_PLANAR_SLOTS_PER_TILE - 1) / CPIR_PLANAR_SLOTS_PER_TILE;
   if (ks_total > 0xffffffffull || ks_total * (L.chunk_words / 16) != L.words_per_row_padded) return CPIR_ERR_INVALID_ARGUMENT;
@@ -1143,50 +962,29 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
   a.ks_lo = (uint32_t)step_lo, a.ks_hi = (uint32_t)step_hi;
   a.q_per_pass = batch;
   a.passes = passes;
-  a.interleave = inter ? 1u : 0u;
-  a.q_far = ks_mode == 3 ? 1u : 0u;
+  a.interleave = 0;
+  a.q_far = in_place ? 1u : 0u;
   // q in host memory: whole steps round-robin over the blocks, so that q is consumed front to back (it may still be arriving) and
   // every word crosses the link exactly once
-  a.strided = ks_mode == 3 ? 1u : 0u;
+  a.strided = in_place ? 1u : 0u;
   a.progress = fill ? fill->progress : nullptr;
   a.abort_flag = fill ? fill->abort_flag : nullptr;
   a.poll_ticks = fill ? (uint64_t)fill->timeout_us * 100 : 0;
-  a.ablate = 0;
   a.keep = nullptr;
-  a.trace = nullptr;
-  if (fill && (ks_mode != 3 || !fill->progress || !fill->abort_flag)) return CPIR_ERR_INVALID_ARGUMENT;
+  CPIR_DIAG_ONLY(a.ablate = 0; a.trace = nullptr;)
+  if (fill && (!in_place || !fill->progress || !fill->abort_flag)) return CPIR_ERR_INVALID_ARGUMENT;
   a.q_scalar = (reinterpret_cast<uintptr_t>(q) % 16 != 0 || q_slot_offset % 4 != 0 || (batch * passes > 1 && q_len % 4 != 0)) ? 1u : 0u;
 
-  // resident blocks per CU, measured on MI355X at 2^20 keys: streaming (slice order) 2 blocks 188.7 us per query, 3 blocks 192.9,
-  // 1 block 273; sharing passes (interleaved) 3 blocks 107 vs 2 blocks 118.  The two-row-set kernel fits 2 blocks per CU.
-  // The step-major kernel where it applies: slice order (every pass its own stream), LDS room for the pass's responses.  It adds the
-  // correction terms itself (and reads every query word once), so no init kernel in front of it.  Measured at 2^20 keys, us per query,
-  // tile-major / step-major: one query, one launch 200.6 / 191.9 (2^22 keys 757 / 723, 8 kB values 1453 / 1394); passes of 8 queries
-  // 32.0 / 25.6, of 4 51.6 / 48.3; one query per pass, 32 passes a launch 185.3 / 185.0 (within half a per cent either way at every
-  // config but 2^22 keys) -- so mode 1 keeps the tile-major kernel for that streaming case.  One-row-set step-major blocks run ONE per CU
-  // (191.9 against 202.3 with two: half as many prologues and flushes, and 4 waves x 2 tiles in flight already cover the latency).
-  // The step-major kernel keeps a pass's responses in LDS: 64 columns x batch u32 per tile group, at most 48 KiB.  Where all tile groups
-  // do not fit (8 kB values: 7 312 columns x 8 queries = 234 KB) the launch is repeated over column WINDOWS of as many tile groups as fit,
-  // each a launch of its own over all steps -- the query words are gathered once per window (a few MB against the GBs of the stream).
-  // (blocks of the two-row-set kernel run two per CU and share its 160 KiB: 48 KiB each beside the 32 KiB of A fragments.  One block per CU
-  // with 112 KiB -- 3 windows instead of 5 at 8 kB values -- measured the same: 191.9 against 193.5 us per query)
-  // (three row sets -- 9 to 12 queries per pass, step-major kernel only -- keep 48 KiB of A fragments, so their accumulators get 31 KiB:
-  // two blocks still share a CU, and a database wider than 10 tile groups is answered in column windows: 2 at 2^20 keys x 1 kB)
-  const uint32_t racc_budget = batch > 8 ? (31u << 10) : (48u << 10);
-  const uint32_t max_tg = racc_budget / (batch * kM * 16 * (uint32_t)sizeof(uint32_t));  // 24 tile groups for 8 queries, 192 for one, 10 for 12
+  // The kernel keeps a pass's responses in LDS: 64 columns x batch u32 per tile group, at most 48 KiB.  Where all tile groups do not fit
+  // (one query beyond 12 288 columns) the launch is repeated over column WINDOWS of as many tile groups as fit, each a launch of its own
+  // over all steps -- the query words are gathered once per window (a few MB against the GBs of the stream).
+  const uint32_t max_tg = (48u << 10) / (batch * kM * 16 * (uint32_t)sizeof(uint32_t));  // 192 tile groups for one query, 48 for four
   const uint32_t windows = (a.tile_groups + max_tg - 1) / max_tg;
   const uint32_t tg_per_window = (a.tile_groups + windows - 1) / windows;
-  // (a query beyond 8 MiB no longer stays in the XCDs' L2 next to the stream, and the tile-major kernel gathers every word of it once
-  // per tile group: at 2^22 keys, 18.9 MB, the step-major kernel streams 727 against 743 us per query, so it takes that case too)
-  const bool long_query = (uint64_t)(a.ks_hi - a.ks_lo) * CPIR_PLANAR_SLOTS_PER_TILE * 4 > (8ull << 20);
-  const bool want_ks = ks_mode >= 2 || (ks_mode == 1 && (batch >= 2 || passes == 1 || long_query));
-  // (a query read in place over the host link must be read ONCE: one window or nothing)
-  KernelFn fn_ks = (want_ks && !inter && (windows == 1 || ks_mode != 3)) ? pick_ks(hb, batch, nt) : nullptr;
-  if (ks_mode == 3 && !fn_ks) return CPIR_ERR_INVALID_ARGUMENT;  // the caller relies on q being read once
-  if (batch > 8 && !fn_ks) return CPIR_ERR_INVALID_ARGUMENT;      // the tile-major kernel has two row sets at most (planar_max_queries_per_pass)
-  int bpc = blocks_per_cu > 0 ? blocks_per_cu : (fn_ks ? (batch <= 4 ? 1 : 2) : (inter ? 3 : 2));
-  if (batch > 4 && bpc > 2) bpc = 2;
-  // grid of a launch over `tgs` tile groups
+  if (in_place && windows != 1) return CPIR_ERR_INVALID_ARGUMENT;  // (a query read in place over the host link must be read ONCE: one window or nothing)
+  // One block per CU (measured at 2^20 keys, one query: 191.9 us against 202.3 with two: half as many prologues and flushes, and 4 waves x
+  // 2 tiles in flight already cover the latency)
+  const int bpc = blocks_per_cu > 0 ? (blocks_per_cu > 2 ? 2 : blocks_per_cu) : 1;
   auto grid_for_units = [&](uint32_t tgs, uint32_t* nx_out) {
     const uint64_t units = (uint64_t)tgs * (a.ks_hi - a.ks_lo);
     uint64_t grid = (uint64_t)dev->num_cus * (uint64_t)bpc;
@@ -1203,77 +1001,43 @@ int launch_respond_planar(const Device* dev, const uint32_t* dtc, const cpir_dtc
 
   const uint32_t nq = batch * passes;
   const bool first = (step_lo == 0);
-  const uint32_t* colsum = first ? dtc + (uint64_t)L.rows_padded * L.words_per_row_padded : nullptr;
+  a.colsum = first ? dtc + (uint64_t)L.rows_padded * L.words_per_row_padded : nullptr;
   if (first && !r_prezeroed) CPIR_HIP_TRY(hipMemsetAsync(r, 0, (size_t)nq * L.num_cols * sizeof(uint32_t), stream));
-  if (fn_ks) {
-    a.colsum = colsum;
-    for (uint32_t w = 0; w < windows; w++) {
-      a.tg_lo = w * tg_per_window;
-      if (a.tg_lo >= a.tile_groups) break;
-      a.tg_n = a.tile_groups - a.tg_lo < tg_per_window ? a.tile_groups - a.tg_lo : tg_per_window;
-      const uint64_t grid = grid_for_units(a.tg_n, &a.nx);
-      const size_t racc_bytes = (size_t)batch * a.tg_n * (kM * 16) * sizeof(uint32_t);
-      // diagnosis (CPIR_KS_TRACE=1; launches in the in-place order only, i.e. the lone host caller's -- NOT the polled one, whose host side
-      // must keep running while the kernel does -- or respond.ks_major = 3): when each block started, had its first fragments, ended;
-      // printed per launch, which is synchronised for it
-      static const bool trace_env = getenv("CPIR_KS_TRACE") != nullptr;
-      static uint64_t* trace_dev = nullptr;
-      const bool tracing = trace_env && ks_mode == 3 && !fill && windows == 1 && grid <= 4096;
-      if (tracing) {
-        if (!trace_dev && hipMalloc(reinterpret_cast<void**>(&trace_dev), 4096 * 4 * sizeof(uint64_t)) != hipSuccess) trace_dev = nullptr;
-        if (trace_dev) (void)hipMemsetAsync(trace_dev, 0, 4096 * 4 * sizeof(uint64_t), stream);
-        a.trace = trace_dev;
-      }
-      hipLaunchKernelGGL(fn_ks, dim3((unsigned)grid), dim3(kThreads), racc_bytes, stream, a);
-      if (tracing && trace_dev) {
-        std::vector<uint64_t> t((size_t)grid * 4);
-        if (hipMemcpyAsync(t.data(), trace_dev, t.size() * 8, hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess) {
-          uint64_t t0 = ~0ull;
-          for (uint64_t b2 = 0; b2 < grid; b2++)
-            if (t[b2 * 4] && t[b2 * 4] < t0) t0 = t[b2 * 4];
-          std::vector<double> st, ff, en;
-          for (uint64_t b2 = 0; b2 < grid; b2++)
-            if (t[b2 * 4]) st.push_back((t[b2 * 4] - t0) * 0.01), ff.push_back((t[b2 * 4 + 1] - t0) * 0.01), en.push_back((t[b2 * 4 + 2] - t0) * 0.01);
-          auto q3 = [](std::vector<double> v2, double* lo, double* med, double* hi) {
-            std::sort(v2.begin(), v2.end());
-            *lo = v2.front(), *med = v2[v2.size() / 2], *hi = v2.back();
-          };
-          if (!st.empty()) {
-            double a0, a1, a2, b0, b1, b2_, c0, c1, c2;
-            q3(st, &a0, &a1, &a2), q3(ff, &b0, &b1, &b2_), q3(en, &c0, &c1, &c2);
-            fprintf(stderr, "[ks trace] blocks %zu  start %.1f/%.1f/%.1f  first fragments %.1f/%.1f/%.1f  end %.1f/%.1f/%.1f us (min/median/max after the first block's start)\n",
-                    st.size(), a0, a1, a2, b0, b1, b2_, c0, c1, c2);
-          }
-        }
-        a.trace = nullptr;
-      }
-    }
-    CPIR_HIP_TRY(hipGetLastError());
-    return CPIR_OK;
+  for (uint32_t w = 0; w < windows; w++) {
+    a.tg_lo = w * tg_per_window;
+    if (a.tg_lo >= a.tile_groups) break;
+    a.tg_n = a.tile_groups - a.tg_lo < tg_per_window ? a.tile_groups - a.tg_lo : tg_per_window;
+    const uint64_t grid = grid_for_units(a.tg_n, &a.nx);
+    const size_t racc_bytes = (size_t)batch * a.tg_n * (kM * 16) * sizeof(uint32_t);
+#ifdef CPIR_DIAG
+    // diagnosis (CPIR_KS_TRACE=1; launches in the in-place order only, i.e. the lone host caller's -- NOT the polled one, whose host side
+    // must keep running while the kernel does): when each block started, had its first fragments, ended; printed per launch, which is
+    // synchronised for it
+    static const bool trace_env = getenv("CPIR_KS_TRACE") != nullptr;
+    const bool tracing = trace_env && in_place && !fill && windows == 1 && grid <= 4096;
+    if (tracing) a.trace = diag_trace_begin(stream);
+#endif
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(kThreads), racc_bytes, stream, a);
+#ifdef CPIR_DIAG
+    if (tracing && a.trace) diag_trace_print_blocks(a.trace, grid, stream);
+    a.trace = nullptr;
+#endif
   }
-  a.colsum = nullptr;
-  a.tg_lo = 0, a.tg_n = a.tile_groups;
-  const uint64_t grid = grid_for_units(a.tile_groups, &a.nx);
-  const uint64_t range_lo = step_lo * CPIR_PLANAR_SLOTS_PER_TILE, range_hi = step_hi * CPIR_PLANAR_SLOTS_PER_TILE;
-  // slices of the query per init block: at most 16 Ki slots each (a lone query must not leave a handful of blocks reading hundreds of
-  // KB each in front of the main kernel: 12.6 us with 64 Ki-slot slices at 2^20 keys)
-  uint32_t split = (uint32_t)((range_hi - range_lo + 16383) / 16384);
-  split = split < 4 ? 4 : (split > 256 ? 256 : split);
-  hipLaunchKernelGGL(planar_init_kernel, dim3(nq * split), dim3(kThreads), 0, stream, q, q_len, q_slot_offset, L.num_slots, colsum,
-                     L.num_cols, r, split, range_lo, range_hi);
-  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(kThreads), 0, stream, a);
   CPIR_HIP_TRY(hipGetLastError());
   return CPIR_OK;
 }
 
-// The wide pass (respond_planar_wide_kernel): `passes` passes of `batch` (1..CPIR_PLANAR_WIDE_MAX_QUERIES_PER_PASS) queries each, one 8-wave
-// block per CU; a database whose accumulators do not fit beside the fragments is answered in column windows of whole groups of 8 tiles.
+
 int launch_respond_planar_wide(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                                uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, bool nontemporal,
-                               bool xcd_split, const uint32_t* keep) {
+                               bool xcd_split, int interleave, const uint32_t* keep) {
   if (L.packing != CPIR_PACK_PLANAR || batch == 0 || batch > CPIR_PLANAR_WIDE_MAX_QUERIES_PER_PASS || passes == 0) return CPIR_ERR_INVALID_ARGUMENT;
   const uint32_t hb = planar_hi_planes(L.mat_elem_bit_len);
-  KernelFn fn = pick_wide(hb, nontemporal, keep != nullptr);
+  // order of the passes: interleaved where the image is small enough for concurrent passes to share its bytes on die, slice order for
+  // HBM-sized streams; `nt` loads keep a once-per-pass stream out of the caches, passes that are meant to share bytes use plain loads
+  const bool inter = planar_passes_interleaved(L, passes, interleave);
+  const bool nt = nontemporal && !inter;
+  KernelFn fn = pick_wide(hb, nt, keep != nullptr);
   if (keep && q_len >= ((uint64_t)1 << 28)) return CPIR_ERR_INVALID_ARGUMENT;  // (32-bit word offsets inside a row set, see the kernel)
   if (!fn || L.chunk_words != (8 + hb) * 256 || L.rows_padded % 16 != 0) return CPIR_ERR_INVALID_ARGUMENT;
   const uint64_t ks_total = (L.num_slots + CPIR_PLANAR_SLOTS_PER_TILE - 1) / CPIR_PLANAR_SLOTS_PER_TILE;
@@ -1293,7 +1057,7 @@ int launch_respond_planar_wide(const Device* dev, const uint32_t* dtc, const cpi
   a.ks_lo = 0, a.ks_hi = (uint32_t)ks_total;
   a.q_per_pass = batch;
   a.passes = passes;
-  a.interleave = 0;
+  a.interleave = inter ? 1u : 0u;
   a.q_far = 0;
   a.strided = 0;
   a.progress = nullptr;
@@ -1301,12 +1065,14 @@ int launch_respond_planar_wide(const Device* dev, const uint32_t* dtc, const cpi
   a.poll_ticks = 0;
   a.q_scalar = (reinterpret_cast<uintptr_t>(q) % 16 != 0 || q_slot_offset % 4 != 0 || (batch * passes > 1 && q_len % 4 != 0)) ? 1u : 0u;
   a.colsum = dtc + (uint64_t)L.rows_padded * L.words_per_row_padded;
+#ifdef CPIR_DIAG
   static const uint32_t ablate_env = [] {
     const char* e = getenv("CPIR_WIDE_ABLATE");
     return e ? (uint32_t)strtoul(e, nullptr, 0) : 0u;
   }();
   a.ablate = ablate_env;
   a.trace = nullptr;
+#endif
   a.keep = keep;  // (device memory, at least L.num_slots entries, 16-byte aligned; the caller has checked that the slots it names lie inside q)
   if (keep && reinterpret_cast<uintptr_t>(keep) % 16 != 0) return CPIR_ERR_INVALID_ARGUMENT;
 
@@ -1320,7 +1086,7 @@ int launch_respond_planar_wide(const Device* dev, const uint32_t* dtc, const cpi
 
   // (up to 156 KiB of dynamic LDS: say so once per instantiation; a runtime that does not know the attribute is not an error)
   static std::atomic<bool> lds_raised[7][2][2];
-  if (!lds_raised[hb][nontemporal ? 1 : 0][keep ? 1 : 0].exchange(true, std::memory_order_relaxed)) {
+  if (!lds_raised[hb][nt ? 1 : 0][keep ? 1 : 0].exchange(true, std::memory_order_relaxed)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLdsBudget) != hipSuccess) (void)hipGetLastError();
   }
   CPIR_HIP_TRY(hipMemsetAsync(r, 0, (size_t)batch * passes * L.num_cols * sizeof(uint32_t), stream));
@@ -1328,7 +1094,7 @@ int launch_respond_planar_wide(const Device* dev, const uint32_t* dtc, const cpi
     a.tg_lo = w * tg_per_window;
     if (a.tg_lo >= a.tile_groups) break;
     a.tg_n = a.tile_groups - a.tg_lo < tg_per_window ? a.tile_groups - a.tg_lo : tg_per_window;
-    const uint64_t units = (uint64_t)a.tg_n * ks_total;
+    const uint64_t units = (uint64_t)a.tg_n * ks_total * (inter ? passes : 1u);  // what the blocks share out: the units, or the (pass, unit) space
     uint64_t grid = (uint64_t)dev->num_cus;  // one block per CU
     a.nx = (xcd_split && ks_total >= 8 && grid % 8 == 0) ? 8u : 1u;
     if (grid > units) {
@@ -1337,39 +1103,16 @@ int launch_respond_planar_wide(const Device* dev, const uint32_t* dtc, const cpi
       if (grid == 0) grid = 1, a.nx = 1;
     }
     const size_t lds = (size_t)fixed + (size_t)a.tg_n * per_tg;
-    static const bool trace_env = getenv("CPIR_KS_TRACE") != nullptr;  // (diagnosis, as for the step-major kernel: per XCD here)
-    static uint64_t* trace_dev = nullptr;
+#ifdef CPIR_DIAG
+    static const bool trace_env = getenv("CPIR_KS_TRACE") != nullptr;  // (as for the step-major kernel; the block ends per XCD here)
     const bool tracing = trace_env && windows == 1 && grid <= 4096;
-    if (tracing) {
-      if (!trace_dev && hipMalloc(reinterpret_cast<void**>(&trace_dev), 4096 * 4 * sizeof(uint64_t)) != hipSuccess) trace_dev = nullptr;
-      if (trace_dev) (void)hipMemsetAsync(trace_dev, 0, 4096 * 4 * sizeof(uint64_t), stream);
-      a.trace = trace_dev;
-    }
+    if (tracing) a.trace = diag_trace_begin(stream);
+#endif
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(kWThreads), lds, stream, a);
-    if (tracing && trace_dev) {
-      std::vector<uint64_t> t((size_t)grid * 4);
-      if (hipMemcpyAsync(t.data(), trace_dev, t.size() * 8, hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess) {
-        uint64_t t0 = ~0ull;
-        for (uint64_t b2 = 0; b2 < grid; b2++)
-          if (t[b2 * 4] && t[b2 * 4] < t0) t0 = t[b2 * 4];
-        double sum[8] = {0}, mx[8] = {0}, mn[8];
-        int cnt[8] = {0};
-        for (int x = 0; x < 8; x++) mn[x] = 1e30;
-        for (uint64_t b2 = 0; b2 < grid; b2++)
-          if (t[b2 * 4]) {
-            const double e = (t[b2 * 4 + 2] - t0) * 0.01;
-            const int x = (int)(b2 % 8);
-            sum[x] += e, cnt[x]++;
-            if (e > mx[x]) mx[x] = e;
-            if (e < mn[x]) mn[x] = e;
-          }
-        fprintf(stderr, "[wide trace] batch %u passes %u, block ends per XCD (min/mean/max us):", batch, passes);
-        for (int x = 0; x < 8; x++)
-          if (cnt[x]) fprintf(stderr, "  %d: %.0f/%.0f/%.0f", x, mn[x], sum[x] / cnt[x], mx[x]);
-        fprintf(stderr, "\n");
-      }
-      a.trace = nullptr;
-    }
+#ifdef CPIR_DIAG
+    if (tracing && a.trace) diag_trace_print_xcds(a.trace, grid, batch, passes, stream);
+    a.trace = nullptr;
+#endif
   }
   CPIR_HIP_TRY(hipGetLastError());
   return CPIR_OK;

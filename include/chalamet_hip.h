@@ -253,11 +253,10 @@ int cpir_op_synth_fill(cpir_device* dev, uint32_t* out, uint64_t count, uint64_t
  *   "respond.xcd_split" {0,1}, "respond.batch_fusion" {0,1} (0: every query of a batch call streams the database on its
  *   own, i.e. a batch call is only a cheaper way to enqueue independent responds), "respond.interleave_passes" {-1,0,1}
  *   (order in which one launch walks its passes; -1 = by shard size), "respond.planar_blocks_per_cu" 0..8, "respond.multi_pass_limit_mb"
- *   (unfused batches on databases above this size get one launch per query), "respond.ks_major" 0..3 (which launches of the
- *   matrix-core respond take the step-major kernel: 0 none, 1 -- the default -- single-pass launches, fused batches and queries
- *   beyond 8 MiB, 2 every launch it applies to, 3 as 2 but failing where it does not apply), "respond.wide_min_batch" (fused batches
- *   of at least this many queries are cut into passes of up to 24 queries that share ONE stream of the database -- the wide pass, one
- *   8-wave block per CU; default 5, i.e. every pass beyond one row set of 4 queries; 0: never -- passes of 12 / 8 as in round 3),
+ *   (unfused batches on databases above this size get one launch per query; VALU packings), "respond.ks_major" 1..3 (planar packing,
+ *   device-resident queries: 1 -- the default -- every launch runs on the wide kernel (1 .. 24 queries per pass, one 8-wave block per CU,
+ *   passes in slice or interleaved order) and the step-major kernel serves the in-place host path only; 2 the step-major kernel wherever
+ *   it applies, i.e. passes of up to 4 queries in slice order -- tests and A/B runs; 3 as 2, launched as the in-place host path launches it),
  *   "respond.host_zero_copy" {0,1}
  *   (1, the default: cpir_server_respond serves a caller that finds the server idle without an upload, the kernel reading the
  *   query in place from page-locked host memory; 0: always stage + upload first), "respond.host_fill_timeout_us" 0..1000000
@@ -265,14 +264,14 @@ int cpir_op_synth_fill(cpir_device* dev, uint32_t* out, uint64_t count, uint64_t
  *   for the words of a step -- default 2000, raised to what copying the whole query takes at 5 GB/s; 0: two launches, each when its half of the query is in place), "matmul.mfma" {0,1} (1, the default:
  *   cpir_op_mat_x_mat and the setup paths run right-hand sides below 2^16 on the i8 matrix cores; 0: on the integer VALU),
  *   "matmul.pipeline" {0,1} (1, the default: the software-pipelined matrix-core kernel; 0: its first cut),
- *   "matmul.ablate" (diagnosis only, results are WRONG while it is non-zero: bit mask of parts of the matrix-core matmul to skip),
  *   "pack.rows" {-1,0,1} (the planar pack pass: 1 = a block streams whole rows of D, 0 = 64-column waves, -1 -- the default -- by width),
  *   "layout.dense" {0,1} and "layout.planar" {0,1}
  *   (default packing chosen by cpir_dtc_layout_for and therefore by every cpir_server_* constructor: planar where it is
  *   offered and enabled, else dense64 where offered and enabled, else the reference packing),
  *   "layout.compact_slots" {0,1,2} (whether a constructor leaves the rows of D without a non-zero field out of the resident image:
  *   0 never, 1 -- the default -- where they are at least 1/32 of the rows, 2 whenever there is one; see cpir_server_slots_served).
- * Process-wide; results are bit-identical for every setting. */
+ * Process-wide; results are bit-identical for every setting: the library has no key and reads no environment variable that makes it skip
+ * work or answer wrongly (the ablation switches of the tuning scripts exist only in a -DCPIR_DIAG build, `make diag`). */
 int cpir_tuning_set(const char* key, int value);
 /* Every key back to its default (what a test harness calls between tests: the knobs are process-wide state). */
 void cpir_tuning_reset(void);
@@ -281,8 +280,8 @@ const char* cpir_respond_kernel_name(const cpir_dtc_layout* layout);
 /* Name of the kernel cpir_op_transpose_compress runs for this layout (under the current "pack.rows" setting), as a kernel trace shows it. */
 const char* cpir_pack_kernel_name(const cpir_dtc_layout* layout);
 /* Queries per pass a FUSED batch of `batch` queries is cut into on this layout under the current tuning (the queries of a pass share one
- * stream of the database): planar 24 at most -- as few passes as that allows, all of about the same width -- where the wide pass takes the
- * batch ("respond.wide_min_batch"), else 12 or 8; other packings 4 (then 2, then 1).  0 for a NULL layout or an empty batch. */
+ * stream of the database): planar 24 at most -- as few passes as that allows, all of about the same width (4 where "respond.ks_major"
+ * sends fused passes to the step-major kernel); other packings 4 (then 2, then 1).  0 for a NULL layout or an empty batch. */
 uint32_t cpir_respond_batch_pass_width(const cpir_dtc_layout* layout, uint32_t batch);
 
 /* ------------------------------------------------------------------------------------------------

@@ -10,6 +10,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
+if os.environ.get("CPIR_MM_ABLATE"):  # the ablation switch exists only in the diagnosis build of the library (`make diag`)
+    from chalametpir_amd import _native  # noqa: E402
+
+    _native.use_diag_build()
 import chalametpir_amd as cp  # noqa: E402
 from bench import CONFIGS  # noqa: E402
 
@@ -46,10 +50,10 @@ def timed(fn):
 
 
 mm = timed(lambda: dev.mat_x_mat(A, D, M, R, N, C, rhs_max_bits=16, stream=stream))
-for bits in [int(x) for x in os.environ.get("CPIR_MM_ABLATE", "").split(",") if x]:
+for bits in [int(x) for x in os.environ.get("CPIR_MM_ABLATE", "").split(",") if x]:  # (the diagnosis build only: see the imports)
     cp.tuning_set("matmul.ablate", bits)
     t = timed(lambda: dev.mat_x_mat(A, D, M, R, N, C, rhs_max_bits=16, stream=stream))
     print(f"  ablate {bits:2d} (1 no MFMA, 2 no A conversion, 4 no A loads, 8 no D DMA): {t:.3f} ms", flush=True)
-cp.tuning_set("matmul.ablate", 0)
+    cp.tuning_set("matmul.ablate", 0)
 pk = timed(lambda: dev.transpose_compress(D, L, dtc, stream=stream))
 print(f"{cfg}: N={N} C={C} b={b}  {cp.mat_x_mat_kernel_name(16)}: {mm:.3f} ms = {R * N * C / mm / 1e9:.1f} TMAC/s;  pack: {pk:.3f} ms", flush=True)

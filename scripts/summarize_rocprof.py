@@ -34,8 +34,8 @@ def counters(root):
 
 
 def is_respond(name):
-    """the dominant online kernel: respond_kernel<...> (VALU path) or respond_planar_kernel<...> (matrix-core path)"""
-    return "respond_kernel" in name or "respond_planar_kernel" in name
+    """the dominant online kernel: respond_kernel<...> (VALU path) or respond_planar_wide_kernel<...> (matrix-core path)"""
+    return "respond_kernel" in name or "respond_planar_wide_kernel" in name
 
 
 def traffic_record(root, summary, tag, git_head=""):

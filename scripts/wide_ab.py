@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Fused batches at a BASELINE shape: passes of 12 through the step-major kernel (respond.wide_min_batch = 0) against the wide pass (up to
+"""Fused batches at a BASELINE shape: passes of 4 through the step-major kernel (respond.ks_major = 2) against the wide kernel (up to
 24 queries per stream of the database), microseconds per query from events, responses compared with each other.
    python scripts/wide_ab.py [N C b [HOLES]]   (default: 2^20 keys x 1 kB = 1179648 x 940, b = 9; HOLES: fraction of the rows set to zero --
                                                 a real encoded database has 0.111 -- which the server then leaves out of its image)"""
@@ -30,7 +30,7 @@ q = torch.empty((NQ, N), dtype=torch.int32, device="cuda")
 for i in range(NQ):
     dev.synth_fill(q, N, 0x1000 + i, offset_words=i * N, stream=stream)
 ref = torch.empty((NQ, C), dtype=torch.int32, device="cuda")
-cp.tuning_set("respond.wide_min_batch", 0)
+cp.tuning_set("respond.ks_major", 2)
 srv.respond_batch_device(q, NQ, ref, stream=stream)
 torch.cuda.synchronize()
 
@@ -53,11 +53,9 @@ def timed(k, reps):
 reps = max(3, int(20 * 1.2e9 / (N * C * b / 8)))
 for k in (1, 2, 4, 5, 6, 8, 12, 13, 16, 20, 24, 32, 48, 72, 96):
     row = [f"batch {k:3d}:"]
-    for wide_min in (0, 13, 1):
-        if wide_min == 1 and k > 24:
-            continue
-        cp.tuning_set("respond.wide_min_batch", wide_min)
+    for ks_major in (2, 1):
+        cp.tuning_set("respond.ks_major", ks_major)
         us, same = timed(k, reps)
-        row.append(f"wide_min={wide_min}: {us:8.1f} us = {us / k:6.2f} us/query{'' if same else '  RESPONSES DIFFER'}")
+        row.append(f"{'step-major' if ks_major == 2 else 'wide'}: {us:8.1f} us = {us / k:6.2f} us/query{'' if same else '  RESPONSES DIFFER'}")
     print("   ".join(row), flush=True)
-cp.tuning_set("respond.wide_min_batch", 5)
+cp.tuning_set("respond.ks_major", 1)

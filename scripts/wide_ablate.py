@@ -11,6 +11,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, ROOT)
     import torch
 
+    from chalametpir_amd import _native
+
+    _native.use_diag_build()  # CPIR_WIDE_ABLATE exists only in the diagnosis build of the library (`make diag`)
     import chalametpir_amd as cp
 
     N, C, b = 1179648, 940, 9

@@ -213,13 +213,14 @@ def test_every_documented_tuning_key_is_accepted_and_bounded():
     doc = header[header.index("Tuning knobs of the respond kernel"):header.index("int cpir_tuning_set")]
     documented = set(re.findall(r'"((?:respond|matmul|layout|pack)\.[a-z_]+)"', doc))
     source = open(os.path.join(ROOT, "chalametpir_amd", "csrc", "respond.hip")).read()
+    source = re.sub(r"#ifdef CPIR_DIAG.*?#endif", "", source, flags=re.S)  # (the diagnosis build's own key is not in the release library)
     accepted = set(re.findall(r'!strcmp\(key, "([a-z_.]+)"\)', source))
     assert accepted == documented, (sorted(accepted - documented), sorted(documented - accepted))
     defaults = {"respond.ks_major": 1, "respond.host_zero_copy": 1, "respond.host_fill_timeout_us": 2000, "respond.batch_fusion": 1,
                 "respond.interleave_passes": -1, "matmul.mfma": 1}
     for key, value in defaults.items():
         cp.tuning_set(key, value)
-    for key, bad in (("respond.ks_major", 4), ("respond.ks_major", -1), ("respond.host_fill_timeout_us", -5),
+    for key, bad in (("respond.ks_major", 4), ("respond.ks_major", 0), ("respond.host_fill_timeout_us", -5),
                      ("respond.host_fill_timeout_us", 2_000_000), ("respond.no_such_key", 1)):
         with pytest.raises(ChalametPIRError):
             cp.tuning_set(key, bad)
@@ -265,8 +266,8 @@ def test_host_gather_variants_agree(native):
 
 def test_how_a_fused_batch_is_cut_into_passes():
     """cpir_respond_batch_pass_width (host-side arithmetic, no GPU): on the planar packing as few passes as 24 queries each allow, all of
-    about the same width; with the wide pass switched off passes of 12 (8 where interleaved tile-major passes take the launch); never
-    more than the batch; other packings 4; every cut covers the batch with passes of at most that width plus a remainder below it"""
+    about the same width; passes of 4 where respond.ks_major sends fused passes to the step-major kernel; never more than the batch; other
+    packings 4; every cut covers the batch with passes of at most that width plus a remainder below it"""
     import chalametpir_amd as cp
 
     try:
@@ -276,15 +277,43 @@ def test_how_a_fused_batch_is_cut_into_passes():
         assert widths == {1: 1, 4: 4, 5: 5, 12: 12, 13: 13, 24: 24, 25: 13, 32: 16, 47: 24, 48: 24, 49: 17, 72: 24, 96: 24, 100: 20, 241: 22, 1009: 24}
         for k, w in widths.items():
             assert 1 <= w <= min(k, 24) and (k // w) * w + (k % w) == k and -(-k // w) <= -(-k // 24) + 1
-        cp.tuning_set("respond.wide_min_batch", 0)
-        assert [cp.respond_batch_pass_width(planar, k) for k in (5, 12, 13, 48)] == [5, 12, 12, 12]
-        small = cp.dtc_layout_for(147456, 940, 9)  # a 1/8 shard: many passes go interleaved through the tile-major kernel, 8 a pass
-        assert cp.respond_batch_pass_width(small, 48) == 8 and cp.respond_batch_pass_width(small, 12) == 12
-        cp.tuning_set("respond.wide_min_batch", 5)
-        assert cp.respond_batch_pass_width(small, 48) == 24
+        small = cp.dtc_layout_for(147456, 940, 9)  # a 1/8 shard: the same cut (the wide kernel takes interleaved launches too)
+        assert cp.respond_batch_pass_width(small, 48) == 24 and cp.respond_batch_pass_width(small, 12) == 12
+        cp.tuning_set("respond.ks_major", 2)
+        assert [cp.respond_batch_pass_width(planar, k) for k in (1, 3, 4, 5, 12, 48)] == [1, 3, 4, 4, 4, 4]
+        cp.tuning_set("respond.ks_major", 1)
         cp.tuning_set("layout.planar", 0)
         other = cp.dtc_layout_for(1179648, 940, 9)
         assert int(other.packing) != 2 and cp.respond_batch_pass_width(other, 48) == 4 and cp.respond_batch_pass_width(other, 3) == 2
         assert cp.respond_batch_pass_width(planar, 0) == 0
     finally:
         cp.tuning_reset()
+
+
+def test_release_library_has_no_wrong_answer_switches(native):
+    """Server::respond has no mode in which it lies (server.rs:184-190): the ablation switches and the timing traces of the tuning scripts
+    are compiled only into the diagnosis build (-DCPIR_DIAG, `make diag`).  The release library neither contains the names of the
+    environment variables nor accepts the tuning key, and its only getenv()s are the documented, result-neutral ones."""
+    import re
+    import subprocess
+
+    import chalametpir_amd as cp
+    from chalametpir_amd import _native
+    from chalametpir_amd.errors import ChalametPIRError
+
+    text = subprocess.run(["strings", "-a", _native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    for name in ("CPIR_WIDE_ABLATE", "CPIR_KS_TRACE", "matmul.ablate", "[ks trace]", "[wide trace]"):
+        assert name not in text, name
+    for key in ("matmul.ablate", "respond.ablate", "respond.wide_ablate"):
+        with pytest.raises(ChalametPIRError):
+            cp.tuning_set(key, 1)
+    # every environment variable the release sources read is on this list, and none of them changes a result
+    allowed = {"CPIR_ABORT_BACKTRACE", "CPIR_RESPOND_TRACE", "CPIR_GATHER", "CPIR_XOF_SCALAR"}
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "chalametpir_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith((".hip", ".cpp", ".hpp")):
+            continue
+        src = open(os.path.join(csrc, name)).read()
+        src = re.sub(r"#ifdef CPIR_DIAG.*?#endif", "", src, flags=re.S)  # (the diagnosis build's own)
+        for var in re.findall(r'getenv\("([A-Z_0-9]+)"\)', src):
+            assert var in allowed, (name, var)

@@ -238,7 +238,7 @@ def test_batches_equal_single_responds(cfg, device):
     import chalametpir_amd as cp
 
     f = cfg
-    batch = 11  # ONE pass on three A row sets when fused (in column windows at these widths); 11 independent passes in one launch when not
+    batch = 11  # ONE pass of the wide kernel (three of its row sets) when fused; 11 independent passes in one launch when not
     Q = torch.empty((batch, f.N), dtype=torch.int32, device="cuda")
     for i in range(batch):
         device.synth_fill(Q, f.N, 0x5000 + i, offset_words=i * f.N, stream=f.stream)
@@ -256,9 +256,9 @@ def test_batches_equal_single_responds(cfg, device):
 
 
 def test_step_major_kernel_everywhere_equals_the_default(cfg, device):
-    """respond.ks_major=2: the step-major kernel (correction terms folded in, every query word read once) answers the single queries
-    too; 0: the tile-major kernel answers everything; 3: the step-major kernel in the strided step order of the in-place host path.
-    Same responses as the default split between the kernels."""
+    """respond.ks_major=2: the step-major kernel (every query word read once; the lone host caller's kernel) answers the device-resident
+    queries too, fused batches in passes of 4; 3: the same in the strided step order of the in-place host path.  Same responses as the wide
+    kernel, which takes every device launch by default."""
     import torch
 
     import chalametpir_amd as cp
@@ -271,15 +271,12 @@ def test_step_major_kernel_everywhere_equals_the_default(cfg, device):
     want = np.stack([respond(f, f.srv, Q[i]) for i in range(batch)])
     assert np.array_equal(want[1], exact_sums(f, Q[1]))
     try:
-        for mode in (2, 0, 3):
+        for mode in (2, 3):
             cp.tuning_set("respond.ks_major", mode)
             got = np.stack([respond(f, f.srv, Q[i]) for i in range(batch)])
             assert np.array_equal(got, want), mode
-            if mode == 3:
-                # 3 = as the in-place host path launches it: whole steps round-robin over the blocks (the left-over steps split by
-                # units), fragments built a visit ahead; it refuses launches it does not apply to, e.g. a fused pass whose responses
-                # exceed the LDS accumulators, so single queries only
-                continue
+            # (3 = as the in-place host path launches it: whole steps round-robin over the blocks, the left-over steps split by units,
+            # fragments built a visit ahead; a pass whose responses exceed its LDS accumulators goes to the wide kernel)
             R = torch.full((batch, f.C), -1, dtype=torch.int32, device="cuda")
             f.srv.respond_batch_device(Q, batch, R, stream=f.stream)
             torch.cuda.synchronize()

@@ -115,10 +115,11 @@ def test_bench_json_contract():
     roof = d["roofline"]
     assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s") and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and "traffic" in roof
-    # HBM traffic per launch is MEASURED in the run (two child runs of the timed loop under rocprofv3 --pmc): for this Infinity-Cache-sized
-    # database anything between a fraction of the layout bytes (on-die hits) and a little above them
+    # HBM traffic per launch is MEASURED in the run (two child runs of the timed loop under rocprofv3 --pmc): this Infinity-Cache-sized
+    # database is walked in the interleaved order (its 32 passes share one stream of it on die), so anything between 1/32 of the layout
+    # bytes plus the queries and a little above all of them
     assert isinstance(roof["traffic"], int) and roof["traffic"] > 0 and "measured in this run" in roof["traffic_source"]
-    assert 0.05 < roof["traffic_over_moved_bytes"] < 1.2
+    assert 0.01 < roof["traffic_over_moved_bytes"] < 1.2 and roof["pass_order"] == "interleaved"
     # the bytes really moved (the resident layout is tighter than the reference packing), against spec and against a live read-only probe
     assert abs(roof["frac_moved"] - roof["moved_GBps"] / roof["peak"]) < 1e-3 and roof["frac_moved"] <= roof["frac"] + 1e-3
     assert roof["read_ceiling_GBps"] > 1000 and abs(roof["frac_vs_read_ceiling"] - roof["moved_GBps"] / roof["read_ceiling_GBps"]) < 1e-3

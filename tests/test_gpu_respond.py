@@ -276,9 +276,8 @@ def test_unaligned_queries_odd_shard_offsets_and_every_batch_size(orc, device):
         dtc_shard = orc.row_wise_compress(orc.transpose(D[lo:hi]), b)
         want_part = orc.row_vector_x_compressed_transposed_matrix(Q[0][lo:hi], dtc_shard, hi - lo, b)[0]
         try:
-            # respond.ks_major: 0 = tile-major kernel + init kernel, 1 = step-major kernel for the fused passes, 2 = step-major kernel
-            # (which adds the correction terms itself) for every pass
-            for ks_major in (1, 2, 0):
+            # respond.ks_major: 1 = the wide kernel for every launch, 2 = the step-major kernel wherever it applies (passes of up to 4)
+            for ks_major in (1, 2):
                 cp.tuning_set("respond.ks_major", ks_major)
                 # one query, buffer shifted by one element: 4-byte but not 16-byte aligned
                 buf = torch.zeros(N + 8, dtype=torch.int32, device="cuda")
@@ -424,7 +423,7 @@ def test_lone_pageable_query_polled_launch_and_its_fallbacks(orc, device):
 
 def test_random_shapes_every_kernel_order(orc, device):
     """seeded random shapes (slots, columns, bit length, shard window, query alignment) through every dispatch of the matrix-core
-    respond: tile-major (0), the default split (1), step-major everywhere (2) and step-major in the strided step order of the in-place
+    respond: the wide kernel (1, the default), the step-major kernel (2) and the step-major kernel in the strided step order of the in-place
     host path (3) -- block counts above and below the number of steps, ragged last steps, shards that start at odd slots -- against
     the oracle; the host entry point on top (lone caller: query read in place / staged)."""
     import torch
@@ -456,7 +455,7 @@ def test_random_shapes_every_kernel_order(orc, device):
             buf = torch.zeros(N + 8, dtype=torch.int32, device="cuda")
             buf[shift:shift + N] = torch.from_numpy(q.view(np.int32)).cuda()
             planar = srv.layout.packing == 2
-            for mode in (0, 1, 2, 3):
+            for mode in (1, 2, 3):
                 if mode == 3 and not planar:
                     continue
                 cp.tuning_set("respond.ks_major", mode)
@@ -472,10 +471,9 @@ def test_random_shapes_every_kernel_order(orc, device):
 
 
 def test_wide_database_fused_batches_go_window_by_window(orc, device):
-    """more columns than the step-major kernel's LDS accumulators hold for a fused batch (8 queries: 1 536 columns; 12 queries: 640): the
-    launch is repeated over column windows; every batch size around the window arithmetic (1 window for 1..3 queries per pass at this
-    width, 2 for 4..8, more for the 9..12 of three row sets) gives the same responses as single responds, tile-major and step-major
-    dispatch alike"""
+    """more columns than the kernels' LDS accumulators hold for a fused pass (step-major kernel, 4 queries: 3 072 columns; wide kernel, 19
+    queries: about 1 700): the launch is repeated over column windows; every batch size around the window arithmetic gives the same
+    responses as single responds, wide and step-major dispatch alike"""
     import torch
 
     import chalametpir_amd as cp
@@ -490,7 +488,7 @@ def test_wide_database_fused_batches_go_window_by_window(orc, device):
         Q = np.stack([random_query(rng, N) for _ in range(nq)])
         want = np.stack([orc.row_vector_x_compressed_transposed_matrix(Q[i], dtc, N, b)[0] for i in range(nq)])
         Q_dev = torch.from_numpy(Q.view(np.int32)).cuda()
-        for ks_major in (1, 2, 0):
+        for ks_major in (1, 2):
             cp.tuning_set("respond.ks_major", ks_major)
             for k in (1, 2, 3, 4, 5, 8, 9, 12, 13, 16, 19):  # (9..12: one pass on three row sets; 13+: a pass of 12 and the rest)
                 R = torch.full((k, C), -1, dtype=torch.int32, device="cuda")
@@ -505,7 +503,7 @@ def test_wide_database_fused_batches_go_window_by_window(orc, device):
 def test_more_columns_than_one_query_fits_in_the_accumulators(orc, device):
     """beyond 12 288 columns even ONE query's responses exceed the step-major kernel's 48 KiB of LDS accumulators: a lone device launch goes
     over two column windows, the host entry point stages the query instead of reading it in place (a query behind the host link must be
-    read once), and everything agrees with the tile-major kernel and the oracle"""
+    read once), and everything agrees with the wide kernel and the oracle"""
     import torch
 
     import chalametpir_amd as cp
@@ -519,7 +517,7 @@ def test_more_columns_than_one_query_fits_in_the_accumulators(orc, device):
     Q = np.stack([random_query(rng, N) for _ in range(3)])
     want = np.stack([orc.row_vector_x_compressed_transposed_matrix(Q[i], dtc, N, b)[0] for i in range(3)])
     Q_dev = torch.from_numpy(Q.view(np.int32)).cuda()
-    for ks_major in (1, 2, 0):
+    for ks_major in (1, 2):
         cp.tuning_set("respond.ks_major", ks_major)
         r = torch.full((C,), -1, dtype=torch.int32, device="cuda")
         srv.respond_device(Q_dev[0], r, stream=stream)

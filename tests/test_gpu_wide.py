@@ -18,10 +18,10 @@ def _responses(orc, Q, dtc, N, b):
 
 @pytest.mark.parametrize("b", [4, 8, 9, 10, 11, 12, 13, 14])
 def test_every_batch_size_through_the_wide_pass(b, orc, device):
-    """respond.wide_min_batch = 1 sends EVERY fused pass through the wide kernel (1 .. 24 queries: one to six row sets, the last one
-    partly filled), 5 (the default) every pass beyond one row set, 13 only what the step-major kernel's three row sets cannot take, 0
-    nothing (passes of 12 on the step-major kernel's two and three row sets); every plane count (b = 4 .. 14); N ragged (the last step is
-    guarded), more than one visit per block"""
+    """every fused batch runs on the wide kernel (1 .. 24 queries per pass: one to six row sets, the last one partly filled; larger
+    batches in as few passes as 24 each allow), and so does every unfused one (passes of ONE query, in slice and in interleaved order);
+    respond.ks_major = 2 answers the same batches in passes of 4 on the step-major kernel; every plane count (b = 4 .. 14); N ragged (the
+    last step is guarded), more than one visit per block"""
     import torch
 
     import chalametpir_amd as cp
@@ -37,21 +37,60 @@ def test_every_batch_size_through_the_wide_pass(b, orc, device):
     want = _responses(orc, Q, dtc, N, b)
     Q_dev = torch.from_numpy(Q.view(np.int32)).cuda()
     try:
-        for wide_min in (1, 5, 13, 0):
-            cp.tuning_set("respond.wide_min_batch", wide_min)
-            for k in (list(range(1, 27)) + [31, 32, 33, 47, 48, 49, 50] if wide_min in (1, 5) else [4, 5, 7, 8, 9, 11, 12, 13, 24, 25, 37]):
+        for ks_major, fusion, order in ((1, 1, -1), (1, 0, 0), (1, 0, 1), (1, 1, 1), (2, 1, -1), (2, 0, 0)):
+            cp.tuning_set("respond.ks_major", ks_major)
+            cp.tuning_set("respond.batch_fusion", fusion)
+            cp.tuning_set("respond.interleave_passes", order)
+            for k in (list(range(1, 27)) + [31, 32, 33, 47, 48, 49, 50] if (ks_major, fusion) == (1, 1) else [1, 2, 3, 4, 5, 7, 8, 9, 12, 13, 24, 25, 37, 50]):
                 R = torch.full((k, C), -1, dtype=torch.int32, device="cuda")
                 srv.respond_batch_device(Q_dev, k, R, stream=stream)
                 torch.cuda.synchronize()
-                assert np.array_equal(R.cpu().numpy().view(np.uint32), want[:k]), (b, wide_min, k)
-        # switched off: the same answers from passes of 12
-        cp.tuning_set("respond.wide_min_batch", 0)
-        R = torch.full((nq, C), -1, dtype=torch.int32, device="cuda")
-        srv.respond_batch_device(Q_dev, nq, R, stream=stream)
-        torch.cuda.synchronize()
-        assert np.array_equal(R.cpu().numpy().view(np.uint32), want)
+                assert np.array_equal(R.cpu().numpy().view(np.uint32), want[:k]), (b, ks_major, fusion, order, k)
     finally:
-        cp.tuning_set("respond.wide_min_batch", 5)
+        cp.tuning_reset()
+        srv.close()
+
+
+@pytest.mark.parametrize("b,steps,C,passes", [(9, 1, 17, 7), (9, 9, 130, 3), (10, 40, 300, 70), (8, 700, 64, 33), (12, 23, 129, 257), (9, 300, 940, 32)])
+def test_passes_in_interleaved_order_share_out_the_pass_unit_space(b, steps, C, passes, orc, device):
+    """the interleaved order of a launch of many passes (what every multi-GPU shard runs): the (pass, unit) space is split evenly over the
+    blocks, so a block may hold the tail of one pass, whole passes and the head of another -- fewer units than blocks, more passes than
+    blocks per XCD, one step only, ragged last steps; every query's response equals the oracle's, and the slice order's"""
+    import torch
+
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(7000 + steps)
+    stream = torch.cuda.current_stream()
+    N = steps * 512 - int(rng.integers(0, 500))
+    D = random_db_matrix(rng, N, C, b)
+    dtc = orc.row_wise_compress(orc.transpose(D), b)
+    srv = cp.Server.from_compressed(dtc, N, b, device=device)
+    distinct = min(passes, 12)  # (the oracle answers a dozen distinct queries; the launch repeats them)
+    Q = np.stack([random_query(rng, N) for _ in range(distinct)])
+    want = _responses(orc, Q, dtc, N, b)
+    pick = np.arange(passes) % distinct
+    Q_dev = torch.from_numpy(Q[pick].view(np.int32)).cuda()
+    try:
+        cp.tuning_set("respond.batch_fusion", 0)
+        got = {}
+        for order in (1, 0):
+            cp.tuning_set("respond.interleave_passes", order)
+            R = torch.full((passes, C), -1, dtype=torch.int32, device="cuda")
+            srv.respond_batch_device(Q_dev, passes, R, stream=stream)
+            torch.cuda.synchronize()
+            got[order] = R.cpu().numpy().view(np.uint32)
+            assert np.array_equal(got[order], want[pick]), (b, steps, C, passes, order)
+        # fused passes of several queries each, interleaved: 3 passes of W queries
+        cp.tuning_set("respond.batch_fusion", 1)
+        cp.tuning_set("respond.interleave_passes", 1)
+        k = min(passes, 60)
+        R = torch.full((k, C), -1, dtype=torch.int32, device="cuda")
+        srv.respond_batch_device(Q_dev, k, R, stream=stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(R.cpu().numpy().view(np.uint32), want[pick[:k]]), (b, steps, C, passes, "fused")
+    finally:
+        cp.tuning_reset()
         srv.close()
 
 
