@@ -525,21 +525,33 @@ respond_planar_wide_kernel(const PlanarArgs a) {
   }
   if (r1 <= r0) return;  // block-uniform: an idle block takes part in nothing
   CPIR_DIAG_ONLY(if (a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 4 + 0] = wall_clock64(), a.trace[blockIdx.x * 4 + 3] = (uint32_t)(r1 - r0);)
-  // the visits of pass p for this block, as plain scalars (block-uniform; 64-bit divisions once per pass, not per unit)
-  uint32_t c_nv, c_ks0, c_tg0, c_tg1;  // current pass: number of visits, step of visit 0, first tile group of visit 0, end of the last visit
-  uint32_t n_nv, n_ks0, n_tg0, n_tg1;  // the pass after it (what the last visit of a pass prefetches and builds for)
-  auto pass_visits = [&](uint32_t p, uint32_t& nv_, uint32_t& ks0_, uint32_t& tg0_, uint32_t& tg1_) __attribute__((always_inline)) {
-    uint64_t s0 = r0, s1 = r1;
-    if (a.interleave) {
-      s0 = p == p_first ? r0 - (uint64_t)p_first * units : 0;
-      s1 = p == p_last ? r1 - (uint64_t)p_last * units : units;
-    }
+  // The visits of a pass for this block, as plain block-uniform scalars.  There are only three kinds of pass: the block's first (in the
+  // interleaved order possibly only its tail), a whole one, the block's last (possibly only its head) -- computed HERE, once: a 64-bit
+  // division inside the loop costs nine vector registers at its most crowded point.  In slice order all three are the same.
+  uint32_t f_nv, f_ks0, f_tg0, f_tg1;  // number of visits, step of visit 0, first tile group of visit 0, end of the last visit
+  uint32_t m_nv, m_ks0, m_tg0, m_tg1;
+  uint32_t l_nv, l_ks0, l_tg0, l_tg1;
+  auto visits_of = [&](uint64_t s0, uint64_t s1, uint32_t& nv_, uint32_t& ks0_, uint32_t& tg0_, uint32_t& tg1_) __attribute__((always_inline)) {
     nv_ = (uint32_t)((s1 - 1) / TG - s0 / TG + 1);
     ks0_ = kb0 + (uint32_t)(s0 / TG), tg0_ = (uint32_t)(s0 % TG), tg1_ = (uint32_t)((s1 - 1) % TG) + 1;
   };
-  pass_visits(p_first, c_nv, c_ks0, c_tg0, c_tg1);
+  if (a.interleave) {
+    const uint64_t first0 = r0 - (uint64_t)p_first * units, last1 = r1 - (uint64_t)p_last * units;
+    visits_of(first0, p_first == p_last ? last1 : units, f_nv, f_ks0, f_tg0, f_tg1);
+    visits_of(0, units, m_nv, m_ks0, m_tg0, m_tg1);
+    visits_of(0, last1, l_nv, l_ks0, l_tg0, l_tg1);
+  } else {
+    visits_of(r0, r1, f_nv, f_ks0, f_tg0, f_tg1);
+    m_nv = l_nv = f_nv, m_ks0 = l_ks0 = f_ks0, m_tg0 = l_tg0 = f_tg0, m_tg1 = l_tg1 = f_tg1;
+  }
+  uint32_t c_nv = f_nv, c_ks0 = f_ks0, c_tg0 = f_tg0, c_tg1 = f_tg1;  // the current pass
+  uint32_t n_nv, n_ks0, n_tg0, n_tg1;                                  // the pass after it (what the last visit of a pass prefetches and builds for)
+  auto pass_after = [&](uint32_t p) __attribute__((always_inline)) {   // p + 1 <= p_last
+    const bool is_last = p + 1 == p_last;
+    n_nv = is_last ? l_nv : m_nv, n_ks0 = is_last ? l_ks0 : m_ks0, n_tg0 = is_last ? l_tg0 : m_tg0, n_tg1 = is_last ? l_tg1 : m_tg1;
+  };
   n_nv = c_nv, n_ks0 = c_ks0, n_tg0 = c_tg0, n_tg1 = c_tg1;
-  if (a.interleave && p_first < p_last) pass_visits(p_first + 1, n_nv, n_ks0, n_tg0, n_tg1);
+  if (p_first < p_last) pass_after(p_first);
 
   const uint32_t limb = cl & 3;
   const uint32_t sel01 = limb | ((4 + limb) << 8);
@@ -557,13 +569,16 @@ respond_planar_wide_kernel(const PlanarArgs a) {
     if (mapped) return slot0 + CPIR_PLANAR_SLOTS_PER_TILE > a.num_slots;  // (word loads: no alignment to ask for)
     return a.q_scalar || slot0 + CPIR_PLANAR_SLOTS_PER_TILE > a.num_slots || a.q_slot_offset + slot0 + CPIR_PLANAR_SLOTS_PER_TILE > a.q_len;
   };
+  // (a row set's base address is uniform -- scalar registers --, the lane adds ITS row of the set and its 16-byte piece: one 64-bit
+  // offset per lane, computed once)
+  const uint64_t q_lane_off = (uint64_t)rr * a.q_len + (uint32_t)(wave * 64 + l16 * 4);
   auto a_issue = [&](uint4(&raw)[kWMaxSets], uint32_t ks_, uint32_t pass_) __attribute__((always_inline)) {
-    const uint64_t base = (uint64_t)ks_ * CPIR_PLANAR_SLOTS_PER_TILE + wave * 64 + l16 * 4;
+    const uint32_t* const bs0 = a.q + (uint64_t)pass_ * nq * a.q_len + a.q_slot_offset + (uint64_t)ks_ * CPIR_PLANAR_SLOTS_PER_TILE;
 #pragma unroll
     for (int s = 0; s < kWMaxSets; s++) {
       raw[s] = make_uint4(0, 0, 0, 0);
       const uint32_t row = 4 * s + rr;
-      if (row < nq) raw[s] = *reinterpret_cast<const uint4*>(a.q + ((uint64_t)pass_ * nq + row) * a.q_len + a.q_slot_offset + base);
+      if (row < nq) raw[s] = *reinterpret_cast<const uint4*>(bs0 + (uint64_t)(4 * s) * a.q_len + q_lane_off);
     }
   };
   auto idx_issue = [&](uint32_t ks_) __attribute__((always_inline)) {
@@ -799,7 +814,7 @@ respond_planar_wide_kernel(const PlanarArgs a) {
           flush_pass(pass, true);  // (nobody accumulates for the next pass before the barrier below)
           pass = npass;
           c_nv = n_nv, c_ks0 = n_ks0, c_tg0 = n_tg0, c_tg1 = n_tg1;
-          if (a.interleave && pass < p_last) pass_visits(pass + 1, n_nv, n_ks0, n_tg0, n_tg1);  // (slice order: every pass walks the same visits)
+          if (pass < p_last) pass_after(pass);
         }
         CPIR_DIAG_ONLY(if (!(a.ablate & 1u))) {
           if (!g_n) a_finish(raw, par ^ 1);
