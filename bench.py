@@ -108,6 +108,9 @@ def main() -> int:
     ap.add_argument("--no-multirank-check", action="store_true",
                     help="N > 1: skip the default-on bit-exactness check behind the timed region (unit / dense / all-ones queries against the "
                          "counter-based generator and exact 64-bit sums; size-independent, runs at every config)")
+    ap.add_argument("--no-like-for-like", action="store_true",
+                    help="N > 1: skip the second timed loop in slice order (`value_slice_order`) and rank 0's single-GPU run of the whole database "
+                         "(`single_gpu_reference`) that make `scaling_like_for_like` -- the scaling figure free of on-die reuse")
     ap.add_argument("--verify", action="store_true",
                     help="rank 0 re-derives the step's responses with the CPU oracle from the full synthetic DB (small configs only)")
     args = ap.parse_args()
@@ -235,29 +238,35 @@ def main() -> int:
     if args.sweep and rank == 0:
         sweep(cp, torch, run_step, qps_step)
 
-    for _ in range(args.warmup):
-        run_step()
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # HIP events on the stream the respond kernels are launched on, bracketing the kernel launches of every timed step
-    step_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t_begin = time.perf_counter()
-    for k in range(args.steps):
-        run_step(step_events[k])
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t_begin
-    kernel_region_ms = sum(a.elapsed_time(b) for a, b in step_events)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_region(warmup, steps):
+        """W untimed warm-up steps, then exactly K steps bracketed by a barrier + device synchronise on both sides; returns the wall time
+        (MAX over ranks) and the summed HIP-event time of the respond launches on their stream"""
+        for _ in range(warmup):
+            run_step()
+        drain()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        # HIP events on the stream the respond kernels are launched on, bracketing the kernel launches of every timed step
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t_begin = time.perf_counter()
+        for k in range(steps):
+            run_step(events[k])
+        drain()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t_begin
+        region_ms = sum(a.elapsed_time(b) for a, b in events)
+        if world > 1:
+            t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())
+        return wall, region_ms
+
+    elapsed, kernel_region_ms = timed_region(args.warmup, args.steps)
 
     n_queries = args.steps * qps_step
     qps = n_queries / elapsed
@@ -332,6 +341,31 @@ def main() -> int:
         },
         "pack_seconds": round(pack_seconds, 3),
     }
+    # LIKE FOR LIKE (N > 1, and the one-shard tuning runs): a shard below ~1 GB runs its passes in the interleaved order -- concurrent passes
+    # share database bytes on die --, the N = 1 headline streams the database from HBM for every query.  `value` is what the product
+    # dispatches; `value_slice_order` is the same shards, the same steps, every pass its own stream (slice order, `nt` loads), i.e. the
+    # figure that may be divided by the N = 1 headline: `scaling_like_for_like` (filled in below, against rank 0's own single-GPU run of
+    # the whole database in this very process).
+    if (world > 1 or args.shard_of > 1) and not args.no_like_for_like:
+        roof0 = result["roofline"]
+        if roof0["pass_order"] == "interleaved":
+            user_order = next((int(kv.split("=")[1]) for kv in args.tune.split(",") if kv.startswith("respond.interleave_passes=")), -1)
+            cp.tuning_set("respond.interleave_passes", 0)
+            elapsed_s, region_ms_s = timed_region(max(1, min(args.warmup, 3)), args.steps)
+            cp.tuning_set("respond.interleave_passes", user_order)
+        else:
+            elapsed_s, region_ms_s = elapsed, kernel_region_ms
+        launch_us_s = region_ms_s * 1e3 / n_queries * passes_per_launch
+        result["value_slice_order"] = round(n_queries / elapsed_s, 2)
+        result["slice_order"] = {
+            "queries_per_sec": round(n_queries / elapsed_s, 2),
+            "ms_per_step": round(elapsed_s / args.steps * 1e3, 4),
+            "us_per_query_per_gpu": round(region_ms_s * 1e3 / n_queries, 2),
+            "frac": round(launch_bytes / (launch_us_s * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if launch_us_s > 0 else 0.0,
+            "frac_moved": round(moved_bytes / (launch_us_s * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if launch_us_s > 0 else 0.0,
+            "note": "the same shards and steps with every pass its own stream of the shard (slice order, nt loads): comparable with the N = 1 "
+                    "headline; `value` is the product's dispatch (pass_order above), which at this shard size shares database bytes on die",
+        }
     if world > 1 and not args.no_multirank_check:
         drain()
         try:
@@ -532,6 +566,24 @@ def main() -> int:
                 result["server_setup_kv_error"] = repr(exc)
     measure_traffic()
 
+    def add_single_gpu_reference():
+        if rank != 0 or "value_slice_order" not in result or "single_gpu_reference" in result:
+            return
+        try:
+            ref = single_gpu_reference(cp, torch, device, ShardedServer, args, N, C, b, mask, q_pool, stream)
+            result["single_gpu_reference"] = ref
+            n_shards = world if world > 1 else args.shard_of
+            # (a one-shard tuning run: every query needs the partial of EVERY shard, so the rate at which one GPU answers its 1/N of a query
+            # IS the rate the N-GPU job answers whole queries at, exchange aside)
+            result["scaling_like_for_like"] = round(result["value_slice_order"] / ref["queries_per_sec"], 3)
+            result["scaling_as_dispatched"] = round(result["value"] / ref["queries_per_sec"], 3)
+            result["scaling_note_like_for_like"] = (f"{'N' if world > 1 else 'shard-of'} = {n_shards}: value_slice_order / single_gpu_reference.queries_per_sec "
+                                                    "(both slice order, nt loads: every query its own stream of the database from HBM)"
+                                                    + ("" if world > 1 else "; one shard alone, no exchange"))
+        except Exception as exc:  # noqa: BLE001 -- an extra must never cost the line
+            log(f"single-GPU reference failed: {exc!r}")
+            result["single_gpu_reference"] = {"error": repr(exc)}
+
     if world > 1 and not args.no_setup:
         # The headline must not be hostage to an optional extra: rank 0 prints the respond line NOW, then the sharded setup is timed under
         # a wall-clock deadline and the enriched line printed again (a consumer takes the LAST line).  The deadline is enforced by a
@@ -559,6 +611,7 @@ def main() -> int:
         try:
             if os.environ.get("CPIR_BENCH_TEST_HANG_SETUP") == "1":  # test hook: a collective that never comes back (tests/test_gpu_multirank.py)
                 time.sleep(1e6)
+            add_single_gpu_reference()  # (rank 0 alone; the other ranks wait in the setup's first collective meanwhile)
             extra = setup_timing_sharded(cp, device, torch, dist, N, C, b, mask, lo, hi, rank, stream, full_layout)
         except Exception as exc:  # noqa: BLE001
             log(f"rank {rank}: sharded setup timing failed: {exc!r}")
@@ -577,6 +630,7 @@ def main() -> int:
         if rank == 0:
             print(json.dumps(result), flush=True)
         return 0
+    add_single_gpu_reference()  # (N > 1 with --no-setup, and the one-shard tuning runs)
     if rank == 0:  # (before the teardown: a process group that refuses to die must not cost the line)
         print(json.dumps(result), flush=True)
     if world > 1:
@@ -604,6 +658,48 @@ def launch_ranks(n: int) -> int:
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     log(f"bench.py: --gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd)}")
     return subprocess.run(cmd, env=env).returncode
+
+
+def single_gpu_reference(cp, torch, device, ShardedServer, args, N, C, b, mask, q_pool, stream):
+    """Rank 0 alone, after the timed regions: the WHOLE synthetic database on this one GPU, 32 queries per step as 32 independent passes in
+    slice order (every query its own stream from HBM) -- the N = 1 headline's loop, measured in this process, so that an N > 1 line can
+    state its scaling against it without a second run (`scaling_like_for_like`)."""
+    t0 = time.perf_counter()
+    D = torch.empty((N, C), dtype=torch.int32, device="cuda")
+    device.synth_fill(D, N * C, SEED_D, mask=mask, stream=stream)
+    whole = ShardedServer.from_device_matrix(D, 0, N, C, b, N, device, stream=stream)
+    torch.cuda.synchronize()
+    del D
+    torch.cuda.empty_cache()
+    per_step = 32
+    pool = q_pool.shape[0] // per_step * per_step
+    r = torch.zeros((per_step, C), dtype=torch.int32, device="cuda")
+    cp.tuning_set("respond.batch_fusion", 0)
+    cp.tuning_set("respond.interleave_passes", 0)
+
+    def step(k):
+        base = (k * per_step) % pool
+        whole.respond_partial_device(q_pool[base:base + per_step], r, batch=per_step, stream=stream)
+
+    try:
+        for k in range(3):
+            step(k)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            step(k)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t1
+    finally:
+        user_order = next((int(kv.split("=")[1]) for kv in args.tune.split(",") if kv.startswith("respond.interleave_passes=")), -1)
+        cp.tuning_set("respond.interleave_passes", user_order)
+    qps = args.steps * per_step / wall
+    del whole, r
+    torch.cuda.empty_cache()
+    return {"queries_per_sec": round(qps, 2), "us_per_query": round(1e6 / qps, 2), "steps": args.steps, "queries_per_step": per_step,
+            "pass_order": "slice", "seconds_spent": round(time.perf_counter() - t0, 2),
+            "note": "the whole database on rank 0's GPU alone, same generator, same loop as the N = 1 headline, measured in this process after "
+                    "the timed regions"}
 
 
 def kernel_source_sha256() -> str:

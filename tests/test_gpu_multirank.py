@@ -69,6 +69,13 @@ def test_driver_command_rehearsal_three_ranks():
     assert out["n_gpus"] == 3 and out["ranks"] == 3 and out["config"]["queries_per_step"] == 96 and out["steps"] == 20
     assert out["multirank_bit_exact"] is True and out["ranks_seen"] == [0, 1, 2]
     assert out["server_setup_wall_sec"] > 0 and "server_setup_timed_out" not in out and out["hint_checksum"] > 0
+    # like for like: the shards of this Infinity-Cache-sized database run their passes interleaved; the line also carries the same steps in
+    # slice order (already in the line printed first) and rank 0's single-GPU run of the whole database, and divides the two
+    assert out["roofline"]["pass_order"] == "interleaved" and first["value_slice_order"] > 0 and first["slice_order"]["frac"] > 0
+    ref = out["single_gpu_reference"]
+    assert ref["queries_per_sec"] > 0 and ref["pass_order"] == "slice" and ref["queries_per_step"] == 32
+    assert abs(out["scaling_like_for_like"] - out["value_slice_order"] / ref["queries_per_sec"]) < 2e-3
+    assert abs(out["scaling_as_dispatched"] - out["value"] / ref["queries_per_sec"]) < 2e-3
 
 
 def test_setup_deadline_is_not_a_success():
@@ -157,3 +164,28 @@ def test_rccl_backend_single_rank():
            "--master-port", "29655", os.path.join(ROOT, "tests", "_rccl_worker.py")]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "rccl single rank ok" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
+def test_two_ranks_over_the_real_backend_where_the_box_has_two_devices():
+    """ARMS ITSELF on a box with two or more GPUs (the driver's 8-GPU node): `bench.py --gpus 2` over the real backend -- "nccl" = RCCL,
+    one rank per device -- must bring up its process group, reduce the shards' partial responses with the int32-view all-reduce and prove
+    the result bit-exact (`multirank_bit_exact`), and the sharded setup must give the single-process hint.  On a one-GPU box the same
+    command runs under the gloo / shared-device hook (RCCL refuses two ranks on one device): never skipped."""
+    import torch
+
+    two = torch.cuda.device_count() >= 2
+    env = dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if not two:
+        env.update(CPIR_BENCH_BACKEND="gloo", CPIR_BENCH_SHARE_DEVICE="1")
+    else:
+        env.pop("CPIR_BENCH_BACKEND", None)
+        env.pop("CPIR_BENCH_SHARE_DEVICE", None)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--config", "cfg1", "--verify"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["backend"] == ("nccl" if two else "gloo")
+    assert out["multirank_bit_exact"] is True and out["ranks_seen"] == [0, 1] and out["verified_vs_oracle"] is True
+    assert out["server_setup_wall_sec"] > 0 and out["hint_checksum"] > 0 and out["scaling_like_for_like"] > 0
