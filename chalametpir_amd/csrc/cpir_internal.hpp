@@ -188,6 +188,11 @@ struct SlotMap {
   uint64_t n_orig = 0;              // slots the map selects from
   bool active() const { return n_kept != 0; }
   void reset();
+  // owns keep_dev: a map that is dropped on an error path (between build_slot_map and the server adopting it) frees its device memory
+  SlotMap() = default;
+  ~SlotMap() { reset(); }
+  SlotMap(const SlotMap&) = delete;
+  SlotMap& operator=(const SlotMap&) = delete;
 };
 int compact_slots_mode();  // tuning "layout.compact_slots": 0 never, 1 (default) where at least 1/32 of the rows are zero, 2 whenever a row is
 void set_compact_slots_mode(int m);

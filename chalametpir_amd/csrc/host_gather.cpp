@@ -24,14 +24,22 @@
 namespace cpir {
 namespace {
 
+// The SOURCE may be only byte-aligned: cpir_server_respond_bytes hands over `query + 8` of a wire buffer (matrix.rs:1001-1007 reads it with
+// a byte copy too).  Every scalar read of it goes through this; the vector paths use unaligned loads / gathers by construction.
+inline uint32_t load_word(const uint32_t* src, size_t i) {
+  uint32_t v;
+  memcpy(&v, reinterpret_cast<const unsigned char*>(src) + 4 * i, 4);
+  return v;
+}
+
 void gather_scalar(uint32_t* dst, const uint32_t* src, const uint32_t* idx, size_t count) {
-  for (size_t i = 0; i < count; i++) dst[i] = src[idx[i]];
+  for (size_t i = 0; i < count; i++) dst[i] = load_word(src, idx[i]);
 }
 
 size_t compress_scalar(uint32_t* dst, const uint32_t* src, const uint8_t* bits, size_t s_lo, size_t s_hi) {
   uint32_t* d = dst;
   for (size_t s = s_lo; s < s_hi; s++)
-    if ((bits[s >> 3] >> (s & 7)) & 1) *d++ = src[s];
+    if ((bits[s >> 3] >> (s & 7)) & 1) *d++ = load_word(src, s);
   return (size_t)(d - dst);
 }
 
@@ -42,7 +50,7 @@ __attribute__((target("avx2"))) void gather_avx2(uint32_t* dst, const uint32_t* 
     const __m256i k = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(idx + i));
     _mm256_storeu_si256(reinterpret_cast<__m256i*>(dst + i), _mm256_i32gather_epi32(reinterpret_cast<const int*>(src), k, 4));
   }
-  for (; i < count; i++) dst[i] = src[idx[i]];
+  for (; i < count; i++) dst[i] = load_word(src, idx[i]);
 }
 
 __attribute__((target("avx512f"))) void gather_avx512(uint32_t* dst, const uint32_t* src, const uint32_t* idx, size_t count) {
@@ -51,7 +59,7 @@ __attribute__((target("avx512f"))) void gather_avx512(uint32_t* dst, const uint3
     const __m512i k = _mm512_loadu_si512(idx + i);
     _mm512_storeu_si512(dst + i, _mm512_i32gather_epi32(k, src, 4));
   }
-  for (; i < count; i++) dst[i] = src[idx[i]];
+  for (; i < count; i++) dst[i] = load_word(src, idx[i]);
 }
 
 __attribute__((target("avx512f,avx512bw,popcnt"))) size_t compress_avx512(uint32_t* dst, const uint32_t* src, const uint8_t* bits, size_t s_lo,

@@ -528,6 +528,27 @@ __global__ void __launch_bounds__(256) group_sum_kernel(const uint32_t* __restri
   }
 }
 
+// the CURRENT device `from` may address the memory of device `to` (both directions are asked for by the caller, each from its own device)
+static int enable_peer_access(int from, int to) {
+  int can = 0;
+  hipError_t e = hipDeviceCanAccessPeer(&can, from, to);
+  if (e == hipSuccess && can) {
+    e = hipDeviceEnablePeerAccess(to, 0);
+    if (e == hipSuccess) return CPIR_OK;
+    if (e == hipErrorPeerAccessAlreadyEnabled) {
+      (void)hipGetLastError();  // (sticky otherwise: the next launch check would report it)
+      return CPIR_OK;
+    }
+  } else if (e == hipSuccess) {
+    e = hipErrorPeerAccessUnsupported;
+  }
+  (void)hipGetLastError();
+  char what[160];
+  snprintf(what, sizeof what, "peer access from device %d to device %d (device-resident queries on a group need it; host queries do not)", from, to);
+  set_last_hip_error(e, what, __FILE__, __LINE__);
+  return CPIR_ERR_HIP;
+}
+
 static int group_dev_create(Server* srv, Server::GroupDevCtx& c) {
   const size_t G = srv->shards.size();
   const uint32_t C = srv->layout.num_cols;
@@ -541,14 +562,10 @@ static int group_dev_create(Server* srv, Server::GroupDevCtx& c) {
   for (size_t g = 0; g < G; g++) {
     const Server* child = srv->shards[g];
     DeviceGuard dg(child->dev->ordinal);
-    if (child->dev->ordinal != root->ordinal) {  // peer access both ways where the hardware offers it (else the runtime stages the copies)
-      int can = 0;
-      if (hipDeviceCanAccessPeer(&can, child->dev->ordinal, root->ordinal) == hipSuccess && can) {
-        const hipError_t pe = hipDeviceEnablePeerAccess(root->ordinal, 0);
-        if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
-        else (void)hipGetLastError();
-      }
-    }
+    // peer access both ways: the shard pulls its slots of the queries out of the root's memory and pushes its partial responses into the
+    // root's table.  Without it a device-resident query cannot be exchanged (the host entry points do not need it: they scatter and sum
+    // on the host): a clear error instead of copies that fail later, at enqueue time or behind it.
+    if (child->dev->ordinal != root->ordinal) CPIR_TRY(enable_peer_access(child->dev->ordinal, root->ordinal));
     if (!(c.stream[g] = device_stream_acquire(child->dev))) return CPIR_ERR_HIP;
     if ((e = hipEventCreateWithFlags(&c.ev[g], hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreateWithFlags(group)");
     const size_t words = ((size_t)child->layout.num_slots + 3) / 4 * 4 * Server::kBatchCap + (size_t)(C + 3) / 4 * 4 * Server::kBatchCap +
@@ -557,12 +574,8 @@ static int group_dev_create(Server* srv, Server::GroupDevCtx& c) {
   }
   DeviceGuard dg(root->ordinal);
   for (size_t g = 1; g < G; g++) {
-    int can = 0;
     const int peer = srv->shards[g]->dev->ordinal;
-    if (peer != root->ordinal && hipDeviceCanAccessPeer(&can, root->ordinal, peer) == hipSuccess && can) {
-      (void)hipDeviceEnablePeerAccess(peer, 0);
-      (void)hipGetLastError();
-    }
+    if (peer != root->ordinal) CPIR_TRY(enable_peer_access(root->ordinal, peer));
   }
   if ((e = hipEventCreateWithFlags(&c.in_ev, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreateWithFlags(group)");
   if ((e = hipEventCreateWithFlags(&c.done_ev, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreateWithFlags(group)");
@@ -603,10 +616,12 @@ static int group_respond_device(Server* srv, const uint32_t* q_dev, uint32_t bat
       uint32_t* r_loc = q_loc + qw * Server::kBatchCap;
       uint32_t* qc_loc = child->map.active() ? r_loc + rw * Server::kBatchCap : nullptr;
       TRY_(hipStreamWaitEvent(s, c.in_ev, 0));
-      if (c.used) TRY_(hipStreamWaitEvent(s, c.done_ev, 0));  // the previous round's table has been summed before this one writes into it
       // this shard's slots of the nb queries: rows of n words out of rows of N words, over the peer link where the devices differ
       TRY_(hipMemcpy2DAsync(q_loc, qw * 4, q_dev + (uint64_t)done * N + child->slot_offset, N * 4, n * 4, nb, hipMemcpyDeviceToDevice, s));
       CPIR_TRY(server_respond_on_device(child, q_loc, qw, 0, nb, nb == 1, r_loc, nullptr, qc_loc, s));
+      // the previous round's table has been summed before this one writes into it -- waited for HERE, behind this round's respond, so that
+      // round k + 1 streams the database while the root still adds up round k
+      if (c.used) TRY_(hipStreamWaitEvent(s, c.done_ev, 0));
       TRY_(hipMemcpyAsync(c.partials + (g * Server::kBatchCap) * (size_t)C, r_loc, (size_t)nb * C * 4, hipMemcpyDeviceToDevice, s));
       TRY_(hipEventRecord(c.ev[g], s));
     }
@@ -1149,7 +1164,9 @@ int cpir_server_respond_bytes(const cpir_server* srv, const uint8_t* query, size
   const uint32_t C = srv->layout.num_cols;
   const size_t need = 8 + (size_t)C * 4;
   if (response_cap < need) return CPIR_ERR_BUFFER_TOO_SMALL;
-  // query + 8 may be only byte-aligned; cpir_server_respond memcpy's from it, so no alignment is required here
+  // query + 8 may be only byte-aligned: every host-side read of the query words is a byte copy or an unaligned vector load (the staging
+  // memcpy's; host_gather.cpp's compaction of a lone query of a server with a slot map: load_word / loadu / gathers), so no alignment is
+  // required here (tests/test_gpu_compact.py::test_wire_buffer_at_odd_addresses)
   std::vector<uint32_t> r(C);
   CPIR_TRY(cpir_server_respond(srv, reinterpret_cast<const uint32_t*>(query + 8), rows, cols, r.data()));
   const uint32_t one = 1;  // Matrix::to_bytes of the 1 x C response (matrix.rs:947-971)

@@ -227,15 +227,33 @@ void DevBuf::dispose_async(int ordinal) {
 static int pack_into_server(Device* dev, Server* srv, const uint32_t* D_dev, uint64_t ldd, const cpir_dtc_layout& L, SlotMap* map, uint32_t* flag_dev,
                             void* hi_plane, hipStream_t stream) {
   cpir_dtc_layout P = L;
+  uint32_t* Dc = nullptr;
   if (map->active()) {
     if (hi_plane) return CPIR_ERR_INVALID_ARGUMENT;
     CPIR_TRY(dtc_layout_for_packing(map->n_kept, L.num_cols, L.mat_elem_bit_len, L.packing, &P));
+    // The kept rows are gathered into a temporary of (almost) D's size while D is still resident: where the device has no room for that --
+    // a database that fits beside its image but not twice -- the map is dropped and the whole matrix packed as it is.  Compaction is an
+    // optimisation, never a reason for setup to fail.
+    const hipError_t ae = hipMallocAsync(reinterpret_cast<void**>(&Dc), (size_t)map->n_kept * L.num_cols * 4, stream);
+    if (ae != hipSuccess) {
+      (void)hipGetLastError();
+      if (ae != hipErrorOutOfMemory) {
+        set_last_hip_error(ae, "hipMallocAsync(compact D)", __FILE__, __LINE__);
+        return CPIR_ERR_HIP;
+      }
+      Dc = nullptr;
+      map->reset();
+      P = L;
+    }
   }
-  CPIR_HIP_TRY(CPIR_HIP_MALLOC(&srv->dtc, (size_t)P.total_words * 4));
+  const hipError_t de = CPIR_HIP_MALLOC(&srv->dtc, (size_t)P.total_words * 4);
+  if (de != hipSuccess) {
+    set_last_hip_error(de, "hipMalloc(dtc)", __FILE__, __LINE__);
+    if (Dc) (void)hipFreeAsync(Dc, stream);
+    return de == hipErrorOutOfMemory ? CPIR_ERR_OUT_OF_DEVICE_MEMORY : CPIR_ERR_HIP;
+  }
   int st;
   if (map->active()) {
-    uint32_t* Dc = nullptr;
-    CPIR_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&Dc), (size_t)map->n_kept * L.num_cols * 4, stream));
     st = launch_gather_rows(dev, D_dev, ldd, *map, L.num_cols, Dc, stream);
     if (st == CPIR_OK) st = launch_transpose_compress(dev, Dc, L.num_cols, P, srv->dtc, flag_dev, stream, nullptr);
     const hipError_t fe = hipFreeAsync(Dc, stream);
@@ -732,9 +750,18 @@ int cpir_server_from_compressed(cpir_device* dev, const uint32_t* compressed, ui
     st = dtc_layout_for_packing(map.n_kept, C, b, L.packing, &P);
     if (st != CPIR_OK) return fail(st);
     e = CPIR_HIP_MALLOC(&compact.p, (size_t)C * P.words_per_row * 4);
-    if (e != hipSuccess) { set_last_hip_error(e, "hipMalloc(compact compressed matrix)", __FILE__, __LINE__); return fail(CPIR_ERR_OUT_OF_DEVICE_MEMORY); }
-    st = launch_gather_compressed(dev, (const uint32_t*)src.p, L.words_per_row, map, C, L.compression_factor, P.words_per_row, (uint32_t*)compact.p, dev->stream);
-    if (st != CPIR_OK) return fail(st);
+    if (e == hipErrorOutOfMemory) {  // no room for a second (compact) copy beside the source: import the whole matrix, serve every slot
+      (void)hipGetLastError();
+      compact.p = nullptr;
+      map.reset();
+      P = L;
+    } else if (e != hipSuccess) {
+      set_last_hip_error(e, "hipMalloc(compact compressed matrix)", __FILE__, __LINE__);
+      return fail(CPIR_ERR_HIP);
+    } else {
+      st = launch_gather_compressed(dev, (const uint32_t*)src.p, L.words_per_row, map, C, L.compression_factor, P.words_per_row, (uint32_t*)compact.p, dev->stream);
+      if (st != CPIR_OK) return fail(st);
+    }
   }
   e = CPIR_HIP_MALLOC(&srv->dtc, (size_t)P.total_words * 4);
   if (e != hipSuccess) { set_last_hip_error(e, "hipMalloc(dtc)", __FILE__, __LINE__); return fail(CPIR_ERR_OUT_OF_DEVICE_MEMORY); }

@@ -531,6 +531,14 @@ class Server:
         _check(self._lib.cpir_server_respond_bytes(self._h, C.addressof(qbuf), len(query), C.addressof(out), cap, C.byref(n)))
         return bytes(out[: n.value])
 
+    def respond_from_address(self, address: int, length: int) -> bytes:
+        """Server::respond on `length` wire bytes at a raw host address (no copy on this side; any alignment)"""
+        cap = 8 + 4 * self.layout.num_cols
+        out = (C.c_uint8 * cap)()
+        n = C.c_size_t()
+        _check(self._lib.cpir_server_respond_bytes(self._h, C.c_void_p(address), length, C.addressof(out), cap, C.byref(n)))
+        return bytes(out[: n.value])
+
     def respond_array(self, q: np.ndarray) -> np.ndarray:
         """respond on the element array of a 1 x N query (query[8..] of the wire image)"""
         q = _u32_host(q)

@@ -57,6 +57,32 @@ def device(native):
     return cp.Device(0)
 
 
+@pytest.fixture(scope="session")
+def group_devices(device):
+    """the device list of a GROUP of k shards on THIS box: distinct devices wherever the box has them (shard i on device i mod the number
+    of visible devices), the one GPU listed k times on a one-GPU box.  The group tests therefore arm themselves on a multi-GPU node --
+    peer copies between different devices, per-device streams and allocations, the root's sum kernel behind events of other devices --
+    and pass as the one-device case elsewhere; they never skip."""
+    import torch
+
+    import chalametpir_amd as cp
+
+    n_vis = max(1, torch.cuda.device_count())
+    opened = {0: device}
+
+    def pick(k):
+        out = []
+        for i in range(k):
+            o = i % n_vis
+            if o not in opened:
+                opened[o] = cp.Device(o)
+            out.append(opened[o])
+        return out
+
+    pick.visible = n_vis
+    return pick
+
+
 @pytest.fixture(autouse=True)
 def _tuning_defaults_between_tests(request):
     """the library's tuning keys are process-wide: whatever a test (or a fixture of its module) flipped is put back to the defaults

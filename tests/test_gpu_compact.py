@@ -193,6 +193,83 @@ def test_device_queries_single_batched_fused_and_shards(b, orc, device):
     whole.close()
 
 
+def test_wire_buffer_at_odd_addresses(orc, device):
+    """Server::respond takes `&[u8]`: the wire image may start at ANY address (matrix.rs:1001-1007 copies the element bytes out).  With a
+    slot map a lone caller's query is compacted on the host straight out of `query + 8` (host_gather.cpp): its scalar and tail reads must
+    not assume 4-byte alignment.  Short queries (the scalar tails) and long ones (the vector body, the polled launch), every offset mod 4."""
+    import ctypes
+
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(1357)
+    b, C = 9, 9
+    for N in (1536 * 2 + 13, 1536 * 400 + 7):
+        D, kept = holey_matrix(rng, N, C, b, zero_frac=0.2)
+        dtc = oracle_dtc(orc, D, b)
+        srv = cp.Server.from_compressed(dtc, N, b, device=device)
+        assert srv.slots_served() == (kept.size, N)
+        q = random_query(rng, N)
+        image = wire(q)
+        want = orc.server_respond(dtc, N, b, image)
+        for shift in (1, 2, 3, 5, 0):
+            buf = (ctypes.c_uint8 * (len(image) + 16))()
+            base = ctypes.addressof(buf)
+            off = (-base) % 8 + shift  # the image starts `shift` bytes past an 8-byte boundary
+            ctypes.memmove(base + off, image, len(image))
+            assert srv.respond_from_address(base + off, len(image)) == want, (N, shift)
+        srv.close()
+
+
+def test_a_database_that_does_not_fit_twice_is_served_uncompacted(orc, device):
+    """compaction gathers the kept rows into a temporary of (almost) D's size while D is still resident; where the device has no room for
+    that the map is dropped and the whole matrix is packed -- setup must not fail for the sake of an optimisation.  The device's free memory
+    is taken away by an allocation of this test's own (nothing is written to it) until only the image fits."""
+    import torch
+
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(2468)
+    b, C = 9, 192
+    N = 1536 * 300
+    D, kept = holey_matrix(rng, N, C, b, zero_frac=0.2)
+    dtc = oracle_dtc(orc, D, b)
+    q = random_query(rng, N)
+    want = orc.row_vector_x_compressed_transposed_matrix(q, dtc, N, b)[0]
+    stream = torch.cuda.current_stream()
+    D_dev = dev(D)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    image_bytes = int(cp.dtc_layout_for(N, C, b).total_words) * 4
+    gather_bytes = kept.size * C * 4
+    room = image_bytes + image_bytes // 5 + (64 << 20)  # what is left to the library: the image, a margin for the map and the runtime
+    assert gather_bytes > room + (32 << 20)  # (so that "the image fits, the temporary does not" is a wide target at every packing)
+    # (everything this test allocates through torch exists BEFORE the ballast, and the ballast is a whole number of 2 MiB pages: torch's
+    # caching allocator would otherwise carve a later small tensor out of the ballast's segment and could not give the segment back)
+    r = torch.empty(C, dtype=torch.int32, device="cuda")
+    q_dev = dev(q)
+    torch.cuda.synchronize()
+    free, _ = torch.cuda.mem_get_info()
+    ballast = None
+    try:
+        ballast = torch.empty((free - room) // (2 << 20) * (2 << 20), dtype=torch.uint8, device="cuda")
+        free_now, _ = torch.cuda.mem_get_info()
+        assert free_now < gather_bytes
+        srv = cp.Server.from_device_matrix(D_dev, N, C, b, device=device, stream=stream)
+        assert srv.slots_served() == (N, N)  # the map was dropped: every slot is resident
+        srv.respond_device(q_dev, r, stream=stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(host(r), want)
+        srv.close()
+    finally:
+        del ballast
+        torch.cuda.empty_cache()
+    assert torch.cuda.mem_get_info()[0] > gather_bytes + 4 * image_bytes, "the test's own ballast was not given back"
+    # with room the same matrix IS compacted
+    srv = cp.Server.from_device_matrix(D_dev, N, C, b, device=device, stream=stream)
+    assert srv.slots_served() == (kept.size, N)
+    srv.close()
+
+
 def test_host_queries_lone_and_concurrent(orc, device):
     """cpir_server_respond on host buffers with a slot map: a lone caller (pageable and page-locked: compacted on the host into the pinned
     block the kernel reads in place; long enough for the polled launch), 6 concurrent callers (uploaded whole, gathered on the device),
@@ -248,7 +325,7 @@ def test_host_queries_lone_and_concurrent(orc, device):
         plain.close()
 
 
-def test_group_handle_with_compacted_shards(orc, device):
+def test_group_handle_with_compacted_shards(orc, device, group_devices):
     """cpir_server_setup_multi: every shard finds its own zero rows; host queries are scattered, partial responses summed on the host"""
     import chalametpir_amd as cp
 
@@ -258,7 +335,7 @@ def test_group_handle_with_compacted_shards(orc, device):
     D, kept = holey_matrix(rng, N, C, b, pattern="runs")
     seed = rng.bytes(32)
     want_hint, want_dtc = orc.server_setup_from_matrix(seed, D, b)
-    grp, hint = cp.Server.setup_from_matrix(seed, D, b, devices=[device, device, device])
+    grp, hint = cp.Server.setup_from_matrix(seed, D, b, devices=group_devices(3))
     try:
         shards = grp.group_shards()
         assert len(shards) == 3

@@ -2,9 +2,10 @@
 (cpir_server_setup_multi / cpir_server_setup_kv_multi), host queries scattered and partial responses summed on the host.
 
 The reference has no multi-device code; the property is that a group is indistinguishable from one device: same hint, same
-packed database, same responses, bit for bit.  A GPU box for tests has ONE device, so the groups here list it several times
-(every shard still has its own packed image, streams, query slice and partial response); on a multi-GPU node the same code
-runs with distinct ordinals."""
+packed database, same responses, bit for bit.  The device list of every group comes from the `group_devices` fixture: DISTINCT devices
+wherever the box has them (shard i on device i mod the visible devices -- on the driver's 8-GPU node every test below runs across
+devices: peer copies, per-device streams, the root's sum behind other devices' events), the one GPU listed several times on a one-GPU box
+(every shard still has its own packed image, streams, query slice and partial response).  Nothing here skips."""
 import threading
 
 import numpy as np
@@ -17,14 +18,14 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("b,N,C,shards", [(9, 3 * 1536 + 700, 37, 3), (10, 9 * 1536, 64, 2), (13, 5 * 512 + 1, 21, 4), (6, 4 * 4096 + 5, 33, 3),
                                           (9, 1000, 5, 8)])
-def test_group_setup_and_respond_match_the_oracle(b, N, C, shards, orc, device):
+def test_group_setup_and_respond_match_the_oracle(b, N, C, shards, orc, device, group_devices):
     import chalametpir_amd as cp
 
     rng = np.random.default_rng(b * 100 + shards)
     seed = rng.bytes(32)
     D = random_db_matrix(rng, N, C, b)
     want_hint, want_dtc = orc.server_setup_from_matrix(seed, D, b)
-    srv, hint = cp.Server.setup_from_matrix(seed, D, b, devices=[device] * shards)
+    srv, hint = cp.Server.setup_from_matrix(seed, D, b, devices=group_devices(shards))
     parts = srv.group_shards()
     assert 1 <= len(parts) <= shards and parts[0][1] == 0 and sum(p[2] for p in parts) == N
     cf = cf_of(b)
@@ -44,7 +45,7 @@ def test_group_setup_and_respond_match_the_oracle(b, N, C, shards, orc, device):
     assert e.value.variant == "IncompatibleDimensionForRowVectorTransposedMatrixMultiplication"
     # caller-supplied A, and a clone sharing the shards
     A = orc.generate_from_seed(1774, N, seed)
-    srv2, hint2 = cp.Server.setup_from_matrix(seed, D, b, pub_mat_a=A, devices=[device] * shards)
+    srv2, hint2 = cp.Server.setup_from_matrix(seed, D, b, pub_mat_a=A, devices=group_devices(shards))
     assert np.array_equal(hint2, want_hint)
     twin = srv.clone()
     srv.close()
@@ -52,7 +53,7 @@ def test_group_setup_and_respond_match_the_oracle(b, N, C, shards, orc, device):
     assert twin.respond(wire(q)) == srv2.respond(wire(q)) == orc.server_respond(want_dtc, N, b, wire(q))
 
 
-def test_group_from_kv_database_equals_one_device(orc, device):
+def test_group_from_kv_database_equals_one_device(orc, device, group_devices):
     import chalametpir_amd as cp
 
     rng = np.random.default_rng(4242)
@@ -63,7 +64,7 @@ def test_group_from_kv_database_equals_one_device(orc, device):
     seed, fseeds = rng.bytes(32), rng.bytes(32 * 100)
     for arity in (3, 4):
         one, hint1, filt1 = cp.Server.setup(seed, db, arity, device=device, filter_seed_material=fseeds)
-        grp, hint2, filt2 = cp.Server.setup(seed, db, arity, devices=[device] * 3, filter_seed_material=fseeds)
+        grp, hint2, filt2 = cp.Server.setup(seed, db, arity, devices=group_devices(3), filter_seed_material=fseeds)
         assert hint1 == hint2 and filt1 == filt2 and len(grp.group_shards()) >= 1
         assert np.array_equal(one.export_compressed(), grp.export_compressed())
         N = one.decompressed_num_cols
@@ -74,13 +75,13 @@ def test_group_from_kv_database_equals_one_device(orc, device):
         assert ph["total"] > 0 and ph["encode"] > 0
 
 
-def test_group_respond_is_reentrant(orc, device):
+def test_group_respond_is_reentrant(orc, device, group_devices):
     import chalametpir_amd as cp
 
     rng = np.random.default_rng(99)
     N, C, b = 6 * 1536 + 11, 29, 9
     D = random_db_matrix(rng, N, C, b)
-    srv, _ = cp.Server.setup_from_matrix(rng.bytes(32), D, b, devices=[device] * 4)
+    srv, _ = cp.Server.setup_from_matrix(rng.bytes(32), D, b, devices=group_devices(4))
     dtc = orc.row_wise_compress(orc.transpose(D), b)
     qs = [random_query(rng, N) for _ in range(16)]
     wants = [orc.row_vector_x_compressed_transposed_matrix(q, dtc, N, b)[0] for q in qs]
@@ -101,7 +102,7 @@ def test_group_respond_is_reentrant(orc, device):
     assert not errors
 
 
-def test_device_pointer_entry_points_take_a_group_on_the_default_stream(orc, device):
+def test_device_pointer_entry_points_take_a_group_on_the_default_stream(orc, device, group_devices):
     """(round 3 rejected a group here; since round 4 the exchange runs on the devices: see the peer-exchange test below) -- the NULL
     stream and a tiny database"""
     import torch
@@ -111,7 +112,7 @@ def test_device_pointer_entry_points_take_a_group_on_the_default_stream(orc, dev
     rng = np.random.default_rng(5)
     N, C, b = 4 * 1536, 8, 9
     D = random_db_matrix(rng, N, C, b)
-    srv, _ = cp.Server.setup_from_matrix(rng.bytes(32), D, b, devices=[device, device])
+    srv, _ = cp.Server.setup_from_matrix(rng.bytes(32), D, b, devices=group_devices(2))
     dtc = orc.row_wise_compress(orc.transpose(D), b)
     qh = random_query(rng, N)
     q = torch.from_numpy(qh.view(np.int32)).cuda()
@@ -127,7 +128,7 @@ def test_device_pointer_entry_points_take_a_group_on_the_default_stream(orc, dev
     srv.close()
 
 
-def test_lifecycle_stress_servers_groups_and_setups_from_many_threads(orc, device):
+def test_lifecycle_stress_servers_groups_and_setups_from_many_threads(orc, device, group_devices):
     """handles created, cloned, queried and dropped concurrently from several threads -- single-device servers (coalescing arenas),
     group handles (per-shard worker threads) and full setups (background release of A / D): every response must still be exact and
     nothing may hang or crash"""
@@ -150,7 +151,7 @@ def test_lifecycle_stress_servers_groups_and_setups_from_many_threads(orc, devic
                 if kind == 0:
                     srv = cp.Server.from_compressed(dtc, N, b, device=device)
                 elif kind == 1:
-                    srv, hint = cp.Server.setup_from_matrix(seed, D, b, devices=[device] * (2 + it % 3))
+                    srv, hint = cp.Server.setup_from_matrix(seed, D, b, devices=group_devices(2 + it % 3))
                     if not np.array_equal(hint, want_hint):
                         errors.append(("group hint", k, it))
                 else:
@@ -178,7 +179,7 @@ def test_lifecycle_stress_servers_groups_and_setups_from_many_threads(orc, devic
 
 
 @pytest.mark.parametrize("b,holes", [(9, False), (9, True), (12, True)])
-def test_group_answers_device_queries_with_a_peer_exchange(b, holes, orc, device):
+def test_group_answers_device_queries_with_a_peer_exchange(b, holes, orc, device, group_devices):
     """cpir_server_respond_device / _batch_device on a group handle: q and r on the root device, every shard pulls its slots over the
     peer link, the C-word partials are pushed into the root's table and summed by a kernel on the caller's stream -- same responses as
     the oracle on the whole matrix, for one query, for batches around and beyond the 48-query round, on databases with and without rows
@@ -194,9 +195,11 @@ def test_group_answers_device_queries_with_a_peer_exchange(b, holes, orc, device
         D[rng.random(N) < 0.15] = 0
     seed = rng.bytes(32)
     _, want_dtc = orc.server_setup_from_matrix(seed, D, b)
-    grp, _ = cp.Server.setup_from_matrix(seed, D, b, devices=[device] * 3)
+    devs = group_devices(3)
+    assert len({d.ordinal for d in devs}) == min(3, group_devices.visible)  # (distinct devices wherever the box has them)
+    grp, _ = cp.Server.setup_from_matrix(seed, D, b, devices=devs)
     try:
-        assert len(grp.group_shards()) == 3
+        assert len(grp.group_shards()) == 3 and [p[0] for p in grp.group_shards()] == [d.ordinal for d in devs]
         if holes:
             assert grp.slots_served()[0] < N
         stream = torch.cuda.current_stream()

@@ -174,7 +174,7 @@ def test_wide_pass_over_column_windows(orc, device):
         srv.close()
 
 
-def test_wide_pass_on_a_compacted_database_and_a_group(orc, device):
+def test_wide_pass_on_a_compacted_database_and_a_group(orc, device, group_devices):
     """rows that hold nothing are left out of the image (compact.hip): the queries are gathered onto the kept slots in front of the wide
     pass; a group of shards answers the same batch through its device exchange"""
     import torch
@@ -189,7 +189,7 @@ def test_wide_pass_on_a_compacted_database_and_a_group(orc, device):
     seed = rng.bytes(32)
     _, dtc = orc.server_setup_from_matrix(seed, D, b)
     srv, _ = cp.Server.setup_from_matrix(seed, D, b, device=device)
-    grp, _ = cp.Server.setup_from_matrix(seed, D, b, devices=[device] * 2)
+    grp, _ = cp.Server.setup_from_matrix(seed, D, b, devices=group_devices(2))
     try:
         assert srv.slots_served()[0] < N
         nq = 30
