@@ -3,6 +3,7 @@
 Restates row_vector_compressed_transposed_matrix_multiplication_works (reference matrix.rs:1319-1376) and adds what the
 reference cannot test (it has no GPU respond): every element bit length, every N mod cf, ragged row counts, the wire
 format and its error behaviour (matrix.rs:973-1010, 329-331), re-entrancy, shards and batches."""
+import os
 import threading
 
 import numpy as np
@@ -532,3 +533,41 @@ def test_more_columns_than_one_query_fits_in_the_accumulators(orc, device):
     assert np.array_equal(srv.respond_array(Q[1]), want[1]) and np.array_equal(srv.respond_array(pin.array), want[1])
     pin.close()
     srv.close()
+
+
+def test_environment_cannot_change_a_response(orc, device):
+    """Server::respond has no mode in which it lies (server.rs:184-190).  Rounds 3-4 had measuring aids in the release library that the
+    environment could switch on (CPIR_WIDE_ABLATE skipped parts of the wide kernel, CPIR_KS_TRACE made launches synchronous): they now
+    exist only in the -DCPIR_DIAG build.  A process with every such variable set answers exactly as the oracle does -- device queries,
+    fused batches, a lone host query -- and the tuning key of the matmul ablation is refused."""
+    import hashlib
+    import subprocess
+    import sys
+
+    rng = np.random.default_rng(31415)
+    b, N, C = 9, 5 * 512 + 77, 45
+    D = random_db_matrix(rng, N, C, b)
+    dtc = orc.row_wise_compress(orc.transpose(D), b)
+    Q = np.stack([random_query(rng, N) for _ in range(30)])
+    want = np.stack([orc.row_vector_x_compressed_transposed_matrix(q, dtc, N, b)[0] for q in Q])
+    np.savez("/tmp/cpir_env_case.npz", dtc=dtc, Q=Q, N=N, b=b)
+    code = (
+        "import sys, hashlib, numpy as np, torch\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+        "import chalametpir_amd as cp\n"
+        "z = np.load('/tmp/cpir_env_case.npz'); dtc, Q, N, b = z['dtc'], z['Q'], int(z['N']), int(z['b'])\n"
+        "srv = cp.Server.from_compressed(dtc, N, b, device=cp.Device(0))\n"
+        "s = torch.cuda.current_stream(); Qd = torch.from_numpy(Q.view(np.int32)).cuda()\n"
+        "R = torch.empty((30, dtc.shape[0]), dtype=torch.int32, device='cuda'); srv.respond_batch_device(Qd, 30, R, stream=s)\n"
+        "r1 = torch.empty(dtc.shape[0], dtype=torch.int32, device='cuda'); srv.respond_device(Qd[3], r1, stream=s); torch.cuda.synchronize()\n"
+        "h = srv.respond_array(Q[5])\n"
+        "try:\n    cp.tuning_set('matmul.ablate', 1); refused = False\nexcept cp.ChalametPIRError:\n    refused = True\n"
+        "print(hashlib.sha256(R.cpu().numpy().tobytes() + r1.cpu().numpy().tobytes() + h.tobytes()).hexdigest(), refused)\n"
+    )
+    expected = hashlib.sha256(want.astype(np.uint32).tobytes() + want[3].astype(np.uint32).tobytes() + want[5].astype(np.uint32).tobytes()).hexdigest()
+    for extra in ({}, {"CPIR_WIDE_ABLATE": "7", "CPIR_KS_TRACE": "1", "CPIR_MM_ABLATE": "15"}):
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        digest, refused = p.stdout.split()[-2:]
+        assert digest == expected and refused == "True", (extra, p.stdout[-300:])
+        assert "[ks trace]" not in p.stderr and "[wide trace]" not in p.stderr
