@@ -9,6 +9,7 @@ for v in "" _cfg5; do
   [ -d "$P" ] || continue
   cp $P/trace/trace_kernel_stats.csv profiles/${T}${v}_kernel_stats.csv
   cp $P/setup_trace/setup_kernel_stats.csv profiles/${T}${v}_setup_kernel_stats.csv
+  [ -f $P/full_trace/full_kernel_stats.csv ] && cp $P/full_trace/full_kernel_stats.csv profiles/${T}${v}_all_sections_kernel_stats.csv
   cp $P/summary.txt profiles/${T}${v}_rocprofv3_summary.txt
   cp $P/summary.json profiles/${T}${v}_rocprofv3_summary.json
   cp $P/trace_bench.json profiles/${T}${v}_bench_under_kernel_trace.json

@@ -11,11 +11,17 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="$ROOT/bench.py --no-setup --no-cpu-baseline --no-host-path --no-read-ceiling --no-live-traffic --steps 10 --warmup 2 $*"
+# the HEADLINE's timed loop and nothing else: since round 5 every device-resident launch runs on one kernel (respond_planar_wide_kernel), so a
+# trace that also held the fused batches and the lone launches would average three different launch shapes under one name; here every
+# dispatch of the kernel is one step of the timed loop (32 passes), and its average duration is the bench line's `roofline.launch_us`
+BENCH="$ROOT/bench.py --headline-only --no-setup --no-setup-kv --no-cpu-baseline --no-host-path --no-read-ceiling --no-live-traffic --steps 20 --warmup 5 $*"
+# ... and the default run's other sections (fused batches, lone launches, the real database, the host path) in a trace of their own
+FULL_BENCH="$ROOT/bench.py --no-setup --no-cpu-baseline --no-read-ceiling --no-live-traffic --steps 10 --warmup 2 $*"
 SETUP_BENCH="$ROOT/bench.py --no-cpu-baseline --no-host-path --no-read-ceiling --no-live-traffic --steps 2 --warmup 1 $*"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- python3 $BENCH > "$OUT/trace_bench.json" 2> "$OUT/trace.err"
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o fetch -- python3 $BENCH > "$OUT/fetch_bench.json" 2> "$OUT/fetch.err"
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o write -- python3 $BENCH > "$OUT/write_bench.json" 2> "$OUT/write.err"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/full_trace" -o full -- python3 $FULL_BENCH > "$OUT/full_bench.json" 2> "$OUT/full.err"
 # the offline kernels (hint matmul, transpose+pack) inside one Server::setup + the setup_roofline timing of each kernel alone
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/setup_trace" -o setup -- python3 $SETUP_BENCH > "$OUT/setup_bench.json" 2> "$OUT/setup.err"
 cd "$ROOT" && python3 scripts/summarize_rocprof.py "$OUT" "$TAG" "$HEAD" > "$OUT/summary.txt" 2>&1

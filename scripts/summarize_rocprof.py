@@ -100,6 +100,32 @@ def main():
         summary["kernels"].append({"name": name, "calls": calls, "avg_us": avg / 1e3, "total_ms": tot / 1e6})
         if is_respond(name) and "avg_us" not in summary["respond"]:
             summary["respond"].update({"name": name, "calls": calls, "avg_us": avg / 1e3})
+    # the bench line printed inside the traced run: its HIP-event launch time must agree with the trace's average for that kernel
+    try:
+        with open(os.path.join(root, "trace_bench.json")) as fh:
+            line = json.loads(fh.read().strip().splitlines()[-1])
+        roof = line["roofline"]
+        if "avg_us" in summary["respond"]:
+            avg = summary["respond"]["avg_us"]
+            algo, moved = roof["bytes_per_launch"], roof["moved_bytes_per_launch"]
+            print(f"-- bench line inside this trace: value {line['value']} q/s, roofline.launch_us {roof['launch_us']} (HIP events) vs kernel-trace "
+                  f"average {avg:.2f} us over {summary['respond']['calls']} dispatches ({(roof['launch_us'] / avg - 1) * 100:+.2f} %)")
+            print(f"-- from the trace's average: {algo / avg / 1e3:.1f} GB/s algorithmic = {algo / avg / 1e3 / 8000:.4f} of 8 TB/s; "
+                  f"{moved / avg / 1e3:.1f} GB/s moved = {moved / avg / 1e3 / 8000:.4f}")
+            summary["respond"].update({"bench_launch_us": roof["launch_us"], "frac_from_trace_avg": algo / avg / 1e3 / 8000,
+                                       "frac_moved_from_trace_avg": moved / avg / 1e3 / 8000})
+    except (OSError, ValueError, IndexError, KeyError):
+        pass
+    full = kernel_stats(os.path.join(root, "full_trace"))
+    full.sort(key=lambda r: -float(r.get("TotalDurationNs", 0) or 0))
+    if full:
+        print("-- kernel stats of the default run's other sections too (fused batches, lone launches, real database, host path: one kernel name, several launch shapes) --")
+        summary["all_sections_kernels"] = []
+        for r in full[:8]:
+            name, calls = r.get("Name", ""), int(float(r.get("Calls", 0)))
+            avg, tot = float(r.get("AverageNs", 0) or 0), float(r.get("TotalDurationNs", 0) or 0)
+            print(f"{calls:7d} calls  avg {avg / 1e3:10.2f} us  total {tot / 1e6:10.3f} ms  {name[:110]}")
+            summary["all_sections_kernels"].append({"name": name, "calls": calls, "avg_us": avg / 1e3, "total_ms": tot / 1e6})
     for label, sub, ctr in (("fetch", "pmc_fetch", "FETCH_SIZE"), ("write", "pmc_write", "WRITE_SIZE")):
         c = counters(os.path.join(root, sub))
         want = summary["respond"].get("name")  # the instantiation that dominates the kernel trace (the headline launches)
