@@ -46,7 +46,7 @@ class OwnMapping:
     """A u32 buffer in a private anonymous mapping of its own (mmap), page-aligned, for tests that hipHostRegister caller memory.
     NEVER register glibc heap memory (a numpy array) in this suite: on the GPU boxes a hipHostRegister / hipHostUnregister cycle over heap
     pages is followed, some allocations later, by "Memory access fault by GPU node-N on address <heap address>" -- with the HIP runtime and
-    torch alone, no code of this repository involved (scripts/probes/register_then_copy_probe.py).  Dedicated mappings, unmapped
+    torch alone, no code of this repository involved (scripts/probes/register_then_copy_probe.py; profiles/HISTORY_design_r3.md 4.6).  Dedicated mappings, unmapped
     after unregistering, do not show it (scripts/probes/register_mmap_probe.py)."""
 
     def __init__(self, count):

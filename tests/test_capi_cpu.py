@@ -227,7 +227,7 @@ def test_every_documented_tuning_key_is_accepted_and_bounded():
 
 
 def test_the_suite_registers_only_mappings_of_its_own():
-    """regression guard for the abort of the GPU suite: hipHostRegister over glibc HEAP memory (a numpy array) is followed,
+    """regression guard for the abort of the GPU suite (profiles/HISTORY_design_r3.md 4.6): hipHostRegister over glibc HEAP memory (a numpy array) is followed,
     on the GPU boxes, by a GPU memory fault some allocations later -- with the runtime alone.  Every hipHostRegister of this suite must
     therefore go through tests/_cases.py::OwnMapping (a private mapping, registered, unregistered with the return code checked, unmapped)."""
     import re
