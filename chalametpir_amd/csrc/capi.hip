@@ -453,7 +453,8 @@ int cpir_host_gather_words(uint32_t* dst, const uint32_t* src, const uint32_t* i
 
 int cpir_host_compress_words(uint32_t* dst, const uint32_t* src, const uint8_t* bits, uint64_t s_lo, uint64_t s_hi, uint64_t* count) {
   if (!dst || !src || !bits || !count || s_lo > s_hi) return CPIR_ERR_INVALID_ARGUMENT;
-  *count = compress_words(dst, src, bits, (size_t)s_lo, (size_t)s_hi);
+  // (a 64-byte aligned destination takes the non-temporal form the arenas' staging uses, any other the plain one: both are reachable from tests)
+  *count = compress_words_streaming(dst, src, bits, (size_t)s_lo, (size_t)s_hi);
   return CPIR_OK;
 }
 

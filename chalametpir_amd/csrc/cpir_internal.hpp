@@ -79,7 +79,10 @@ struct Device {
   //   * idle_streams: a pool of plain non-blocking streams for the transient users (the upload of A in setup, the lanes of a group).
   std::mutex pool_mu;
   std::vector<hipStream_t> idle_streams;
+  static constexpr int kUpStreams = 4;
   hipStream_t up_stream = nullptr, run_stream = nullptr;
+  hipStream_t up_more[kUpStreams - 1] = {nullptr, nullptr, nullptr};  // further upload streams (tuning "respond.upload_streams")
+  uint32_t up_turn = 0;  // (guarded by upload_mu) queries take the upload streams in turn: one's copy is set up while another's crosses the link
   std::mutex upload_mu, launch_mu;
 };
 // host_respond.hip
@@ -140,6 +143,7 @@ int launch_respond_read_once(const Device* dev, const uint32_t* dtc, const cpir_
                              const PlanarHostFill* fill = nullptr);
 // steps [step_lo, step_hi) of 512 slots only (0, 0 = all): a query may be answered by several launches, each over the steps whose
 // query words are in place by then; they add up in r
+uint32_t respond_upload_streams();  // tuning "respond.upload_streams" (1..4)
 uint32_t respond_host_fill_timeout_us();  // tuning "respond.host_fill_timeout_us"; 0 = never launch in front of the copy
 bool respond_read_once_applicable(const cpir_dtc_layout& L);  // planar packing, LDS room for one response, respond.host_zero_copy on
 const char* respond_kernel_name(const cpir_dtc_layout& L);
@@ -215,6 +219,8 @@ const char* gather_words_variant();
 // [s_lo, s_hi), whose bit is set, in order; returns how many.  The AVX-512 form streams; without it callers use gather_words.
 bool compress_words_vectorised();
 size_t compress_words(uint32_t* dst, const uint32_t* src, const uint8_t* bits, size_t s_lo, size_t s_hi);
+// the same for a destination that is cold in the caches and read by the device next (non-temporal stores where the CPU and dst's alignment allow)
+size_t compress_words_streaming(uint32_t* dst, const uint32_t* src, const uint8_t* bits, size_t s_lo, size_t s_hi);
 
 // matmul.hip
 int launch_mat_x_mat(const Device* dev, const uint32_t* A, uint64_t lda, const uint32_t* D, uint64_t ldd, uint32_t* M,

@@ -25,7 +25,7 @@ class StagingHelpers {
   };
   static void copy(const Job& j) {
     const size_t n = j.bytes / 4;
-    if (j.idx && j.bits && n) (void)compress_words(static_cast<uint32_t*>(j.dst), static_cast<const uint32_t*>(j.src), j.bits, j.idx[0], (size_t)j.idx[n - 1] + 1);
+    if (j.idx && j.bits && n) (void)compress_words_streaming(static_cast<uint32_t*>(j.dst), static_cast<const uint32_t*>(j.src), j.bits, j.idx[0], (size_t)j.idx[n - 1] + 1);
     else if (j.idx) gather_words(static_cast<uint32_t*>(j.dst), static_cast<const uint32_t*>(j.src), j.idx, n);
     else memcpy(j.dst, j.src, j.bytes);
   }
@@ -122,6 +122,8 @@ void device_release(Device* d) {
     DeviceGuard g(d->ordinal);
     for (hipStream_t s : d->idle_streams) (void)hipStreamDestroy(s);
     if (d->up_stream) (void)hipStreamDestroy(d->up_stream);
+    for (hipStream_t x : d->up_more)
+      if (x) (void)hipStreamDestroy(x);
     if (d->run_stream) (void)hipStreamDestroy(d->run_stream);
     if (d->stream) (void)hipStreamDestroy(d->stream);
     delete d;
@@ -137,14 +139,20 @@ int device_host_streams(Device* d) {
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // (least, greatest): numerically greatest <= least
   hipStream_t up = nullptr, run = nullptr;
+  hipStream_t more[Device::kUpStreams - 1] = {nullptr, nullptr, nullptr};
   hipError_t e = hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
+  for (hipStream_t& x : more)
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&x, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithPriority(&run, hipStreamNonBlocking, prio_hi);
   if (e != hipSuccess) {
     set_last_hip_error(e, "hipStreamCreateWithFlags (host path)", __FILE__, __LINE__);
     if (up) (void)hipStreamDestroy(up);
+    for (hipStream_t x : more)
+      if (x) (void)hipStreamDestroy(x);
     return CPIR_ERR_HIP;
   }
   d->up_stream = up, d->run_stream = run;
+  for (int i = 0; i < Device::kUpStreams - 1; i++) d->up_more[i] = more[i];
   return CPIR_OK;
 }
 
@@ -230,11 +238,17 @@ static void arena_free(RespondArena& a) {
   a = RespondArena{};
 }
 
+static void sync_upload_streams(Device* d) {
+  if (d->up_stream) (void)hipStreamSynchronize(d->up_stream);
+  for (hipStream_t x : d->up_more)
+    if (x) (void)hipStreamSynchronize(x);
+}
+
 static void arenas_destroy(Server* srv) {
   // whatever this server enqueued on the device's shared host-path streams (a trailing memset of the response seat) must be done before
   // its blocks go (hipFree waits for the device anyway -- scripts/probes/free_sync_probe.hip -- this says it in the code)
   if (srv->run_stream) (void)hipStreamSynchronize(srv->run_stream);
-  if (srv->up_stream) (void)hipStreamSynchronize(srv->up_stream);
+  if (srv->up_stream) sync_upload_streams(srv->dev);
   for (RespondArena& a : srv->arena) arena_free(a);
   srv->up_stream = srv->run_stream = nullptr;  // (owned by the device handle)
 }
@@ -338,9 +352,10 @@ void server_destroy(Server* srv) {
   if (srv->trace_on && srv->trace.calls.load()) {
     const Server::Trace& t = srv->trace;
     const double n = (double)t.calls.load(), nb = (double)(t.batches.load() ? t.batches.load() : 1);
-    fprintf(stderr, "[cpir respond trace] %.0f calls in %.0f batches; us per call: seat wait %.1f, staging %.1f, copy out %.1f; followers wait %.1f; "
-                    "us per batch (leader): gate %.1f, enqueue %.1f, device %.1f; batch sizes",
-            n, nb, t.ns_seat.load() / n / 1e3, t.ns_stage.load() / n / 1e3, t.ns_out.load() / n / 1e3,
+    fprintf(stderr, "[cpir respond trace] %.0f calls in %.0f batches; us per call: seat wait %.1f, staging %.1f (copy / compaction %.1f, upload lock %.1f, "
+                    "copy calls %.1f where split), copy out %.1f; followers wait %.1f; us per batch (leader): gate %.1f, enqueue %.1f, device %.1f; batch sizes",
+            n, nb, t.ns_seat.load() / n / 1e3, t.ns_stage.load() / n / 1e3, t.ns_stage_copy.load() / n / 1e3, t.ns_stage_lock.load() / n / 1e3,
+            t.ns_stage_enq.load() / n / 1e3, t.ns_out.load() / n / 1e3,
             t.ns_follow.load() / (n - nb > 0 ? n - nb : 1) / 1e3, t.ns_gate.load() / nb / 1e3, t.ns_enqueue.load() / nb / 1e3, t.ns_gpu.load() / nb / 1e3);
     for (int i = 1; i <= 8; i++) fprintf(stderr, " %d:%llu", i, (unsigned long long)t.batch_hist[i].load());
     fprintf(stderr, "; served alone (query read in place) %llu, %.1f us each; of those %llu by one launch polling the copy, %u such launches gave up\n",
@@ -946,6 +961,8 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
   const bool tr = srv->trace_on;
   const double t_enter = tr ? now_seconds() : 0;
   const bool read_once_ok = respond_read_once_applicable(srv->phys);
+  const size_t q_lo = (size_t)srv->slot_offset, q_hi = q_lo + (size_t)srv->layout.num_slots;
+  const bool caller_pinned = pinned_range_device_pointer(q + q_lo, (q_hi - q_lo) * 4) != nullptr;
   std::unique_lock<std::mutex> lk(srv->mu);
   RespondArena* a = nullptr;
   bool solo = false;
@@ -957,6 +974,7 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
         if (!a && x.state == RespondArena::FREE) {
           if (!x.q_dev) CPIR_TRY(arena_create(srv, x));
           a = &x, x.state = RespondArena::OPEN, x.status = CPIR_OK;
+          x.compact_seats = srv->map.active() && !caller_pinned;  // (see RespondArena)
           // nobody else is filling an arena or on the device, and no company expected (with recent concurrent callers a lone launch
           // would only split the batch they are about to form): this caller is served alone, its query read in place
           solo = read_once_ok && srv->spread() == 1;
@@ -972,6 +990,7 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
   }
   const uint32_t seat = a->joined++;
   const bool leader = (seat == 0);
+  const bool compact = a->compact_seats;
   srv->caller_enters();
   lk.unlock();
   const double t_seated = tr ? now_seconds() : 0;
@@ -991,19 +1010,80 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
 
   // ---- stage the query (the reference copies too: from_bytes .to_vec(), matrix.rs:1001-1007) and enqueue its upload -----------------
   // (a shard reads only its own slots of the query: only those are staged and uploaded)
+  // (two upload streams taken in turn, query by query: a copy costs the copy engine ~15 us of set-up whatever its size, which one stream
+  // pays between two queries' 83 us on the link and two streams overlap)
   hipError_t up = hipSuccess;
-  const size_t q_lo = (size_t)srv->slot_offset, q_hi = q_lo + (size_t)srv->layout.num_slots;
+  hipStream_t ups = nullptr;
+  const uint32_t n_ups = respond_upload_streams();
+  auto take_upload_stream = [&] {  // under upload_mu
+    const uint32_t t = srv->dev->up_turn++ % n_ups;
+    ups = t ? srv->dev->up_more[t - 1] : srv->up_stream;
+  };
   uint32_t* const qd = a->q_dev + seat * N;
-  if (pinned_range_device_pointer(q + q_lo, (q_hi - q_lo) * 4) != nullptr) {
+  if (compact) {
+    // A server that holds only the slots with a non-zero row: the query is COMPACTED onto them while it is staged (host_gather.cpp: one
+    // sequential pass over the source through the bitmap of the kept slots, about the cost of the memcpy it replaces), so the link carries
+    // n_kept of the N words -- 8/9 for a real encoded database -- and the launch needs no map.  In source pieces of 1 MiB where nobody
+    // else is uploading (the DMA of one piece runs while the next is compacted), else whole and uploaded when the link is this query's.
+    const SlotMap& m = srv->map;
+    uint32_t* const qp = a->q_pinned + seat * N;              // (room for N words; n_kept are written)
+    uint32_t* const qcd = a->q_compact + seat * m.n_pad;      // the seat's compact query on the device
+    const uint32_t* const src = q + q_lo;
+    const size_t n_orig = (size_t)m.n_orig;
+    // (every upload starts on a 256-byte boundary of the seat and is a whole number of 64 words long -- the last one runs to n_pad, whose
+    // words behind n_kept nobody reads: copies with ragged ends take the runtime's slow path)
+    const size_t n_pad = (size_t)m.n_pad;
+    std::unique_lock<std::mutex> ul(srv->dev->upload_mu, std::try_to_lock);
+    double tc = 0, tl = 0, te = 0, t0 = tr ? now_seconds() : 0;  // (trace: compaction / waiting for the link's turn / the runtime's copy calls)
+    auto lap = [&](double& acc) {
+      if (tr) {
+        const double t1 = now_seconds();
+        acc += t1 - t0, t0 = t1;
+      }
+    };
+    if (!compress_words_vectorised()) {
+      gather_words(qp, src, m.keep_host.data(), (size_t)m.n_kept);
+      lap(tc);
+      if (!ul.owns_lock()) ul.lock();
+      lap(tl);
+      take_upload_stream();
+      up = hipMemcpyAsync(qcd, qp, n_pad * 4, hipMemcpyHostToDevice, ups);
+      lap(te);
+    } else if (ul.owns_lock()) {
+      take_upload_stream();
+      const size_t piece = (size_t)1 << 18;
+      size_t out = 0, sent = 0;
+      for (size_t o = 0; o < n_orig && up == hipSuccess; o += piece) {
+        const bool last = o + piece >= n_orig;
+        out += compress_words_streaming(qp + out, src, m.keep_bits.data(), o, last ? n_orig : o + piece);
+        lap(tc);
+        const size_t upto = last ? n_pad : (out & ~(size_t)63);
+        if (upto > sent) up = hipMemcpyAsync(qcd + sent, qp + sent, (upto - sent) * 4, hipMemcpyHostToDevice, ups), sent = upto;
+        lap(te);
+      }
+    } else {
+      (void)compress_words_streaming(qp, src, m.keep_bits.data(), 0, n_orig);
+      lap(tc);
+      ul.lock();
+      lap(tl);
+      take_upload_stream();
+      up = hipMemcpyAsync(qcd, qp, n_pad * 4, hipMemcpyHostToDevice, ups);
+      lap(te);
+    }
+    if (up == hipSuccess) up = hipEventRecord(a->seat_ev[seat], ups);
+    if (tr) srv->trace.ns_stage_copy += (uint64_t)(tc * 1e9), srv->trace.ns_stage_lock += (uint64_t)(tl * 1e9), srv->trace.ns_stage_enq += (uint64_t)(te * 1e9);
+  } else if (caller_pinned) {
     // the caller's buffer is page-locked already (cpir_host_alloc, hipHostMalloc, hipHostRegister): DMA straight from it
     std::lock_guard<std::mutex> ul(srv->dev->upload_mu);
-    up = hipMemcpyAsync(qd + q_lo, q + q_lo, (q_hi - q_lo) * 4, hipMemcpyHostToDevice, srv->up_stream);
-    if (up == hipSuccess) up = hipEventRecord(a->seat_ev[seat], srv->up_stream);
+    take_upload_stream();
+    up = hipMemcpyAsync(qd + q_lo, q + q_lo, (q_hi - q_lo) * 4, hipMemcpyHostToDevice, ups);
+    if (up == hipSuccess) up = hipEventRecord(a->seat_ev[seat], ups);
   } else {
     uint32_t* const qp = a->q_pinned + seat * N;
     const size_t piece = (size_t)1 << 18;  // 1 MiB of u32
     std::unique_lock<std::mutex> ul(srv->dev->upload_mu, std::try_to_lock);
     if (ul.owns_lock()) {
+      take_upload_stream();
       // nobody else is uploading: in pieces, so that the DMA of one piece runs while the next ones are being copied into the pinned
       // block -- by this thread and, when they are free, by the staging helpers; the pieces are uploaded in order as they complete
       // (each copy costs the copy engine ~15 us whatever its size, so with helpers the query goes up in TWO halves, each copied by all
@@ -1032,27 +1112,32 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
                   __builtin_ia32_pause();
 #endif
                 }
-            if (up == hipSuccess) up = hipMemcpyAsync(qd + o_lo, qp + o_lo, (o_hi - o_lo) * 4, hipMemcpyHostToDevice, srv->up_stream);
+            if (up == hipSuccess) up = hipMemcpyAsync(qd + o_lo, qp + o_lo, (o_hi - o_lo) * 4, hipMemcpyHostToDevice, ups);
           }
         } else {
           memcpy(qp + q_lo, q + q_lo, words * 4);
-          up = hipMemcpyAsync(qd + q_lo, qp + q_lo, words * 4, hipMemcpyHostToDevice, srv->up_stream);
+          up = hipMemcpyAsync(qd + q_lo, qp + q_lo, words * 4, hipMemcpyHostToDevice, ups);
         }
         g_staging.release();
       } else {
         for (size_t o = q_lo; o < q_hi && up == hipSuccess; o += piece) {
           const size_t n = (q_hi - o < piece) ? q_hi - o : piece;
           memcpy(qp + o, q + o, n * 4);
-          up = hipMemcpyAsync(qd + o, qp + o, n * 4, hipMemcpyHostToDevice, srv->up_stream);
+          up = hipMemcpyAsync(qd + o, qp + o, n * 4, hipMemcpyHostToDevice, ups);
         }
       }
     } else {
       // the link is busy with somebody else's query: copy while waiting, then upload in one piece when it is this query's turn
+      const double t0 = tr ? now_seconds() : 0;
       memcpy(qp + q_lo, q + q_lo, (q_hi - q_lo) * 4);
+      const double t1 = tr ? now_seconds() : 0;
       ul.lock();
-      up = hipMemcpyAsync(qd + q_lo, qp + q_lo, (q_hi - q_lo) * 4, hipMemcpyHostToDevice, srv->up_stream);
+      const double t2 = tr ? now_seconds() : 0;
+      take_upload_stream();
+      up = hipMemcpyAsync(qd + q_lo, qp + q_lo, (q_hi - q_lo) * 4, hipMemcpyHostToDevice, ups);
+      if (tr) srv->trace.ns_stage_copy += (uint64_t)((t1 - t0) * 1e9), srv->trace.ns_stage_lock += (uint64_t)((t2 - t1) * 1e9), srv->trace.ns_stage_enq += (uint64_t)((now_seconds() - t2) * 1e9);
     }
-    if (up == hipSuccess) up = hipEventRecord(a->seat_ev[seat], srv->up_stream);
+    if (up == hipSuccess) up = hipEventRecord(a->seat_ev[seat], ups);
   }
   if (up != hipSuccess) set_last_hip_error(up, "hipMemcpyAsync(query upload)", __FILE__, __LINE__);
 
@@ -1100,7 +1185,8 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
       for (uint32_t i = 0; i < k && e == hipSuccess; i++) e = hipStreamWaitEvent(srv->run_stream, a->seat_ev[i], 0);
       a->r0_zero = false;
       if (e == hipSuccess)
-        st = server_respond_on_device(srv, a->q_dev, srv->total_slots, srv->slot_offset, k, false, a->r_dev, nullptr, a->q_compact, srv->run_stream);
+        st = compact ? respond_batched(srv->dev, srv->dtc, srv->phys, a->q_compact, srv->map.n_pad, 0, k, a->r_dev, nullptr, srv->run_stream)
+                     : server_respond_on_device(srv, a->q_dev, srv->total_slots, srv->slot_offset, k, false, a->r_dev, nullptr, a->q_compact, srv->run_stream);
       if (e == hipSuccess && st == CPIR_OK) e = hipMemcpyAsync(a->r_pinned, a->r_dev, (size_t)k * C * 4, hipMemcpyDeviceToHost, srv->run_stream);
       if (e == hipSuccess) e = hipEventRecord(a->done_ev, srv->run_stream);
     }
@@ -1110,7 +1196,7 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
     if (st == CPIR_OK && e == hipSuccess) {
       e2 = wait_for_event(a->done_ev);
     } else {
-      (void)hipStreamSynchronize(srv->up_stream);
+      sync_upload_streams(srv->dev);
       (void)hipStreamSynchronize(srv->run_stream);
     }
     if (e == hipSuccess) e = e2;

@@ -48,6 +48,10 @@ struct RespondArena {
   uint32_t* handed_dev = nullptr;
   uint32_t hand_seq = 0;                   // (guarded like r0_zero: one lone caller per arena at a time)
   bool r0_zero = false;                    // seat 0 of r_dev holds zeros (guarded by the arena's own leader: one at a time)
+  // (servers with a slot map) the seats of this round hold COMPACT queries -- every caller compacts its query onto the kept slots while it
+  // stages it, uploads 8/9 of the words into q_compact, and the launch needs no map -- or whole ones (DMA straight from page-locked caller
+  // buffers, the kernel applies the map).  Decided by the caller that opens the arena, the same for all its seats; guarded by Server::mu.
+  bool compact_seats = false;
   // guarded by Server::mu
   enum State { FREE, OPEN, LAUNCHED, DONE } state = FREE;
   uint32_t joined = 0;  // seats taken
@@ -110,6 +114,7 @@ struct Server {
   // CPIR_RESPOND_TRACE=1: per-phase wall time of the host path, printed when the server is destroyed (diagnosis)
   struct Trace {
     std::atomic<uint64_t> calls{0}, solo{0}, ns_solo{0}, batches{0}, ns_seat{0}, ns_stage{0}, ns_gate{0}, ns_enqueue{0}, ns_gpu{0}, ns_follow{0}, ns_out{0};
+    std::atomic<uint64_t> ns_stage_copy{0}, ns_stage_lock{0}, ns_stage_enq{0};  // staging split: host copy / compaction, waiting for the upload lock, the runtime's copy calls
     std::atomic<uint64_t> batch_hist[9] = {};
     // a lone caller whose query is staged under a polled launch: until the jobs are with the helpers / until the launch call is back /
     // until the last job is published / until the response is there

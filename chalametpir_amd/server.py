@@ -282,15 +282,21 @@ def host_gather(src: np.ndarray, idx: np.ndarray) -> np.ndarray:
     return out
 
 
-def host_compress(src: np.ndarray, keep_mask: np.ndarray, s_lo: int = 0, s_hi: Optional[int] = None) -> np.ndarray:
-    """src[s] for s in [s_lo, s_hi) with keep_mask[s] set, through the library's streaming compaction (cpir_host_compress_words)"""
+def host_compress(src: np.ndarray, keep_mask: np.ndarray, s_lo: int = 0, s_hi: Optional[int] = None, *, dst_misalign_words: int = 0) -> np.ndarray:
+    """src[s] for s in [s_lo, s_hi) with keep_mask[s] set, through the library's streaming compaction (cpir_host_compress_words).  The
+    destination starts `dst_misalign_words` words past a 64-byte boundary: 0 takes the non-temporal form (what the arenas' staging blocks
+    get), anything else the plain one.  The words around the output are checked for not having been touched."""
     src = np.ascontiguousarray(src, dtype=np.uint32)
     s_hi = src.size if s_hi is None else s_hi
     bits = np.concatenate([np.packbits(np.asarray(keep_mask, dtype=bool), bitorder="little"), np.zeros(8, dtype=np.uint8)])
-    out = np.empty(max(1, s_hi - s_lo), dtype=np.uint32)
+    cap = max(1, s_hi - s_lo)
+    raw = np.full(cap + 64, 0xA5A5A5A5, dtype=np.uint32)
+    off = (-(raw.ctypes.data // 4)) % 16 + 16 + dst_misalign_words  # a 64-byte boundary of the buffer, a guard of 16 words in front
     n = C.c_uint64()
-    _check(_native.load().cpir_host_compress_words(_ptr(out), _ptr(src), bits.ctypes.data, s_lo, s_hi, C.byref(n)))
-    return out[: n.value].copy()
+    _check(_native.load().cpir_host_compress_words(raw.ctypes.data + 4 * off, _ptr(src), bits.ctypes.data, s_lo, s_hi, C.byref(n)))
+    if not (np.all(raw[:off] == 0xA5A5A5A5) and np.all(raw[off + n.value:] == 0xA5A5A5A5)):
+        raise AssertionError("host compaction wrote outside its output range")
+    return raw[off: off + n.value].copy()
 
 
 def host_gather_variant() -> str:

@@ -100,6 +100,14 @@ int main(int argc, char** argv) {
     for (uint32_t f = 0; f < cf; f++) w |= ((uint32_t)(x >> (16 * f)) & fmask) << (f * S);
     dtc[i] = w;
   }
+  /* CPIR_BENCH_HOLES=K: every K-th slot (pseudo-randomly) holds nothing in any column, like the rows of a real encoded database that no
+   * key owns (one in nine at arity 3): the server then leaves them out of its image and compacts every query onto the others */
+  if (getenv("CPIR_BENCH_HOLES")) {
+    const uint64_t K = strtoull(getenv("CPIR_BENCH_HOLES"), NULL, 10);
+    for (uint64_t n = 0; K && n < g_N; n++)
+      if (mix(n ^ 0xabcdefull) % K == 0)
+        for (uint32_t c = 0; c < g_C; c++) dtc[(uint64_t)c * W + n / cf] &= ~(((1u << S) - 1u) << ((n % cf) * S));
+  }
   if (g_N % cf) /* fields past the last slot are zero */
     for (uint32_t c = 0; c < g_C; c++) dtc[(uint64_t)c * W + W - 1] &= (1u << ((g_N % cf) * S)) - 1u;
   CHECK(cpir_server_from_compressed(dev, dtc, g_C, g_N, b, &g_srv));
@@ -120,6 +128,19 @@ int main(int argc, char** argv) {
     memcpy(g_qp[k], g_q[k], 4 * g_N);
     g_want[k] = (uint32_t*)malloc(4 * (size_t)g_C);
     CHECK(cpir_server_respond(g_srv, g_q[k], 1, g_N, g_want[k]));
+  }
+  /* 4th argument "tT" (e.g. t16) + 5th 0 / 1: ONLY T closed-loop callers with pageable / page-locked queries, three rounds (with
+   * CPIR_RESPOND_TRACE=1 the library prints where their time went when the server is released) */
+  if (argc > 4 && argv[4][0] == 't') {
+    const int T = atoi(argv[4] + 1), pinned = argc > 5 ? atoi(argv[5]) : 0;
+    if (argc > 6) CHECK(cpir_tuning_set("respond.upload_streams", atoi(argv[6])));
+    (void)run(T, 4, pinned);
+    printf("{\"callers\": %d, \"pinned\": %d, \"queries_per_sec\": [", T, pinned);
+    for (int r = 0; r < 3; r++) printf("%s%.0f", r ? ", " : "", run(T, 960 / T, pinned));
+    printf("], \"mismatches\": %d}\n", g_bad);
+    cpir_server_release(g_srv);
+    cpir_device_close(dev);
+    return g_bad ? 2 : 0;
   }
   const int lone_only = argc > 4 && !strcmp(argv[4], "lone"); /* 4th argument "lone": the single-caller latencies only */
   const int lone = 200;
@@ -143,7 +164,7 @@ int main(int argc, char** argv) {
          lg, (unsigned long long)value_bytes, arity, (unsigned long long)g_N, g_C, b, (unsigned long long)(4 * g_N), lone_pageable, lone_pinned);
   const int threads[] = {2, 4, 8, 16};
   for (int i = 0; i < 4 && !lone_only; i++) {
-    const int T = threads[i], calls = 640 / T;
+    const int T = threads[i], calls = 1920 / T;
     const double qp = run(T, calls, 0), qn = run(T, calls, 1);
     printf(", \"callers_%d_queries_per_sec\": %.0f, \"callers_%d_pinned_queries_per_sec\": %.0f", T, qp, T, qn);
   }

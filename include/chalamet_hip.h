@@ -257,6 +257,8 @@ int cpir_op_synth_fill(cpir_device* dev, uint32_t* out, uint64_t count, uint64_t
  *   device-resident queries: 1 -- the default -- every launch runs on the wide kernel (1 .. 24 queries per pass, one 8-wave block per CU,
  *   passes in slice or interleaved order) and the step-major kernel serves the in-place host path only; 2 the step-major kernel wherever
  *   it applies, i.e. passes of up to 4 queries in slice order -- tests and A/B runs; 3 as 2, launched as the in-place host path launches it),
+ *   "respond.upload_streams" 1..4 (concurrent host callers: their query uploads take this many HIP streams in turn, so that one copy is
+ *   set up while another crosses the link; default 2),
  *   "respond.host_zero_copy" {0,1}
  *   (1, the default: cpir_server_respond serves a caller that finds the server idle without an upload, the kernel reading the
  *   query in place from page-locked host memory; 0: always stage + upload first), "respond.host_fill_timeout_us" 0..1000000

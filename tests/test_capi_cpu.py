@@ -254,9 +254,10 @@ def test_host_gather_variants_agree(native):
         assert np.array_equal(cp.host_gather(src, idx), src[idx]), count
     assert cp.host_gather_variant() in ("scalar", "avx2", "avx512", "avx512-compress")
     # the streaming form: a bitmap over the source, any [s_lo, s_hi) window (copy jobs start and end at arbitrary source words)
-    for n in (1, 15, 16, 17, 1000, 100003):
+    for n in (1, 15, 16, 17, 1000, 4096, 4607, 9000, 100003):  # (around the streaming form's 4 096-word buffer too)
         keep = rng.random(n) < 0.89
         assert np.array_equal(cp.host_compress(src[:n], keep), src[:n][keep]), n
+        assert np.array_equal(cp.host_compress(src[:n], keep, dst_misalign_words=3), src[:n][keep]), n  # (the plain form: an unaligned destination)
         for _ in range(4):
             lo = int(rng.integers(0, n))
             hi = int(rng.integers(lo, n + 1))
