@@ -184,7 +184,10 @@ def use_library(path: str) -> None:
 def use_diag_build() -> str:
     """Tuning scripts only: build (if need be) and bind the diagnosis build of the library; returns its path."""
     path = os.path.join(_PKG, "lib", "diag", "libchalamet_hip.so")
-    subprocess.run(["make", "-C", CSRC_DIR, "-s", "diag"], check=True)
+    # (the library travels to the GPU box, its objects do not: make would rebuild everything there -- two minutes -- although nothing changed)
+    sources = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith((".hip", ".cpp", ".hpp"))] + [HEADER_PATH]
+    if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in sources):
+        subprocess.run(["make", "-C", CSRC_DIR, "-s", "-j8", "diag"], check=True)
     use_library(path)
     return path
 

@@ -479,7 +479,11 @@ constexpr int kWThreads = 512;
 constexpr int kWM = 8;        // column tiles per work unit = waves per block
 constexpr int kWMaxSets = 6;  // row sets of 4 queries
 
-template <int HB, bool NT, bool MAP>
+// EMU32 (a -DCPIR_DIAG build only, responses WRONG): the row sets are taken two at a time and each pair's two 16x16x64 MFMAs replaced by ONE
+// v_mfma_i32_32x32x32_i8 on the first set's fragment -- the same number of byte products per tile, half the fragment reads and half the
+// operand bytes per product, 16 accumulator registers per product instead of 4: what a 32-column image layout would make of the matrix
+// cores' and the LDS's share of a fused pass, measured without building that layout (scripts/wide_ablate.py, CPIR_WIDE_ABLATE bit 8).
+template <int HB, bool NT, bool MAP, bool EMU32 = false>
 __global__ void __launch_bounds__(kWThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 respond_planar_wide_kernel(const PlanarArgs a) {
   constexpr int NL = 8 + HB;
@@ -801,9 +805,46 @@ respond_planar_wide_kernel(const PlanarArgs a) {
         val += 128u * qsum + base_term;  // 128 * 0x80808080 = 0x40404000 mod 2^32
         atomicAdd(rcol + qq * cpad, query < nq ? val : 0u);  // LDS; this wave owns tile T of the step
       };
-      row_set(0u, std::integral_constant<bool, kPeel>{});
+      if constexpr (!EMU32) {
+        row_set(0u, std::integral_constant<bool, kPeel>{});
 #pragma unroll 1
-      for (uint32_t s = 1; s < ns; s++) row_set(s, std::false_type{});
+        for (uint32_t s = 1; s < ns; s++) row_set(s, std::false_type{});
+      } else {
+        typedef int v16i __attribute__((ext_vector_type(16)));
+        if constexpr (HB > 0 && kPeel) {
+#pragma unroll
+          for (int kb = 0; kb < 8; kb++)
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+              uint32_t x = 0;
+#pragma unroll
+              for (int p = 0; p < HB; p++) x += ((comp(cur[8 + p], kb >> 1) >> (4 * (kb & 1) + d)) & 0x01010101u) << p;
+              hbv[kb][d] = (int)x;
+            }
+        }
+#pragma unroll 1
+        for (uint32_t s = 0; s < ns; s += 2) {
+          const uint4* const ap = abuf + (s + 2 < ns ? s + 2 : s) * 512 + lane;
+          const uint32_t query = 4 * s + grp, qq = query < nq ? query : nq - 1;
+          const uint32_t qsum = qs[par * 32 + qq];
+          v16i acc_lo = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc_hi = acc_lo;
+#pragma unroll
+          for (int kb = 0; kb < 8; kb++) {
+            acc_lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(as_v4i(f[kb]), as_v4i(cur[kb]), acc_lo, 0, 0, 0);
+            if constexpr (HB > 0) acc_hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(as_v4i(f[kb]), hbv[kb], acc_hi, 0, 0, 0);
+            f[kb] = ap[kb * 64];
+          }
+          uint32_t val = 0, val2 = 0;
+#pragma unroll
+          for (int i = 0; i < 8; i++) val += ((uint32_t)acc_lo[i] + ((uint32_t)acc_hi[i] << 8)) << (8 * (i & 3));
+#pragma unroll
+          for (int i = 8; i < 16; i++) val2 += ((uint32_t)acc_lo[i] + ((uint32_t)acc_hi[i] << 8)) << (8 * (i & 3));
+          val += 128u * qsum + base_term;
+          atomicAdd(rcol + qq * cpad, query < nq ? val : 0u);
+          const uint32_t query2 = query + 4, qq2 = query2 < nq ? query2 : nq - 1;
+          atomicAdd(rcol + qq2 * cpad, query2 < nq ? val2 + base_term : 0u);  // (the pair's second set: as many LDS atomics as the real kernel)
+        }
+      }
     }
     first_of_visit = false;
     if (last_of_visit) {
@@ -1087,6 +1128,7 @@ int launch_respond_planar_wide(const Device* dev, const uint32_t* dtc, const cpi
   }();
   a.ablate = ablate_env;
   a.trace = nullptr;
+  if ((ablate_env & 8u) && hb == 1 && nt && !keep) fn = respond_planar_wide_kernel<1, true, false, true>;  // (the 32x32x32 emulation: see the kernel)
 #endif
   a.keep = keep;  // (device memory, at least L.num_slots entries, 16-byte aligned; the caller has checked that the slots it names lie inside q)
   if (keep && reinterpret_cast<uintptr_t>(keep) % 16 != 0) return CPIR_ERR_INVALID_ARGUMENT;
