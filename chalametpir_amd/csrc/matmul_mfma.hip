@@ -481,9 +481,23 @@ __device__ __forceinline__ void pipe_store_quad(const MfmaArgs& a, const PipeLan
 // SIMD run in lockstep between barriers: left to itself the compiler issues the 14 MFMAs of a group back to back and both waves then
 // convert at the same time, with the matrix pipe idle).  LDS reads may still move across the pins (the next group's A fragments).
 // (x, y, z, w) = the quad; wbase = where limb 0 of this lane's dword goes; limbs i are 256 dwords apart.
-template <bool SUM>
-__device__ __forceinline__ void mfma_group_with_conversion(v4i (&acc)[2][4], const v4i (&af)[4], const v4i (&bf)[2][2], uint32_t x, uint32_t y,
-                                                           uint32_t z, uint32_t w, uint32_t* wbase, bool store, bool rin, uint32_t& rs) {
+// A wave's 128 accumulator registers: [row tile of 16][column tile of 16][shift s] v4i for v_mfma_i32_16x16x64_i8.  EMU32 (a -DCPIR_DIAG build
+// only, hints WRONG): the same 128 registers as [pair of row tiles][shift s] v16i, every pair of 16x16x64 MFMAs replaced by ONE
+// v_mfma_i32_32x32x32_i8 -- the same byte products, operand fetches and register count per k-step, half as many matrix instructions of twice
+// the length: what the instruction SHAPE alone changes (cpir_tuning_set("matmul.ablate", 16), scripts/setup_kernels_timing.py).
+typedef int v16i __attribute__((ext_vector_type(16)));
+template <bool EMU32>
+struct MfmaAcc {
+  v4i a[4][2][4];
+};
+template <>
+struct MfmaAcc<true> {
+  v16i a[2][4];
+};
+
+template <bool SUM, bool EMU32>
+__device__ __forceinline__ void mfma_group_with_conversion(MfmaAcc<EMU32>& accs, const int m, const v4i (&af)[4], const v4i (&bf)[2][2], uint32_t x,
+                                                           uint32_t y, uint32_t z, uint32_t w, uint32_t* wbase, bool store, bool rin, uint32_t& rs) {
   uint32_t pa = 0, pb = 0, pc = 0, pd = 0, l0 = 0, l1 = 0, l2 = 0, l3 = 0, r1 = 0, r2 = 0;
   auto micro = [&](int k) {
     switch (k) {
@@ -512,25 +526,38 @@ __device__ __forceinline__ void mfma_group_with_conversion(v4i (&acc)[2][4], con
       default: break;
     }
   };
+  if constexpr (!EMU32) {
 #pragma unroll
-  for (int n = 0; n < 2; n++)
+    for (int n = 0; n < 2; n++)
 #pragma unroll
-    for (int q = 0; q < 7; q++) {
-      const int sidx = q < 4 ? q : q - 3, ai = q < 4 ? q : q - 4, bj = q < 4 ? 0 : 1, step = n * 7 + q;
-      acc[n][sidx] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[ai], bf[n][bj], acc[n][sidx], 0, 0, 0);
-      if (step < 9) {
-        __builtin_amdgcn_sched_barrier(0x100);
-        micro(2 * step);
-        micro(2 * step + 1);
-        __builtin_amdgcn_sched_barrier(0x100);
+      for (int q = 0; q < 7; q++) {
+        const int sidx = q < 4 ? q : q - 3, ai = q < 4 ? q : q - 4, bj = q < 4 ? 0 : 1, step = n * 7 + q;
+        accs.a[m][n][sidx] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[ai], bf[n][bj], accs.a[m][n][sidx], 0, 0, 0);
+        if (step < 9) {
+          __builtin_amdgcn_sched_barrier(0x100);
+          micro(2 * step);
+          micro(2 * step + 1);
+          __builtin_amdgcn_sched_barrier(0x100);
+        }
       }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 7; q++) {  // seven 32-pass MFMAs, the 18 micro-operations spread 3, 3, 3, 3, 2, 2, 2 behind them
+      const int sidx = q < 4 ? q : q - 3, ai = q < 4 ? q : q - 4, bj = q < 4 ? 0 : 1;
+      accs.a[m >> 1][sidx] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ai], bf[m & 1][bj], accs.a[m >> 1][sidx], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0x100);
+      const int first = q < 4 ? 3 * q : 12 + 2 * (q - 4), count = q < 4 ? 3 : 2;
+#pragma unroll
+      for (int t = 0; t < count; t++) micro(first + t);
+      __builtin_amdgcn_sched_barrier(0x100);
     }
+  }
 }
 
 // One (row tile, column tile, K sub-range) unit for one wave.  Register set S0 carries the even k-steps (relative to k0), S1 the odd ones.
-template <bool SUM, int RHS>
+template <bool SUM, int RHS, bool EMU32>
 __device__ __forceinline__ void mfma_pipe_unit(const MfmaArgs& a, const PipeLane& pl, PipeUnit& u, uint4* lds, uint32_t lds_b0, uint32_t lane,
-                                               uint32_t wave, uint32_t k0, uint32_t T, v4i (&acc)[4][2][4]) {
+                                               uint32_t wave, uint32_t k0, uint32_t T, MfmaAcc<EMU32>& acc) {
   constexpr bool PLANAR = RHS != kRhsPlanes;
   constexpr bool BIT = RHS == kRhsImageBit;
   const uint32_t wm = wave >> 2, wn = wave & 3;
@@ -603,7 +630,7 @@ __device__ __forceinline__ void mfma_pipe_unit(const MfmaArgs& a, const PipeLane
       }
       uint32_t* const wbase = reinterpret_cast<uint32_t*>(lds + ((t + 1) & 1) * kPiecesA * 64) + pl.wdw[m];
       const bool rin = conv && u.rvalid[m] && (uint64_t)(k0 + t + 1) * kBK + pl.kq[m] < a.inner;
-      mfma_group_with_conversion<SUM>(acc[m], af, bf, (uint32_t)set[m][0], (uint32_t)set[m][1], (uint32_t)set[m][2], (uint32_t)set[m][3], wbase,
+      mfma_group_with_conversion<SUM, EMU32>(acc, m, af, bf, (uint32_t)set[m][0], (uint32_t)set[m][1], (uint32_t)set[m][2], (uint32_t)set[m][3], wbase,
                                       conv, rin, u.rs[m]);
       if (conv && t + 3 < T) pipe_load_quad(a, pl, u, set[m], m, k0 + t + 3);
     }
@@ -700,7 +727,7 @@ __device__ __forceinline__ void mfma_pipe_unit(const MfmaArgs& a, const PipeLane
           }
         }
         uint32_t* const wbase = reinterpret_cast<uint32_t*>(lds + a_par * kPiecesA * 64) + pl.wdw[m];
-        mfma_group_with_conversion<SUM>(acc[m], af, bf, (uint32_t)set[m][0], (uint32_t)set[m][1], (uint32_t)set[m][2], (uint32_t)set[m][3],
+        mfma_group_with_conversion<SUM, EMU32>(acc, m, af, bf, (uint32_t)set[m][0], (uint32_t)set[m][1], (uint32_t)set[m][2], (uint32_t)set[m][3],
                                         wbase, true, u.rvalid[m], u.rs[m]);
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(set[m]) : "v"(aoffq[m]), "s"(a_run) : "memory");
       }
@@ -738,7 +765,7 @@ __device__ __forceinline__ void mfma_pipe_unit(const MfmaArgs& a, const PipeLane
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int RHS>
+template <int RHS, bool EMU32 = false>
 __global__ void __launch_bounds__(kMT) __attribute__((amdgpu_waves_per_eu(2, 2))) mat_x_mat_mfma_pipe_kernel(const MfmaArgs a) {
   constexpr bool PLANAR = RHS != kRhsPlanes;
   __shared__ uint4 lds[kPipePieces * 64];
@@ -791,16 +818,23 @@ __global__ void __launch_bounds__(kMT) __attribute__((amdgpu_waves_per_eu(2, 2))
       u.rs[j] = 0;
     }
 
-    v4i acc[4][2][4];
+    MfmaAcc<EMU32> acc;
+    if constexpr (!EMU32) {
 #pragma unroll
-    for (int m = 0; m < 4; m++)
+      for (int m = 0; m < 4; m++)
 #pragma unroll
-      for (int n = 0; n < 2; n++)
+        for (int n = 0; n < 2; n++)
 #pragma unroll
-        for (int s2 = 0; s2 < 4; s2++) acc[m][n][s2] = v4i{0, 0, 0, 0};
+          for (int s2 = 0; s2 < 4; s2++) acc.a[m][n][s2] = v4i{0, 0, 0, 0};
+    } else {
+#pragma unroll
+      for (int mp = 0; mp < 2; mp++)
+#pragma unroll
+        for (int s2 = 0; s2 < 4; s2++) acc.a[mp][s2] = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    }
 
-    if (u.sum_rows) mfma_pipe_unit<true, RHS>(a, pl, u, lds, lds_b0, lane, wave, k0, k1 - k0, acc);
-    else mfma_pipe_unit<false, RHS>(a, pl, u, lds, lds_b0, lane, wave, k0, k1 - k0, acc);
+    if (u.sum_rows) mfma_pipe_unit<true, RHS, EMU32>(a, pl, u, lds, lds_b0, lane, wave, k0, k1 - k0, acc);
+    else mfma_pipe_unit<false, RHS, EMU32>(a, pl, u, lds, lds_b0, lane, wave, k0, k1 - k0, acc);
 
     // ---- this unit's part of the output tile: sum_s acc_s << 8s, one u32 atomic per element ----
     const uint32_t fr = lane & 15, fq = lane >> 4;
@@ -812,8 +846,13 @@ __global__ void __launch_bounds__(kMT) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           const uint64_t r = (uint64_t)rt * kBM + wm * 64 + m * 16 + fq * 4 + i;
-          const uint32_t v = (uint32_t)acc[m][n][0][i] + ((uint32_t)acc[m][n][1][i] << 8) + ((uint32_t)acc[m][n][2][i] << 16) +
-                             ((uint32_t)acc[m][n][3][i] << 24);
+          uint32_t v;
+          if constexpr (!EMU32) {
+            v = (uint32_t)acc.a[m][n][0][i] + ((uint32_t)acc.a[m][n][1][i] << 8) + ((uint32_t)acc.a[m][n][2][i] << 16) + ((uint32_t)acc.a[m][n][3][i] << 24);
+          } else {  // (the emulation's values mean nothing: every register still leaves through one atomic)
+            const int e = (m & 1) * 8 + n * 4 + i;
+            v = (uint32_t)acc.a[m >> 1][0][e] + ((uint32_t)acc.a[m >> 1][1][e] << 8) + ((uint32_t)acc.a[m >> 1][2][e] << 16) + ((uint32_t)acc.a[m >> 1][3][e] << 24);
+          }
           if (r < a.rows && c < a.cols) atomicAdd(a.M + r * a.ldm + c, v);
         }
       }
@@ -963,6 +1002,13 @@ static int launch_product(const Device* dev, MfmaArgs& a, const uint32_t* colsum
   if (!pipe && a.lo_tiles) return CPIR_ERR_INVALID_ARGUMENT;  // only the pipelined kernel reads the planar image (callers ask mfma_planar_rhs_applicable first)
   CPIR_HIP_TRY(hipMemsetAsync(a.rowsum, 0, 4 * round_up((uint32_t)rows, kBM), stream));
   if (!accumulate) CPIR_HIP_TRY(hipMemset2DAsync(M, ldm * sizeof(uint32_t), 0, cols * sizeof(uint32_t), rows, stream));
+#ifdef CPIR_DIAG
+  if (pipe && (a.ablate & 16u)) {  // the 32x32x32 emulation (see MfmaAcc)
+    if (a.lo_tiles && !a.hi_plane) hipLaunchKernelGGL((mat_x_mat_mfma_pipe_kernel<kRhsImageBit, true>), dim3(grid), dim3(kMT), 0, stream, a);
+    else if (a.lo_tiles) hipLaunchKernelGGL((mat_x_mat_mfma_pipe_kernel<kRhsImage, true>), dim3(grid), dim3(kMT), 0, stream, a);
+    else hipLaunchKernelGGL((mat_x_mat_mfma_pipe_kernel<kRhsPlanes, true>), dim3(grid), dim3(kMT), 0, stream, a);
+  } else
+#endif
   if (pipe && a.lo_tiles && !a.hi_plane) hipLaunchKernelGGL(mat_x_mat_mfma_pipe_kernel<kRhsImageBit>, dim3(grid), dim3(kMT), 0, stream, a);
   else if (pipe && a.lo_tiles) hipLaunchKernelGGL(mat_x_mat_mfma_pipe_kernel<kRhsImage>, dim3(grid), dim3(kMT), 0, stream, a);
   else if (pipe) hipLaunchKernelGGL(mat_x_mat_mfma_pipe_kernel<kRhsPlanes>, dim3(grid), dim3(kMT), 0, stream, a);
