@@ -255,6 +255,34 @@ def test_batches_equal_single_responds(cfg, device):
         cp.tuning_set("respond.batch_fusion", 1)
 
 
+def test_passes_of_one_launch_in_both_orders_at_full_size(cfg, device):
+    """what bench.py's step is at this config -- many independent passes (one query each) in ONE launch -- in slice order (every pass its own
+    stream of the database: the N = 1 headline) and in the interleaved order (the (pass, unit) space shared out: what the shards of a
+    multi-GPU run dispatch, blocks straddling passes): the same responses as single launches, two of them checked against exact 64-bit
+    sums; 13 passes so that the passes do not divide the blocks of an XCD evenly"""
+    import torch
+
+    import chalametpir_amd as cp
+
+    f = cfg
+    passes = 13
+    Q = torch.empty((passes, f.N), dtype=torch.int32, device="cuda")
+    for i in range(passes):
+        device.synth_fill(Q, f.N, 0x9100 + i, offset_words=i * f.N, stream=f.stream)
+    singles = np.stack([respond(f, f.srv, Q[i]) for i in range(passes)])
+    assert np.array_equal(singles[0], exact_sums(f, Q[0])) and np.array_equal(singles[passes - 1], exact_sums(f, Q[passes - 1]))
+    try:
+        cp.tuning_set("respond.batch_fusion", 0)
+        for order in (0, 1):
+            cp.tuning_set("respond.interleave_passes", order)
+            R = torch.full((passes, f.C), -1, dtype=torch.int32, device="cuda")
+            f.srv.respond_batch_device(Q, passes, R, stream=f.stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(R.cpu().numpy().view(np.uint32), singles), order
+    finally:
+        cp.tuning_reset()
+
+
 def test_step_major_kernel_everywhere_equals_the_default(cfg, device):
     """respond.ks_major=2: the step-major kernel (every query word read once; the lone host caller's kernel) answers the device-resident
     queries too, fused batches in passes of 4; 3: the same in the strided step order of the in-place host path.  Same responses as the wide
