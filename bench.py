@@ -1077,8 +1077,12 @@ def host_path_timing(server, q_pool, N, torch, full=True):
         "note": "cpir_server_respond on host buffers.  A lone caller is served without an upload: the step-major kernel reads the query in "
                 "place over the host link (from the caller's page-locked buffer, or from the server's pinned block WHILE the caller's pageable query is "
                 "being copied into it: one launch in front of the copy, the kernel polling the copy's progress) + D2H. "
-                "Concurrent callers: pinned staging (skipped for page-locked queries) + H2D + batched respond + D2H, coalesced into arenas of up "
-                "to 8 seats, uploads in single file on one stream, kernels back to back on another; link_bound = h2d_GBps / query_bytes",
+                "Concurrent callers: pinned staging (skipped for page-locked queries; on a server with a slot map the query is compacted while it "
+                "is staged) + H2D + batched respond + D2H, coalesced into arenas of up to 8 seats, uploads on two streams taken in turn, kernels "
+                "back to back on another; link_bound = h2d_GBps / query_bytes",
+        "concurrent_callers_are": "PYTHON threads: each call holds the interpreter lock for 50-100 us around the library call, which caps this "
+                                  "harness near 7-9 k calls/s whatever the library does (16 callers read LOWER than 8 for that reason alone). The "
+                                  "library's own concurrency figures are respond_host_path_native / _native_compacted (plain C threads, same entry point)",
     }
     for p in pins:
         p.close()

@@ -144,6 +144,7 @@ int launch_respond_read_once(const Device* dev, const uint32_t* dtc, const cpir_
 // steps [step_lo, step_hi) of 512 slots only (0, 0 = all): a query may be answered by several launches, each over the steps whose
 // query words are in place by then; they add up in r
 uint32_t respond_upload_streams();  // tuning "respond.upload_streams" (1..4)
+uint32_t respond_helper_spin_us();  // tuning "respond.helper_spin_us"
 uint32_t respond_host_fill_timeout_us();  // tuning "respond.host_fill_timeout_us"; 0 = never launch in front of the copy
 bool respond_read_once_applicable(const cpir_dtc_layout& L);  // planar packing, LDS room for one response, respond.host_zero_copy on
 const char* respond_kernel_name(const cpir_dtc_layout& L);

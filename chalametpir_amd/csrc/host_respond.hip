@@ -23,6 +23,16 @@ class StagingHelpers {
     const uint32_t* idx = nullptr;
     const uint8_t* bits = nullptr;
   };
+  // The jobs of ONE query, an array on the submitter's stack: posted with one lock and one wake-up, claimed job by job with an atomic
+  // counter (round 4 pushed every job into a deque under the mutex and popped it under the mutex: 72 jobs x 4 threads contending, 7 us
+  // before the launch call of a lone pageable query could even be made).
+  struct Batch {
+    const Job* jobs = nullptr;
+    size_t n = 0;
+    std::atomic<size_t> next{0};
+    std::atomic<int> users{0};  // helpers that hold a pointer to this batch
+    uint32_t spin_us = 0;       // how long the helpers keep looking for the NEXT batch behind this one before they go to sleep
+  };
   static void copy(const Job& j) {
     const size_t n = j.bytes / 4;
     if (j.idx && j.bits && n) (void)compress_words_streaming(static_cast<uint32_t*>(j.dst), static_cast<const uint32_t*>(j.src), j.bits, j.idx[0], (size_t)j.idx[n - 1] + 1);
@@ -33,6 +43,7 @@ class StagingHelpers {
     {
       std::lock_guard<std::mutex> lk(mu_);
       stop_ = true;
+      gen_.fetch_add(1, std::memory_order_release);
     }
     cv_.notify_all();
     for (std::thread& t : threads_)
@@ -47,54 +58,74 @@ class StagingHelpers {
     return true;
   }
   void release() { owner_.unlock(); }
-  void submit(const Job& j) {
+  // hand the batch to the helpers (the caller holds the helpers: try_acquire); it must stay alive until retire() has returned
+  void post(Batch* b) {
     {
       std::lock_guard<std::mutex> lk(mu_);
-      jobs_.push_back(j);
-    }
-    cv_.notify_one();
-  }
-  template <class MakeJob>
-  void submit_all(size_t n, MakeJob&& make) {  // one lock, one wake-up for the lot
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      for (size_t i = 0; i < n; i++) jobs_.push_back(make(i));
+      cur_ = b;
+      gen_.fetch_add(1, std::memory_order_release);
     }
     cv_.notify_all();
   }
-  // the submitter helps: run one queued job, if any
-  bool help() {
-    Job j;
+  // every job of the batch has been run (the caller has seen all `done` flags): no helper may keep a pointer to it
+  void retire(Batch* b) {
     {
       std::lock_guard<std::mutex> lk(mu_);
-      if (jobs_.empty()) return false;
-      j = jobs_.front();
-      jobs_.pop_front();
+      cur_ = nullptr;
     }
-    copy(j);
-    j.done->store(1, std::memory_order_release);
+    while (b->users.load(std::memory_order_acquire)) {
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+  }
+  // the submitter helps: run one unclaimed job of its own batch, if any
+  static bool help(Batch* b) {
+    const size_t i = b->next.fetch_add(1, std::memory_order_relaxed);
+    if (i >= b->n) return false;
+    copy(b->jobs[i]);
+    b->jobs[i].done->store(1, std::memory_order_release);
     return true;
   }
 
  private:
   void run() {
     (void)pthread_setname_np(pthread_self(), "cpir-stage");
+    uint64_t seen = 0;
+    double spin_seconds = 0;
     for (;;) {
-      Job j;
+      // A caller in a loop (the reference's own online bench: one thread, one query after the other) comes back within a few hundred
+      // microseconds: the helpers keep looking for that long before they go to sleep -- waking a sleeping thread costs the first
+      // kilobytes of the next query's copy, which the kernel launched beside it waits for.
+      // (only behind a LONE caller's batch: with concurrent callers the helpers would spin on cores the callers' own copies need)
+      const double t0 = now_seconds();
+      while (gen_.load(std::memory_order_acquire) == seen && now_seconds() - t0 < spin_seconds) {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+      }
+      Batch* b = nullptr;
       {
         std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return stop_ || !jobs_.empty(); });
-        if (jobs_.empty()) return;
-        j = jobs_.front();
-        jobs_.pop_front();
+        cv_.wait(lk, [&] { return stop_ || gen_.load(std::memory_order_relaxed) != seen; });
+        if (stop_) return;
+        seen = gen_.load(std::memory_order_relaxed);
+        b = cur_;
+        if (b) b->users.fetch_add(1, std::memory_order_relaxed);
       }
-      copy(j);
-      j.done->store(1, std::memory_order_release);
+      spin_seconds = 0;
+      if (b) {
+        while (help(b)) {
+        }
+        spin_seconds = b->spin_us * 1e-6;
+        b->users.fetch_sub(1, std::memory_order_release);
+      }
     }
   }
   std::mutex owner_, mu_;
   std::condition_variable cv_;
-  std::deque<Job> jobs_;
+  Batch* cur_ = nullptr;           // guarded by mu_
+  std::atomic<uint64_t> gen_{0};   // bumped under mu_ with every post (and at shutdown): what the helpers watch
   std::vector<std::thread> threads_;
   bool stop_ = false;
 };
@@ -840,8 +871,11 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
       const double tp0 = ptr ? now_seconds() : 0;
       double tp1 = 0, tp2 = 0;
       if (polled) publish_fill_progress(a->fill_progress, 0u);
-      for (size_t i = 0; i < n_jobs; i++) done[i].store(0, std::memory_order_relaxed);
-      g_staging.submit_all(n_jobs, [&](size_t i) { return job(i, &done[i]); });
+      StagingHelpers::Job jobs[kMaxJobs];
+      for (size_t i = 0; i < n_jobs; i++) done[i].store(0, std::memory_order_relaxed), jobs[i] = job(i, &done[i]);
+      StagingHelpers::Batch batch;
+      batch.jobs = jobs, batch.n = n_jobs, batch.spin_us = respond_helper_spin_us();
+      g_staging.post(&batch);
       if (ptr) tp1 = now_seconds();
       if (polled) {
         journal_note("respond: polled launch", a->q_pinned, words * 4, __FILE__, __LINE__);
@@ -852,7 +886,7 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
       if (ptr) tp2 = now_seconds();
       auto wait_for_job = [&](size_t i) {
         while (!done[i].load(std::memory_order_acquire))
-          if (!g_staging.help()) {
+          if (!StagingHelpers::help(&batch)) {
 #if defined(__x86_64__)
             __builtin_ia32_pause();
 #endif
@@ -873,7 +907,8 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
           if (s_hi > s_lo) rc = launch_respond_read_once(srv->dev, srv->dtc, L, a->q_pinned_dev, kq_len, kq_off, a->r_dev, st, s_lo, s_hi);
         }
       }
-      for (size_t i = 0; i < n_jobs; i++) wait_for_job(i);  // every job must have run before the stack array goes away, whatever happened
+      for (size_t i = 0; i < n_jobs; i++) wait_for_job(i);  // every job must have run before the stack arrays go away, whatever happened
+      g_staging.retire(&batch);
       g_staging.release();
       if (ptr) {
         const double tp3 = now_seconds();
@@ -1096,24 +1131,29 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
         const size_t n_jobs = (words + kJob - 1) / kJob;
         if (n_jobs <= kMaxJobs) {
           std::atomic<int> done[kMaxJobs];
+          StagingHelpers::Job jobs[kMaxJobs];
           for (size_t i = 0; i < n_jobs; i++) {
             done[i].store(0, std::memory_order_relaxed);
             const size_t o = q_lo + i * kJob, n = (q_hi - o < kJob) ? q_hi - o : kJob;
-            g_staging.submit(StagingHelpers::Job{qp + o, q + o, n * 4, &done[i]});
+            jobs[i] = StagingHelpers::Job{qp + o, q + o, n * 4, &done[i]};
           }
+          StagingHelpers::Batch batch;
+          batch.jobs = jobs, batch.n = n_jobs;
+          g_staging.post(&batch);
           size_t next = 0;
           for (int h = 0; h < 2; h++) {
             const size_t o_lo = q_lo + (h ? half : 0), o_hi = h ? q_hi : q_lo + half;
             const size_t j_hi = (o_hi - q_lo + kJob - 1) / kJob;
             for (; next < j_hi; next++)
               while (!done[next].load(std::memory_order_acquire))
-                if (!g_staging.help()) {
+                if (!StagingHelpers::help(&batch)) {
 #if defined(__x86_64__)
                   __builtin_ia32_pause();
 #endif
                 }
             if (up == hipSuccess) up = hipMemcpyAsync(qd + o_lo, qp + o_lo, (o_hi - o_lo) * 4, hipMemcpyHostToDevice, ups);
           }
+          g_staging.retire(&batch);  // (every job has run: no helper may keep a pointer to the stack arrays)
         } else {
           memcpy(qp + q_lo, q + q_lo, words * 4);
           up = hipMemcpyAsync(qd + q_lo, qp + q_lo, words * 4, hipMemcpyHostToDevice, ups);

@@ -297,6 +297,7 @@ struct Tuning {
   int host_fill_timeout_us = 2000;  // a lone pageable host query: ONE launch polling the copy's progress, each wave for at most this long (0: off)
   int host_zero_copy = 1;          // a lone host query is read by the kernel in place (page-locked memory), not uploaded first
   int upload_streams = 2;          // concurrent host callers: their uploads take this many streams in turn (1..4)
+  int helper_spin_us = 300;        // a lone pageable caller: the copy helpers keep looking for its next query this long before they sleep
   // planar packing, device-resident queries: 1 = the wide kernel takes every launch (the step-major kernel serves the in-place host path
   // only); 2 = the step-major kernel wherever it applies (passes of up to 4 queries in slice order: tests and A/B runs); 3 = as 2, launched
   // as the in-place host path launches it (strided steps, far-mode fragment schedule: diagnosis)
@@ -378,6 +379,9 @@ extern "C" int cpir_tuning_set(const char* key, int value) {
     g_tuning.host_fill_timeout_us = value;
   } else if (!strcmp(key, "respond.host_zero_copy")) {
     g_tuning.host_zero_copy = value ? 1 : 0;
+  } else if (!strcmp(key, "respond.helper_spin_us")) {
+    if (value < 0 || value > 10000) return CPIR_ERR_INVALID_ARGUMENT;
+    g_tuning.helper_spin_us = value;
   } else if (!strcmp(key, "respond.upload_streams")) {
     if (value < 1 || value > 4) return CPIR_ERR_INVALID_ARGUMENT;
     g_tuning.upload_streams = value;
@@ -462,6 +466,11 @@ uint64_t respond_scratch_words(const cpir_dtc_layout&, uint32_t) {
 
 const char* respond_kernel_name(const cpir_dtc_layout& L) {
   return L.packing == CPIR_PACK_PLANAR ? "respond_planar_wide_kernel" : "respond_kernel";
+}
+
+uint32_t respond_helper_spin_us() {
+  std::lock_guard<std::mutex> lk(g_tuning_mu);
+  return (uint32_t)g_tuning.helper_spin_us;
 }
 
 uint32_t respond_upload_streams() {

@@ -143,6 +143,7 @@ int main(int argc, char** argv) {
     return g_bad ? 2 : 0;
   }
   const int lone_only = argc > 4 && !strcmp(argv[4], "lone"); /* 4th argument "lone": the single-caller latencies only */
+  if (lone_only && argc > 5) CHECK(cpir_tuning_set("respond.helper_spin_us", atoi(argv[5]))); /* ... 5th: respond.helper_spin_us */
   const int lone = 200;
   /* the lone caller is the thread that allocated the buffers and built the server (memory placed where it runs) */
   double lone_pageable, lone_pinned;

@@ -257,6 +257,9 @@ int cpir_op_synth_fill(cpir_device* dev, uint32_t* out, uint64_t count, uint64_t
  *   device-resident queries: 1 -- the default -- every launch runs on the wide kernel (1 .. 24 queries per pass, one 8-wave block per CU,
  *   passes in slice or interleaved order) and the step-major kernel serves the in-place host path only; 2 the step-major kernel wherever
  *   it applies, i.e. passes of up to 4 queries in slice order -- tests and A/B runs; 3 as 2, launched as the in-place host path launches it),
+ *   "respond.helper_spin_us" 0..10000 (a lone pageable caller's query is copied into page-locked memory by this thread and three helper
+ *   threads: behind such a query the helpers keep looking for the next one this long -- a caller in a loop comes back within that time and
+ *   does not pay for waking them -- before they go to sleep; default 300, 0: sleep at once),
  *   "respond.upload_streams" 1..4 (concurrent host callers: their query uploads take this many HIP streams in turn, so that one copy is
  *   set up while another crosses the link; default 2),
  *   "respond.host_zero_copy" {0,1}
