@@ -765,8 +765,15 @@ __device__ __forceinline__ void mfma_pipe_unit(const MfmaArgs& a, const PipeLane
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+#ifdef CPIR_DIAG
 template <int RHS, bool EMU32 = false>
+#else
+template <int RHS>  // (the release kernel has no such parameter: its name in a trace is mat_x_mat_mfma_pipe_kernel<RHS>)
+#endif
 __global__ void __launch_bounds__(kMT) __attribute__((amdgpu_waves_per_eu(2, 2))) mat_x_mat_mfma_pipe_kernel(const MfmaArgs a) {
+#ifndef CPIR_DIAG
+  constexpr bool EMU32 = false;
+#endif
   constexpr bool PLANAR = RHS != kRhsPlanes;
   __shared__ uint4 lds[kPipePieces * 64];
 
@@ -826,12 +833,15 @@ __global__ void __launch_bounds__(kMT) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int n = 0; n < 2; n++)
 #pragma unroll
           for (int s2 = 0; s2 < 4; s2++) acc.a[m][n][s2] = v4i{0, 0, 0, 0};
-    } else {
+    }
+#ifdef CPIR_DIAG
+    else {
 #pragma unroll
       for (int mp = 0; mp < 2; mp++)
 #pragma unroll
         for (int s2 = 0; s2 < 4; s2++) acc.a[mp][s2] = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     }
+#endif
 
     if (u.sum_rows) mfma_pipe_unit<true, RHS, EMU32>(a, pl, u, lds, lds_b0, lane, wave, k0, k1 - k0, acc);
     else mfma_pipe_unit<false, RHS, EMU32>(a, pl, u, lds, lds_b0, lane, wave, k0, k1 - k0, acc);
@@ -846,13 +856,16 @@ __global__ void __launch_bounds__(kMT) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           const uint64_t r = (uint64_t)rt * kBM + wm * 64 + m * 16 + fq * 4 + i;
-          uint32_t v;
+          uint32_t v = 0;
           if constexpr (!EMU32) {
             v = (uint32_t)acc.a[m][n][0][i] + ((uint32_t)acc.a[m][n][1][i] << 8) + ((uint32_t)acc.a[m][n][2][i] << 16) + ((uint32_t)acc.a[m][n][3][i] << 24);
-          } else {  // (the emulation's values mean nothing: every register still leaves through one atomic)
+          }
+#ifdef CPIR_DIAG
+          else {  // (the emulation's values mean nothing: every register still leaves through one atomic)
             const int e = (m & 1) * 8 + n * 4 + i;
             v = (uint32_t)acc.a[m >> 1][0][e] + ((uint32_t)acc.a[m >> 1][1][e] << 8) + ((uint32_t)acc.a[m >> 1][2][e] << 16) + ((uint32_t)acc.a[m >> 1][3][e] << 24);
           }
+#endif
           if (r < a.rows && c < a.cols) atomicAdd(a.M + r * a.ldm + c, v);
         }
       }

@@ -483,9 +483,16 @@ constexpr int kWMaxSets = 6;  // row sets of 4 queries
 // v_mfma_i32_32x32x32_i8 on the first set's fragment -- the same number of byte products per tile, half the fragment reads and half the
 // operand bytes per product, 16 accumulator registers per product instead of 4: what a 32-column image layout would make of the matrix
 // cores' and the LDS's share of a fused pass, measured without building that layout (scripts/wide_ablate.py, CPIR_WIDE_ABLATE bit 8).
+#ifdef CPIR_DIAG
 template <int HB, bool NT, bool MAP, bool EMU32 = false>
+#else
+template <int HB, bool NT, bool MAP>  // (the release kernel has no such parameter: its name in a trace is respond_planar_wide_kernel<HB, NT, MAP>)
+#endif
 __global__ void __launch_bounds__(kWThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 respond_planar_wide_kernel(const PlanarArgs a) {
+#ifndef CPIR_DIAG
+  constexpr bool EMU32 = false;
+#endif
   constexpr int NL = 8 + HB;
   constexpr int ST16 = NL * 64;
   extern __shared__ uint4 wsm[];
@@ -1091,7 +1098,10 @@ int launch_respond_planar_wide(const Device* dev, const uint32_t* dtc, const cpi
   const uint32_t hb = planar_hi_planes(L.mat_elem_bit_len);
   // order of the passes: interleaved where the image is small enough for concurrent passes to share its bytes on die, slice order for
   // HBM-sized streams; `nt` loads keep a once-per-pass stream out of the caches, passes that are meant to share bytes use plain loads
-  const bool inter = planar_passes_interleaved(L, passes, interleave);
+  // (the interleaved order numbers the (pass, unit) space in 64 bits and multiplies it by a block index: far beyond any real launch, but the
+  // slice order is always there)
+  const uint64_t units_all = (uint64_t)((L.rows_padded / 16 + kWM - 1) / kWM) * ((L.num_slots + CPIR_PLANAR_SLOTS_PER_TILE - 1) / CPIR_PLANAR_SLOTS_PER_TILE);
+  const bool inter = planar_passes_interleaved(L, passes, interleave) && units_all * passes < ((uint64_t)1 << 50);
   const bool nt = nontemporal && !inter;
   KernelFn fn = pick_wide(hb, nt, keep != nullptr);
   if (keep && q_len >= ((uint64_t)1 << 28)) return CPIR_ERR_INVALID_ARGUMENT;  // (32-bit word offsets inside a row set, see the kernel)
