@@ -171,7 +171,10 @@ uint64_t respond_multi_pass_limit_bytes();
 
 // pack.hip
 int launch_transpose_compress(const Device* dev, const uint32_t* D, uint64_t ldd, const cpir_dtc_layout& L, uint32_t* dtc,
-                              uint32_t* or_of_entries, hipStream_t stream, void* hi_plane = nullptr);
+                              uint32_t* or_of_entries, hipStream_t stream, void* hi_plane = nullptr, const uint32_t* keep = nullptr);
+// keep: a slot map applied by the pack kernel itself (L = the COMPACT layout, slot n of the image = row keep[n] of D; device memory, at
+// least L.num_slots entries) -- where transpose_compress_takes_slot_map(L); else the caller gathers the rows first
+bool transpose_compress_takes_slot_map(const cpir_dtc_layout& L);
 // planar packing: hi_plane (planar_hi_plane_bytes(L) bytes, 16-byte aligned; 0 bytes for b <= 8) also receives the byte (field >> 8) XOR
 // 0x80 of every field as 1 KiB MFMA operand pieces [column tile of 16][k-block of 64 slots] -- with the low-byte pieces of the image
 // itself the right-hand side of the hint matmul, so that Server::setup reads D once (launch_mat_x_mat_mfma_planar)

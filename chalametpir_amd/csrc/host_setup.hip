@@ -221,29 +221,33 @@ void DevBuf::dispose_async(int ordinal) {
 }
 
 // Packs D (L.num_slots x C on the device, leading dimension ldd) into srv->dtc (allocated here).  With an active `map` (the rows of D that
-// have a non-zero field: build_slot_map, compact.hip) only those rows are packed -- gathered into a stream-ordered temporary first -- and the
+// have a non-zero field: build_slot_map, compact.hip) only those rows are packed -- by the pack kernel itself through the map (planar packing), else gathered into a stream-ordered temporary first -- and the
 // server adopts the map and the compact layout; hi_plane (the hint matmul's second operand plane, written by the pack pass) only goes with an
 // uncompacted image.  Enqueues on `stream`; the caller synchronises.
 static int pack_into_server(Device* dev, Server* srv, const uint32_t* D_dev, uint64_t ldd, const cpir_dtc_layout& L, SlotMap* map, uint32_t* flag_dev,
                             void* hi_plane, hipStream_t stream) {
   cpir_dtc_layout P = L;
   uint32_t* Dc = nullptr;
+  bool in_kernel = false;  // the pack kernel applies the map itself
   if (map->active()) {
     if (hi_plane) return CPIR_ERR_INVALID_ARGUMENT;
     CPIR_TRY(dtc_layout_for_packing(map->n_kept, L.num_cols, L.mat_elem_bit_len, L.packing, &P));
-    // The kept rows are gathered into a temporary of (almost) D's size while D is still resident: where the device has no room for that --
-    // a database that fits beside its image but not twice -- the map is dropped and the whole matrix packed as it is.  Compaction is an
-    // optimisation, never a reason for setup to fail.
-    const hipError_t ae = hipMallocAsync(reinterpret_cast<void**>(&Dc), (size_t)map->n_kept * L.num_cols * 4, stream);
-    if (ae != hipSuccess) {
-      (void)hipGetLastError();
-      if (ae != hipErrorOutOfMemory) {
-        set_last_hip_error(ae, "hipMallocAsync(compact D)", __FILE__, __LINE__);
-        return CPIR_ERR_HIP;
+    in_kernel = transpose_compress_takes_slot_map(P);
+    if (!in_kernel) {
+      // (the other two packings) the kept rows are gathered into a temporary of (almost) D's size while D is still resident: where the
+      // device has no room for that -- a database that fits beside its image but not twice -- the map is dropped and the whole matrix
+      // packed as it is.  Compaction is an optimisation, never a reason for setup to fail.
+      const hipError_t ae = hipMallocAsync(reinterpret_cast<void**>(&Dc), (size_t)map->n_kept * L.num_cols * 4, stream);
+      if (ae != hipSuccess) {
+        (void)hipGetLastError();
+        if (ae != hipErrorOutOfMemory) {
+          set_last_hip_error(ae, "hipMallocAsync(compact D)", __FILE__, __LINE__);
+          return CPIR_ERR_HIP;
+        }
+        Dc = nullptr;
+        map->reset();
+        P = L;
       }
-      Dc = nullptr;
-      map->reset();
-      P = L;
     }
   }
   const hipError_t de = CPIR_HIP_MALLOC(&srv->dtc, (size_t)P.total_words * 4);
@@ -253,7 +257,10 @@ static int pack_into_server(Device* dev, Server* srv, const uint32_t* D_dev, uin
     return de == hipErrorOutOfMemory ? CPIR_ERR_OUT_OF_DEVICE_MEMORY : CPIR_ERR_HIP;
   }
   int st;
-  if (map->active()) {
+  if (map->active() && in_kernel) {
+    // planar packing: the pack kernel reads row keep[n] of D for slot n of the image -- no gathered copy of D, no second D's worth of memory
+    st = launch_transpose_compress(dev, D_dev, ldd, P, srv->dtc, flag_dev, stream, nullptr, map->keep_dev);
+  } else if (map->active()) {
     st = launch_gather_rows(dev, D_dev, ldd, *map, L.num_cols, Dc, stream);
     if (st == CPIR_OK) st = launch_transpose_compress(dev, Dc, L.num_cols, P, srv->dtc, flag_dev, stream, nullptr);
     const hipError_t fe = hipFreeAsync(Dc, stream);

@@ -369,6 +369,9 @@ struct PackStreamArgs {
   // plane ARE the low-byte pieces of the image; written in the same pass so that D is read once for both products
   uint4* hi_plane;
   uint32_t kb_total;  // k-blocks of 64 slots in the plane: ceil(N / 64)
+  // optional slot map (compact.hip): slot n of the image is row keep[n] of D -- the rows that hold something are packed straight out of
+  // the whole matrix, no gathered copy of it in between (which would need room for D twice); NULL: slot n is row n
+  const uint32_t* keep;
 };
 
 // GUARD: this step reaches past the last slot (only the last step of a database whose N is not a multiple of 512)
@@ -404,7 +407,8 @@ __device__ __forceinline__ void pack_stream_unit(const PackStreamArgs& a, uint4*
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       const uint64_t n = nb + j;
-      const uint64_t nr = (!GUARD || n < a.N) ? n : a.N - 1;  // clamped rows are zeroed below
+      const uint64_t ns = (!GUARD || n < a.N) ? n : a.N - 1;  // clamped rows are zeroed below
+      const uint64_t nr = a.keep ? (uint64_t)a.keep[ns] : ns;
       if constexpr (VEC) {
         const uint4 t = *reinterpret_cast<const uint4*>(a.D + nr * a.ld + csafe);
         v[j][0] = t.x, v[j][1] = t.y, v[j][2] = t.z, v[j][3] = t.w;
@@ -560,7 +564,8 @@ __device__ __forceinline__ void pack_rows_unit(const PackStreamArgs& a, uint4* m
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       const uint64_t n = nb + j;
-      const uint64_t nr = (!GUARD || n < a.N) ? n : a.N - 1;  // clamped rows are zeroed in process_batch
+      const uint64_t ns = (!GUARD || n < a.N) ? n : a.N - 1;  // clamped rows are zeroed in process_batch
+      const uint64_t nr = a.keep ? (uint64_t)a.keep[ns] : ns;   // (wave-uniform: scalar loads)
       if constexpr (VEC) {
         buf[j] = *reinterpret_cast<const uint4*>(a.D + nr * a.ld + csafe);
       } else {
@@ -734,14 +739,14 @@ __global__ void __launch_bounds__(kThreads) planar_export_kernel(const uint8_t* 
 }
 
 int launch_planar_pack(const uint32_t* src, uint64_t ld, bool from_ref, const cpir_dtc_layout& L, uint32_t* dtc, uint32_t* or_of_entries,
-                       hipStream_t stream, uint4* hi_plane = nullptr) {
+                       hipStream_t stream, uint4* hi_plane = nullptr, const uint32_t* keep = nullptr) {
   const uint32_t hb = planar_hi_planes(L.mat_elem_bit_len);
   const uint64_t ks_total = (L.num_slots + CPIR_PLANAR_SLOTS_PER_TILE - 1) / CPIR_PLANAR_SLOTS_PER_TILE;
   const uint32_t col_tiles = L.rows_padded / 16;
   if (!planar_offered(L.mat_elem_bit_len) || ks_total > 0x7fffffffull || col_tiles > 65535u) return CPIR_ERR_INVALID_ARGUMENT;
   uint32_t* colsum = dtc + (uint64_t)L.rows_padded * L.words_per_row_padded;
   CPIR_HIP_TRY(hipMemsetAsync(colsum, 0, (size_t)L.rows_padded * sizeof(uint32_t), stream));
-  if (from_ref && hi_plane) return CPIR_ERR_INVALID_ARGUMENT;
+  if (from_ref && (hi_plane || keep)) return CPIR_ERR_INVALID_ARGUMENT;
   if (from_ref) {
     const dim3 grid((unsigned)ks_total, col_tiles);
     hipLaunchKernelGGL((planar_pack_kernel<true>), grid, dim3(kThreads), 0, stream, src, ld, L.num_slots, L.num_cols, L.mat_elem_bit_len,
@@ -763,6 +768,7 @@ int launch_planar_pack(const uint32_t* src, uint64_t ld, bool from_ref, const cp
   pa.low_mask = L.mat_elem_bit_len < 8 ? ((1u << L.mat_elem_bit_len) - 1u) * 0x01010101u : 0xFFFFFFFFu;
   pa.hi_plane = hb ? hi_plane : nullptr;
   pa.kb_total = (uint32_t)((L.num_slots + 63) / 64);
+  pa.keep = keep;
 #define LAUNCH_PP3(KERNEL_, HB_, VEC_)                                                                                            \
   do {                                                                                                                              \
     if (full_steps)                                                                                                                 \
@@ -827,14 +833,18 @@ uint64_t planar_hi_plane_bytes(const cpir_dtc_layout& L) {
   return (uint64_t)(L.rows_padded / 16) * ((L.num_slots + 63) / 64) * 1024;
 }
 
+// keep (planar packing only -- transpose_compress_takes_slot_map): L describes the COMPACT image and slot n of it is row keep[n] of D
+bool transpose_compress_takes_slot_map(const cpir_dtc_layout& L) { return L.packing == CPIR_PACK_PLANAR; }
+
 int launch_transpose_compress(const Device* dev, const uint32_t* D, uint64_t ldd, const cpir_dtc_layout& L, uint32_t* dtc,
-                              uint32_t* or_of_entries, hipStream_t stream, void* hi_plane) {
+                              uint32_t* or_of_entries, hipStream_t stream, void* hi_plane, const uint32_t* keep) {
   (void)dev;
   if (!D || !dtc || ldd < L.num_cols) return CPIR_ERR_INVALID_ARGUMENT;
   CPIR_TRY(check_layout(L));
   if (reinterpret_cast<uintptr_t>(dtc) % 16 != 0) return CPIR_ERR_INVALID_ARGUMENT;
   if (hi_plane && (L.packing != CPIR_PACK_PLANAR || reinterpret_cast<uintptr_t>(hi_plane) % 16 != 0)) return CPIR_ERR_INVALID_ARGUMENT;
-  if (L.packing == CPIR_PACK_PLANAR) return launch_planar_pack(D, ldd, false, L, dtc, or_of_entries, stream, reinterpret_cast<uint4*>(hi_plane));
+  if (keep && !transpose_compress_takes_slot_map(L)) return CPIR_ERR_INVALID_ARGUMENT;
+  if (L.packing == CPIR_PACK_PLANAR) return launch_planar_pack(D, ldd, false, L, dtc, or_of_entries, stream, reinterpret_cast<uint4*>(hi_plane), keep);
   if (L.packing == CPIR_PACK_DENSE64) {
     const uint64_t chunks = L.words_per_row_padded / L.chunk_words;
     if (chunks * 16 > 0x7fffffffull) return CPIR_ERR_INVALID_ARGUMENT;
