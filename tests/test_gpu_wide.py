@@ -279,3 +279,48 @@ def test_wide_pass_random_shapes(orc, device):
         torch.cuda.synchronize()
         assert np.array_equal(r.cpu().numpy().view(np.uint32), want[0]), (trial, "lone")
         srv.close()
+
+
+def test_random_shapes_passes_and_orders(orc, device):
+    """seeded random shapes through the wide kernel's pass bookkeeping: steps from 1 to a few hundred (fewer units than blocks, the XCD split
+    on and off), column counts around the 8-tile groups, 1 .. 70 passes of 1 .. 6 queries, both orders, shards with an offset -- every
+    response against the oracle"""
+    import torch
+
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(20251004)
+    stream = torch.cuda.current_stream()
+    try:
+        for trial in range(36):
+            b = int(rng.choice([9, 9, 10, 8, 12]))
+            steps = int(rng.choice([1, 2, 5, 7, 8, 9, 31, 64, 100, 257]))
+            N = max(3, steps * 512 - int(rng.integers(0, 511)))
+            C = int(rng.choice([1, 15, 16, 17, 127, 128, 129, 200, 300]))
+            if N * C > 6_000_000:
+                C = max(1, 6_000_000 // N)
+            per_pass = int(rng.choice([1, 1, 1, 2, 3, 5, 6]))
+            passes = int(rng.choice([1, 2, 3, 7, 8, 31, 32, 33, 70]))
+            nq = per_pass * passes
+            D = random_db_matrix(rng, N, C, b)
+            lo = int(rng.integers(0, N // 4 + 1)) if trial % 3 == 0 else 0
+            hi = N
+            dtc = orc.row_wise_compress(orc.transpose(D[lo:hi]), b)
+            D_dev = torch.from_numpy(np.ascontiguousarray(D[lo:hi]).view(np.int32)).cuda()
+            srv = cp.Server.from_device_matrix(D_dev, hi - lo, C, b, device=device, slot_offset=lo, total_slots=N, stream=stream)
+            distinct = min(nq, 7)
+            Q = np.stack([random_query(rng, N) for _ in range(distinct)])
+            want = _responses(orc, Q[:, lo:hi], dtc, hi - lo, b)
+            pick = np.arange(nq) % distinct
+            Q_dev = torch.from_numpy(Q[pick].view(np.int32)).cuda()
+            for order in (0, 1):
+                cp.tuning_set("respond.interleave_passes", order)
+                cp.tuning_set("respond.batch_fusion", 0 if per_pass == 1 else 1)
+                R = torch.full((nq, C), -1, dtype=torch.int32, device="cuda")
+                # (unfused: nq passes of one query; fused: the library cuts the nq queries into passes of its own width, up to 24)
+                srv.respond_batch_device(Q_dev, nq, R, stream=stream)
+                torch.cuda.synchronize()
+                assert np.array_equal(R.cpu().numpy().view(np.uint32), want[pick]), (trial, b, N, C, lo, per_pass, passes, order)
+            srv.close()
+    finally:
+        cp.tuning_reset()
