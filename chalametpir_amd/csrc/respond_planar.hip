@@ -460,21 +460,22 @@ respond_planar_ks_kernel(const PlanarArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
-// The WIDE pass (round 4): up to 24 queries answered by ONE stream of the database.
+// The WIDE kernel: every device-resident launch -- 1 .. 24 queries per pass answered by ONE stream of the database, any number of passes.
 //
-// What bounds a fused pass is the LDS, not the matrix cores (three row sets keep them 27 % busy): a query costs 2 KiB of A fragments per
-// step and 4 bytes per column of accumulators, and the step-major kernel above runs TWO 4-wave blocks per CU, each with its own
-// double-buffered fragments -- 12 queries per pass, and at 2^20 keys x 1 kB only in two column windows, i.e. the 12 queries are gathered
-// twice.  Here ONE 8-wave block owns the CU's whole LDS: single-buffered fragments (6 row sets x 8 KiB) + the accumulators of up to 24
-// queries x 1 024 columns (96 KiB).  Same walk (512-slot steps, contiguous units split evenly over the blocks, slot axis split over the
-// XCDs), same arithmetic, same packed image, same responses bit for bit; differences to the kernel above:
+// ONE 8-wave block owns the CU's whole LDS: single-buffered A fragments (1 .. 6 row sets x 8 KiB) + the accumulators of up to 24 queries x
+// 1 024 columns (96 KiB).  (Round 4's step-major kernel with two / three row sets ran TWO 4-wave blocks per CU, each with its own
+// double-buffered fragments: 12 queries per pass at most, and at 2^20 keys x 1 kB only in two column windows.)  Same walk as the step-major
+// kernel above (512-slot steps, contiguous units split evenly over the blocks, slot axis split over the XCDs), same arithmetic, same
+// packed image, same responses bit for bit; what differs:
 //   * a unit is a step x 8 column tiles (one per wave); PlanarArgs::tg_lo / tg_n count groups of EIGHT tiles here;
 //   * every wave gathers ONE k-block (64 slots) of all row sets: one 16-byte load per lane and row set (a row set's four query rows x
 //     256 contiguous bytes), parked in the fragment slab it is about to fill and read back in fragment order, as above;
 //   * the row sets are a LOOP (their number is a run-time value, the tile stays in registers and is multiplied by one set after the
 //     other, two accumulators live at a time), not an unrolled dimension: 6 sets unrolled would need ~400 VGPRs;
 //   * fragments are single-buffered: the step's last unit ends with barrier / build the next step's fragments from registers (their
-//     loads were issued in the step's first unit) / barrier; the next tile's loads are in flight across both.
+//     loads were issued in the step's first unit) / barrier; the next tile's loads are in flight across both;
+//   * the passes of a launch go in slice or in interleaved order (see the kernel), and a slot map is applied while the query words are
+//     gathered (MAP).
 constexpr int kWThreads = 512;
 constexpr int kWM = 8;        // column tiles per work unit = waves per block
 constexpr int kWMaxSets = 6;  // row sets of 4 queries
