@@ -356,6 +356,10 @@ def main() -> int:
         else:
             elapsed_s, region_ms_s = elapsed, kernel_region_ms
         launch_us_s = region_ms_s * 1e3 / n_queries * passes_per_launch
+        result["value_is"] = (("the product's dispatch at this shard size: passes in the INTERLEAVED order, i.e. concurrent passes share database bytes on "
+                               "die -- not comparable with the N = 1 headline; compare `value_slice_order` (same shards, every pass its own stream) with "
+                               "it: `scaling_like_for_like`") if roof0["pass_order"] == "interleaved" else
+                              "slice order: every pass its own stream of the shard from HBM, as the N = 1 headline (value_slice_order = value)")
         result["value_slice_order"] = round(n_queries / elapsed_s, 2)
         result["slice_order"] = {
             "queries_per_sec": round(n_queries / elapsed_s, 2),
