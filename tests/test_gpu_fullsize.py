@@ -190,6 +190,51 @@ def test_shard_partials_sum_to_the_whole(world, full, device):
     assert np.array_equal(total.cpu().numpy().view(np.uint32), want)
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_a_step_of_the_multi_gpu_bench_shard_by_shard(world, full, device):
+    """what `bench.py --gpus N` does in one step, rank after rank on the one GPU at FULL size: every shard (boundaries as the bench cuts
+    them: multiples of the planar shard unit) answers the step's 32 queries as 32 independent passes of ONE launch -- at these shard sizes
+    in the interleaved order -- and as fused passes; the partial responses are summed with wrap-around (what the all-reduce does) and must
+    equal the whole database's responses, two of which are held against exact 64-bit sums"""
+    import torch
+
+    import chalametpir_amd as cp
+    from chalametpir_amd.distributed import shard_range
+
+    f = full
+    nq = 32
+    Q = torch.empty((nq, f.N), dtype=torch.int32, device="cuda")
+    for i in range(nq):
+        device.synth_fill(Q, f.N, 0x6100 + i, offset_words=i * f.N, stream=f.stream)
+    whole = f.servers["planar"]
+    want = torch.empty((nq, f.C), dtype=torch.int32, device="cuda")
+    whole.respond_batch_device(Q, nq, want, stream=f.stream)
+    torch.cuda.synchronize()
+    want = want.cpu().numpy().view(np.uint32)
+    for i in (0, nq - 1):
+        assert np.array_equal(want[i], exact_reference_response(f, Q[i])), i
+    layout = cp.dtc_layout_for(f.N, f.C, f.b)
+    assert int(layout.packing) == 2
+    try:
+        for fusion in (0, 1):
+            cp.tuning_set("respond.batch_fusion", fusion)
+            total = torch.zeros((nq, f.C), dtype=torch.int32, device="cuda")
+            covered = 0
+            for rank in range(world):
+                lo, hi = shard_range(f.N, layout, rank, world)
+                covered += hi - lo
+                srv = cp.Server.from_device_matrix(f.D[lo:hi], hi - lo, f.C, f.b, device=device, slot_offset=lo, total_slots=f.N, stream=f.stream)
+                part = torch.full((nq, f.C), -1, dtype=torch.int32, device="cuda")
+                srv.respond_batch_device(Q, nq, part, stream=f.stream)
+                total += part
+                torch.cuda.synchronize()
+                srv.close()
+            assert covered == f.N
+            assert np.array_equal(total.cpu().numpy().view(np.uint32), want), (world, fusion)
+    finally:
+        cp.tuning_reset()
+
+
 @pytest.mark.parametrize("packing", PACKINGS)
 def test_batches_equal_single_responds(packing, full, device):
     import torch
