@@ -1416,8 +1416,9 @@ def setup_kernel_roofline(cp, device, torch, N, C, b, cf, mask, layout, stream):
 
 def setup_timing_sharded(cp, device, torch, dist, N, C, b, mask, lo, hi, rank, stream, unit):
     """server_setup on the N-sharded database with ONE expansion of A per node: rank 0 squeezes the sponge block by block (it is
-    sequential, so this is the floor of setup whatever the number of GPUs), uploads each block and sends every rank its column slab over
-    the process group (RCCL send/recv over xGMI); every rank multiplies its slab with its shard of D on the matrix cores and packs its
+    sequential, so this is the floor of setup whatever the number of GPUs), uploads each block once and BROADCASTS it over the process
+    group (RCCL over xGMI; every rank cuts its column slab out of the landed block -- host-staged test backends send slabs point to point
+    instead: chalametpir_amd/distributed.py::scatter_public_matrix); every rank multiplies its slab with its shard of D on the matrix cores and packs its
     shard; the partial hints are sum-reduced to rank 0.  Wall time = max over ranks, barrier to barrier."""
     from chalametpir_amd.distributed import reduce_u32_, scatter_public_matrix
 
@@ -1446,8 +1447,8 @@ def setup_timing_sharded(cp, device, torch, dist, N, C, b, mask, lo, hi, rank, s
     out = {
         "server_setup_wall_sec": round(float(t[0].item()), 3),
         "server_setup_note": "sharded setup from (seed_mu, encoded D shards in HBM), ONE XOF expansion of A per node: rank 0 squeezes, uploads and "
-                             "sends column slabs block by block (RCCL send/recv), every rank: shard pack, partial hint matmul (matrix cores) on its "
-                             "slab; partial hints sum-reduced (RCCL) to rank 0",
+                             "broadcasts block by block (RCCL; host-staged test backends: slabs point to point), every rank keeps its column slab: "
+                             "shard pack, partial hint matmul (matrix cores) on its slab; partial hints sum-reduced to rank 0",
         "server_setup_max_rank_local_sec": round(float(t[1].item()), 3),
         "server_setup_expand_and_scatter_sec": round(float(t[2].item()), 3),
         "xof_expansions_per_node": 1,
