@@ -94,7 +94,7 @@ def main() -> int:
     ap.add_argument("--headline-only", action="store_true", help=argparse.SUPPRESS)  # internal: the timed loop and nothing else (the counter passes' child)
     ap.add_argument("--no-host-path", action="store_true", help="skip timing Server.respond on host buffers (PCIe inclusive)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
-    ap.add_argument("--tune", default="", help="comma list key=value for cpir_tuning_set, e.g. respond.rows_per_unit=16")
+    ap.add_argument("--tune", default="", help="comma list key=value for cpir_tuning_set, e.g. respond.interleave_passes=0")
     ap.add_argument("--sweep", action="store_true", help="time every respond kernel variant (stderr table) before the run")
     ap.add_argument("--enqueue", default="batch", choices=["batch", "python"],
                     help="how a step's launches are enqueued: one C call for the step (default) or one ctypes call per query")
@@ -1198,11 +1198,10 @@ def group_host_path_timing(cp, torch, device0, single, q_pool, N, C, b, mask, sh
 
 def sweep(cp, torch, run_step, qps_step):
     """time each respond kernel variant (one process, interleaved rounds) -- tuning aid, output on stderr"""
-    variants = [(R, nt, bpc) for R in (4, 8, 16) for nt in (0, 1) for bpc in (1, 2, 3, 4, 0)]
+    variants = [(nt, bpc) for nt in (0, 1) for bpc in (1, 2, 3, 4, 0)]
     best = {}
     for rnd in range(3):
-        for R, nt, bpc in variants:
-            cp.tuning_set("respond.rows_per_unit", R)
+        for nt, bpc in variants:
             cp.tuning_set("respond.nontemporal", nt)
             cp.tuning_set("respond.blocks_per_cu", bpc)
             run_step()
@@ -1214,14 +1213,13 @@ def sweep(cp, torch, run_step, qps_step):
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / (3 * qps_step)
-            best[(R, nt, bpc)] = min(best.get((R, nt, bpc), 1e30), us)
+            best[(nt, bpc)] = min(best.get((nt, bpc), 1e30), us)
     for k, us in sorted(best.items(), key=lambda kv: kv[1]):
-        log(f"sweep R={k[0]:2d} nt={k[1]} blocks/CU={k[2]}: {us:8.1f} us/query")
-    R, nt, bpc = min(best, key=best.get)
-    cp.tuning_set("respond.rows_per_unit", R)
+        log(f"sweep nt={k[0]} blocks/CU={k[1]}: {us:8.1f} us/query")
+    nt, bpc = min(best, key=best.get)
     cp.tuning_set("respond.nontemporal", nt)
     cp.tuning_set("respond.blocks_per_cu", bpc)
-    log(f"sweep: using R={R} nt={nt} blocks/CU={bpc}")
+    log(f"sweep: using nt={nt} blocks/CU={bpc}")
 
 
 def cpu_baseline(server, q_pool, r_step, N, C, b, full_bytes, budget_s, torch, stream):

@@ -756,8 +756,9 @@ int launch_planar_pack(const uint32_t* src, uint64_t ld, bool from_ref, const cp
   }
   // wide databases: whole rows per block (planar_pack_rows_kernel); narrow ones keep the 64-column waves, which waste fewer lanes there
   const int rows_mode = pack_rows_mode();
-  // (with two or more bit planes the whole-rows kernel needs more registers than two waves per SIMD leave it: the 64-column waves stay)
-  const bool rows = rows_mode > 0 || (rows_mode < 0 && col_tiles >= 32 && hb <= 1);
+  // (with two or more bit planes the whole-rows kernel needs more registers than two waves per SIMD leave it: the 64-column waves stay,
+  // whatever "pack.rows" says)
+  const bool rows = hb <= 1 && (rows_mode > 0 || (rows_mode < 0 && col_tiles >= 32));
   const uint32_t stripe_groups = rows ? (col_tiles + 63) / 64 : (col_tiles + 15) / 16;  // 4 waves x 16 (4) tiles per block
   if (ks_total * stripe_groups > 0x7fffffffull) return CPIR_ERR_INVALID_ARGUMENT;
   const uint64_t full_steps = L.num_slots / CPIR_PLANAR_SLOTS_PER_TILE;  // steps that lie wholly inside the database
@@ -776,10 +777,15 @@ int launch_planar_pack(const uint32_t* src, uint64_t ld, bool from_ref, const cp
     if (full_steps < ks_total)                                                                                                      \
       hipLaunchKernelGGL((KERNEL_<HB_, VEC_, true>), dim3(stripe_groups), dim3(kThreads), 0, stream, pa, (uint32_t)full_steps);     \
   } while (0)
-#define LAUNCH_PP2(HB_, VEC_)                                       \
-  do {                                                              \
-    if (rows) LAUNCH_PP3(planar_pack_rows_kernel, HB_, VEC_);       \
-    else LAUNCH_PP3(planar_pack_stream_kernel, HB_, VEC_);          \
+  // (the whole-rows kernel exists for at most one bit plane -- every BASELINE configuration --: with more it needs the registers of a whole SIMD)
+#define LAUNCH_PP2(HB_, VEC_)                                                      \
+  do {                                                                             \
+    if constexpr ((HB_) <= 1) {                                                    \
+      if (rows) LAUNCH_PP3(planar_pack_rows_kernel, ((HB_) <= 1 ? (HB_) : 1), VEC_); \
+      else LAUNCH_PP3(planar_pack_stream_kernel, HB_, VEC_);                       \
+    } else {                                                                       \
+      LAUNCH_PP3(planar_pack_stream_kernel, HB_, VEC_);                            \
+    }                                                                              \
   } while (0)
 #define LAUNCH_PP(HB_)               \
   do {                               \
@@ -812,7 +818,7 @@ const char* pack_kernel_name(const cpir_dtc_layout& L) {
   if (L.packing != CPIR_PACK_PLANAR) return "transpose_compress_kernel";
   const uint32_t hb = planar_hi_planes(L.mat_elem_bit_len), col_tiles = L.rows_padded / 16;
   const int rows_mode = pack_rows_mode();
-  const bool rows = rows_mode > 0 || (rows_mode < 0 && col_tiles >= 32 && hb <= 1);  // (the same rule as launch_planar_pack)
+  const bool rows = hb <= 1 && (rows_mode > 0 || (rows_mode < 0 && col_tiles >= 32));  // (the same rule as launch_planar_pack)
   return rows ? "planar_pack_rows_kernel" : "planar_pack_stream_kernel";
 }
 

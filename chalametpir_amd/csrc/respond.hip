@@ -286,7 +286,6 @@ __global__ void __launch_bounds__(kThreads) respond_kernel(const RespondArgs a) 
 
 // ---- tuning state (benchmark harness can override; defaults chosen from measurements) ----------------
 struct Tuning {
-  int rows_per_unit = 8;   // R in {4, 8, 16} (reference packing, single query)
   int nontemporal = 1;     // streamed DB loads with the nt cache policy (read once per query; keeps q in L2)
   int blocks_per_cu = 2;   // resident 256-thread blocks per CU; 0 = ask the occupancy API
   int xcd_split = 1;       // split the chunk axis by blockIdx % 8
@@ -314,14 +313,10 @@ struct Picked {
 };
 
 template <class P, int Q>
-Picked pick_rows(int R, bool nt) {
-  if constexpr (Q == 1 && P::kLoads == 1) {
-    if (R == 4) return {nt ? respond_kernel<P, 4, 1, true> : respond_kernel<P, 4, 1, false>, 4};
-    if (R == 16) return {nt ? respond_kernel<P, 16, 1, true> : respond_kernel<P, 16, 1, false>, 16};
-    return {nt ? respond_kernel<P, 8, 1, true> : respond_kernel<P, 8, 1, false>, 8};
-  } else if constexpr (Q == 1) {
-    // dense64: two loads per row per lane; R = 8 keeps 16 loads in flight per lane, R = 4 for tuning
-    if (R == 4) return {nt ? respond_kernel<P, 4, 1, true> : respond_kernel<P, 4, 1, false>, 4};
+Picked pick_rows(bool nt) {
+  if constexpr (Q == 1) {
+    // R database rows per unit: 8 (reference packing: one load per row and lane; dense64: two, i.e. 16 loads in flight per lane) -- rounds
+    // 1-2 also built R = 4 and 16 as tuning variants; 8 was the measured best at every configuration and is all that is left
     return {nt ? respond_kernel<P, 8, 1, true> : respond_kernel<P, 8, 1, false>, 8};
   } else {
     // fused batches keep Q*R accumulator pairs in registers
@@ -331,19 +326,19 @@ Picked pick_rows(int R, bool nt) {
 }
 
 template <int Q>
-Picked pick_kernel(const cpir_dtc_layout& L, int R, bool nt) {
+Picked pick_kernel(const cpir_dtc_layout& L, bool nt) {
   if (L.packing == CPIR_PACK_REFERENCE) {
     switch (L.compression_factor) {
-      case 2: return pick_rows<RefPack<2>, Q>(R, nt);
-      case 3: return pick_rows<RefPack<3>, Q>(R, nt);
-      default: return pick_rows<RefPack<4>, Q>(R, nt);
+      case 2: return pick_rows<RefPack<2>, Q>(nt);
+      case 3: return pick_rows<RefPack<3>, Q>(nt);
+      default: return pick_rows<RefPack<4>, Q>(nt);
     }
   }
   switch (L.mat_elem_bit_len) {  // the bit lengths dense_fields_per_word64() offers
-    case 7: return pick_rows<DensePack<7>, Q>(R, nt);
-    case 9: return pick_rows<DensePack<9>, Q>(R, nt);
-    case 11: return pick_rows<DensePack<11>, Q>(R, nt);
-    case 12: return pick_rows<DensePack<12>, Q>(R, nt);
+    case 7: return pick_rows<DensePack<7>, Q>(nt);
+    case 9: return pick_rows<DensePack<9>, Q>(nt);
+    case 11: return pick_rows<DensePack<11>, Q>(nt);
+    case 12: return pick_rows<DensePack<12>, Q>(nt);
     default: return {};
   }
 }
@@ -353,10 +348,7 @@ Picked pick_kernel(const cpir_dtc_layout& L, int R, bool nt) {
 extern "C" int cpir_tuning_set(const char* key, int value) {
   if (!key) return CPIR_ERR_INVALID_ARGUMENT;
   std::lock_guard<std::mutex> lk(g_tuning_mu);
-  if (!strcmp(key, "respond.rows_per_unit")) {
-    if (value != 4 && value != 8 && value != 16) return CPIR_ERR_INVALID_ARGUMENT;
-    g_tuning.rows_per_unit = value;
-  } else if (!strcmp(key, "respond.nontemporal")) {
+  if (!strcmp(key, "respond.nontemporal")) {
     g_tuning.nontemporal = value ? 1 : 0;
   } else if (!strcmp(key, "respond.blocks_per_cu")) {
     if (value < 0 || value > 8) return CPIR_ERR_INVALID_ARGUMENT;
@@ -536,9 +528,9 @@ int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout
   if (keep) return CPIR_ERR_INVALID_ARGUMENT;  // only the wide kernel applies a slot map itself: the caller gathers the queries first
   if (L.words_per_row_padded / L.chunk_words > 0xffffffffull) return CPIR_ERR_INVALID_ARGUMENT;
   Picked k;
-  if (batch == 1) k = pick_kernel<1>(L, t.rows_per_unit, t.nontemporal);
-  else if (batch == 2) k = pick_kernel<2>(L, t.rows_per_unit, t.nontemporal);
-  else if (batch == 4) k = pick_kernel<4>(L, t.rows_per_unit, t.nontemporal);
+  if (batch == 1) k = pick_kernel<1>(L, t.nontemporal);
+  else if (batch == 2) k = pick_kernel<2>(L, t.nontemporal);
+  else if (batch == 4) k = pick_kernel<4>(L, t.nontemporal);
   else return CPIR_ERR_INVALID_ARGUMENT;  // callers split other batch sizes into 4 / 2 / 1
   if (!k.fn) return CPIR_ERR_INVALID_ARGUMENT;
 

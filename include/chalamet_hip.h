@@ -249,7 +249,7 @@ int cpir_op_respond_batch(cpir_device* dev, const uint32_t* dtc, const cpir_dtc_
 int cpir_op_synth_fill(cpir_device* dev, uint32_t* out, uint64_t count, uint64_t seed, uint64_t index0, uint32_t mask,
                        void* stream);
 /* Tuning knobs of the respond kernel (benchmark harness only; defaults are the measured best):
- *   "respond.rows_per_unit" in {4, 8, 16}, "respond.nontemporal" {0,1}, "respond.blocks_per_cu" 0..8 (0 = occupancy API),
+ *   "respond.nontemporal" {0,1}, "respond.blocks_per_cu" 0..8 (0 = occupancy API),
  *   "respond.xcd_split" {0,1}, "respond.batch_fusion" {0,1} (0: every query of a batch call streams the database on its
  *   own, i.e. a batch call is only a cheaper way to enqueue independent responds), "respond.interleave_passes" {-1,0,1}
  *   (order in which one launch walks its passes; -1 = by shard size), "respond.planar_blocks_per_cu" 0..8, "respond.multi_pass_limit_mb"
@@ -269,7 +269,8 @@ int cpir_op_synth_fill(cpir_device* dev, uint32_t* out, uint64_t count, uint64_t
  *   for the words of a step -- default 2000, raised to what copying the whole query takes at 5 GB/s; 0: two launches, each when its half of the query is in place), "matmul.mfma" {0,1} (1, the default:
  *   cpir_op_mat_x_mat and the setup paths run right-hand sides below 2^16 on the i8 matrix cores; 0: on the integer VALU),
  *   "matmul.pipeline" {0,1} (1, the default: the software-pipelined matrix-core kernel; 0: its first cut),
- *   "pack.rows" {-1,0,1} (the planar pack pass: 1 = a block streams whole rows of D, 0 = 64-column waves, -1 -- the default -- by width),
+ *   "pack.rows" {-1,0,1} (the planar pack pass with at most one bit plane: 1 = a block streams whole rows of D, 0 = 64-column waves, -1 --
+ *   the default -- by width; with two or more bit planes always the 64-column waves),
  *   "layout.dense" {0,1} and "layout.planar" {0,1}
  *   (default packing chosen by cpir_dtc_layout_for and therefore by every cpir_server_* constructor: planar where it is
  *   offered and enabled, else dense64 where offered and enabled, else the reference packing),

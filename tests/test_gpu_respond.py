@@ -182,17 +182,14 @@ def test_every_kernel_variant_is_bit_identical(orc, device):
     q = random_query(rng, N)
     want = orc.row_vector_x_compressed_transposed_matrix(q, dtc, N, b)[0]
     try:
-        for R in (4, 8, 16):
-            for nt in (0, 1):
-                for xs in (0, 1):
-                    for bpc in (0, 1, 3):
-                        cp.tuning_set("respond.rows_per_unit", R)
-                        cp.tuning_set("respond.nontemporal", nt)
-                        cp.tuning_set("respond.xcd_split", xs)
-                        cp.tuning_set("respond.blocks_per_cu", bpc)
-                        assert np.array_equal(srv.respond_array(q), want), (R, nt, xs, bpc)
+        for nt in (0, 1):
+            for xs in (0, 1):
+                for bpc in (0, 1, 3):
+                    cp.tuning_set("respond.nontemporal", nt)
+                    cp.tuning_set("respond.xcd_split", xs)
+                    cp.tuning_set("respond.blocks_per_cu", bpc)
+                    assert np.array_equal(srv.respond_array(q), want), (nt, xs, bpc)
     finally:
-        cp.tuning_set("respond.rows_per_unit", 8)
         cp.tuning_set("respond.nontemporal", 1)
         cp.tuning_set("respond.xcd_split", 1)
         cp.tuning_set("respond.blocks_per_cu", 2)
