@@ -45,6 +45,21 @@ def main():
     slab, a, z = scatter_public_matrix(seed, 2000, 512, device=torch.device("cuda", 0), rows=37, block_bytes=4 * 2000 * 5)
     assert (a, z) == (0, 2000)
     assert np.array_equal(slab.cpu().numpy().view(np.uint32), cp.generate_from_seed(37, 2000, seed))
+    # every other collective bench.py --gpus N issues, with the dtypes and reduce ops it uses (one rank: the values must come back unchanged,
+    # but the backend has to accept the dtype / op combination): wall-time MAX in float64, int64 SUM / MIN / MAX of the multirank check,
+    # the step's asynchronous int32 all-reduce with its wait
+    t64 = torch.tensor([1.25, 2.5], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t64, op=dist.ReduceOp.MAX)
+    i64 = torch.tensor([3, -4, 1 << 40], dtype=torch.int64, device="cuda")
+    for op in (dist.ReduceOp.SUM, dist.ReduceOp.MIN, dist.ReduceOp.MAX):
+        v = i64.clone()
+        dist.all_reduce(v, op=op)
+        assert torch.equal(v, i64), op
+    big = torch.arange(256 * 940, dtype=torch.int32, device="cuda").reshape(256, 940)
+    work = dist.all_reduce(big, async_op=True)
+    work.wait()
+    torch.cuda.synchronize()
+    assert t64.tolist() == [1.25, 2.5] and int(big[255, 939]) == 256 * 940 - 1
     dist.barrier()
     dist.destroy_process_group()
     print("rccl single rank ok")
