@@ -639,7 +639,8 @@ respond_planar_wide_kernel(const PlanarArgs a) {
 #pragma unroll
         for (int d = 0; d < 4; d++) back[d] = *reinterpret_cast<const uint4*>(stage + (cl >> 2) * 64 + grp * 16 + d * 4);
         wave_lds_fence();
-        const bool arow = 4 * s + (cl >> 2) < nq;
+        const bool arow = 4 * s + (cl >> 2) < nq CPIR_DIAG_ONLY(&& !(a.ablate & 16u));  // (diagnosis, bit 16: all-zero A fragments -- the same
+                                                                                      // matrix instructions on operands that draw less power)
         uint32_t part = 0, o[4];
 #pragma unroll
         for (int d = 0; d < 4; d++) {
