@@ -51,7 +51,7 @@ def timed(k, reps):
 
 
 reps = max(3, int(20 * 1.2e9 / (N * C * b / 8)))
-for k in (1, 2, 4, 5, 6, 8, 12, 13, 16, 20, 24, 32, 48, 72, 96):
+for k in (1, 2, 4, 5, 6, 8, 12, 13, 16, 20, 24, 28, 32, 36, 48, 64, 72, 96):
     row = [f"batch {k:3d}:"]
     for ks_major in (2, 1):
         cp.tuning_set("respond.ks_major", ks_major)
