@@ -122,6 +122,7 @@ SIGNATURES = {
     "cpir_server_from_compressed": (C.c_int, [vp, u32p, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(vp)]),
     "cpir_server_export_compressed": (C.c_int, [vp, u32p, C.c_uint64]),
     "cpir_server_setup_timings": (C.c_int, [vp, C.POINTER(C.c_double)]),
+    "cpir_server_host_path_counts": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "cpir_server_retain": (vp, [vp]),
     "cpir_server_release": (None, [vp]),
     "cpir_server_layout": (C.c_int, [vp, C.POINTER(DtcLayout)]),

@@ -401,6 +401,16 @@ int cpir_server_setup_timings(const cpir_server* srv, double out[CPIR_SETUP_TIMI
   return CPIR_OK;
 }
 
+int cpir_server_host_path_counts(const cpir_server* srv, uint64_t out[CPIR_HOST_PATH_COUNT]) {
+  if (!srv || !out) return CPIR_ERR_INVALID_ARGUMENT;
+  const Server::Served& s = srv->served;
+  out[0] = s.calls.load(std::memory_order_relaxed), out[1] = s.alone.load(std::memory_order_relaxed);
+  out[2] = srv->fill_polled.load(std::memory_order_relaxed), out[3] = s.polled_void.load(std::memory_order_relaxed);
+  out[4] = s.in_uploaded_rounds.load(std::memory_order_relaxed), out[5] = s.uploaded_rounds.load(std::memory_order_relaxed);
+  out[6] = s.in_place_calls.load(std::memory_order_relaxed), out[7] = s.in_place_rounds.load(std::memory_order_relaxed);
+  return CPIR_OK;
+}
+
 cpir_server* cpir_server_retain(cpir_server* srv) {
   if (srv) srv->refs.fetch_add(1);
   return srv;

@@ -143,6 +143,11 @@ int launch_respond_read_once(const Device* dev, const uint32_t* dtc, const cpir_
                              const PlanarHostFill* fill = nullptr);
 // steps [step_lo, step_hi) of 512 slots only (0, 0 = all): a query may be answered by several launches, each over the steps whose
 // query words are in place by then; they add up in r
+// up to CPIR_PLANAR_KS_MAX_QUERIES_PER_PASS queries answered by ONE pass that reads each of them in place (q_rows: device-visible address of
+// word 0 of every query, every one q_len words long); r (batch x C) is zeroed by the call
+int launch_respond_read_rows_in_place(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* const* q_rows, uint32_t batch,
+                                      uint64_t q_len, uint64_t q_slot_offset, uint32_t* r, hipStream_t stream);
+uint32_t respond_inplace_seats();   // tuning "respond.inplace_seats" (0 = off, 2..4)
 uint32_t respond_upload_streams();  // tuning "respond.upload_streams" (1..4)
 uint32_t respond_helper_spin_us();  // tuning "respond.helper_spin_us"
 uint32_t respond_host_fill_timeout_us();  // tuning "respond.host_fill_timeout_us"; 0 = never launch in front of the copy
@@ -156,7 +161,9 @@ constexpr uint32_t CPIR_PLANAR_KS_MAX_QUERIES_PER_PASS = 4;
 int launch_respond_planar_ks(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                              uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, int blocks_per_cu,
                              bool nontemporal, bool xcd_split, bool in_place, bool r_prezeroed, uint64_t step_lo, uint64_t step_hi,
-                             const PlanarHostFill* fill);
+                             const PlanarHostFill* fill, const uint32_t* const* q_rows = nullptr);
+// q_rows (then q == NULL, one pass): the address of word 0 of each of the `batch` queries, wherever each lies -- the queries of concurrent
+// host callers read in place, each from its caller's page-locked buffer (device-visible addresses)
 uint32_t respond_planar_pass_width(const cpir_dtc_layout& L, uint32_t batch);  // respond.hip: queries per pass of a fused batch under the current tuning
 // the wide kernel: one 8-wave block per CU, up to 24 queries (six A row sets, looped) per stream of the database, any number of passes
 constexpr uint32_t CPIR_PLANAR_WIDE_MAX_QUERIES_PER_PASS = 24;

@@ -962,6 +962,7 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
     // the polled launch gave up waiting: its results are void.  The pinned block is complete by now: answer from it, without polling.
     polled = false;
     journal_note("respond: polled launch VOID", a->q_pinned, words * 4, __FILE__, __LINE__);
+    srv->served.polled_void.fetch_add(1, std::memory_order_relaxed);
     srv->fill_aborts.fetch_add(1, std::memory_order_relaxed);
     if (!a->r0_zero) e = hipMemsetAsync(a->r_dev, 0, (C + 1) * 4, st);
     a->r0_zero = false;
@@ -997,39 +998,70 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
   const double t_enter = tr ? now_seconds() : 0;
   const bool read_once_ok = respond_read_once_applicable(srv->phys);
   const size_t q_lo = (size_t)srv->slot_offset, q_hi = q_lo + (size_t)srv->layout.num_slots;
-  const bool caller_pinned = pinned_range_device_pointer(q + q_lo, (q_hi - q_lo) * 4) != nullptr;
+  const void* const q_dev_visible = pinned_range_device_pointer(q + q_lo, (q_hi - q_lo) * 4);
+  const bool caller_pinned = q_dev_visible != nullptr;
+  // A query that a pass may read in place beside those of other callers (RespondArena::in_place): page-locked, 16-byte aligned, no slot map
+  // (a compacted query exists nowhere until it is staged)
+  const uint32_t inplace_cap = respond_inplace_seats();
+  const uint32_t* q0_in_place = nullptr;  // the device-visible address of q[0]
+  if (caller_pinned && inplace_cap >= 2 && read_once_ok && !srv->map.active()) {
+    const uint32_t* const p = static_cast<const uint32_t*>(q_dev_visible) - q_lo;
+    if (reinterpret_cast<uintptr_t>(p) % 16 == 0) q0_in_place = p;
+  }
   std::unique_lock<std::mutex> lk(srv->mu);
   RespondArena* a = nullptr;
   bool solo = false;
+  // ... and only while the callers recently seen inside at the same time are few enough for one such pass: more of them are link-bound
+  // either way, and the upload path overlaps their copies with the kernel of the arena before
+  const uint32_t company = srv->inside + 1 > srv->peak_inside ? srv->inside + 1 : srv->peak_inside;
+  const bool want_in_place = q0_in_place && company >= 2 && company <= inplace_cap;
   for (;;) {
-    for (RespondArena& x : srv->arena)  // 1. an open arena that is still spreading
-      if (!a && x.state == RespondArena::OPEN && x.joined < srv->spread()) a = &x;
-    if (!a)
-      for (RespondArena& x : srv->arena)  // 2. a free arena
-        if (!a && x.state == RespondArena::FREE) {
-          if (!x.q_dev) CPIR_TRY(arena_create(srv, x));
-          a = &x, x.state = RespondArena::OPEN, x.status = CPIR_OK;
-          x.compact_seats = srv->map.active() && !caller_pinned;  // (see RespondArena)
-          // nobody else is filling an arena or on the device, and no company expected (with recent concurrent callers a lone launch
-          // would only split the batch they are about to form): this caller is served alone, its query read in place
-          solo = read_once_ok && srv->spread() == 1;
-          for (const RespondArena& y : srv->arena)
-            if (&y != a && (y.state == RespondArena::OPEN || y.state == RespondArena::LAUNCHED)) solo = false;
-          if (solo) x.state = RespondArena::LAUNCHED;  // closed at once: later callers open the next arena and upload meanwhile
-        }
-    if (!a)
-      for (RespondArena& x : srv->arena)  // 3. no arena free: fill the open one up
-        if (!a && x.state == RespondArena::OPEN && x.joined < Server::kSeats) a = &x;
+    if (want_in_place) {
+      for (RespondArena& x : srv->arena)  // 1. an open in-place arena with a seat left
+        if (!a && x.state == RespondArena::OPEN && x.in_place && x.joined < inplace_cap) a = &x;
+      if (!a)
+        for (RespondArena& x : srv->arena)  // 2. a free arena
+          if (!a && x.state == RespondArena::FREE) {
+            if (!x.q_dev) CPIR_TRY(arena_create(srv, x));
+            a = &x, x.state = RespondArena::OPEN, x.status = CPIR_OK;
+            x.compact_seats = false, x.in_place = true;
+          }
+    } else {
+      for (RespondArena& x : srv->arena)  // 1. an open arena that is still spreading
+        if (!a && x.state == RespondArena::OPEN && !x.in_place && x.joined < srv->spread()) a = &x;
+      if (!a)
+        for (RespondArena& x : srv->arena)  // 2. a free arena
+          if (!a && x.state == RespondArena::FREE) {
+            if (!x.q_dev) CPIR_TRY(arena_create(srv, x));
+            a = &x, x.state = RespondArena::OPEN, x.status = CPIR_OK;
+            x.compact_seats = srv->map.active() && !caller_pinned;  // (see RespondArena)
+            x.in_place = false;
+            // nobody else is filling an arena or on the device, and no company expected (with recent concurrent callers a lone launch
+            // would only split the batch they are about to form): this caller is served alone, its query read in place
+            solo = read_once_ok && srv->spread() == 1;
+            for (const RespondArena& y : srv->arena)
+              if (&y != a && (y.state == RespondArena::OPEN || y.state == RespondArena::LAUNCHED)) solo = false;
+            if (solo) x.state = RespondArena::LAUNCHED;  // closed at once: later callers open the next arena and upload meanwhile
+          }
+      if (!a)
+        for (RespondArena& x : srv->arena)  // 3. no arena free: fill the open one up
+          if (!a && x.state == RespondArena::OPEN && !x.in_place && x.joined < Server::kSeats) a = &x;
+    }
     if (a) break;
     srv->cv.wait(lk);  // every arena is full or in flight
   }
   const uint32_t seat = a->joined++;
   const bool leader = (seat == 0);
   const bool compact = a->compact_seats;
+  const bool in_place_round = a->in_place;
+  const uint32_t round_at_entry = __atomic_load_n(&a->rounds_done, __ATOMIC_RELAXED);
+  if (in_place_round) a->seat_q[seat] = q0_in_place;
   srv->caller_enters();
   lk.unlock();
   const double t_seated = tr ? now_seconds() : 0;
+  srv->served.calls.fetch_add(1, std::memory_order_relaxed);
   if (solo) {
+    srv->served.alone.fetch_add(1, std::memory_order_relaxed);
     const int st = respond_alone(srv, a, q, r_out);
     if (tr) {
       srv->trace.calls++, srv->trace.solo++;
@@ -1055,7 +1087,9 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
     ups = t ? srv->dev->up_more[t - 1] : srv->up_stream;
   };
   uint32_t* const qd = a->q_dev + seat * N;
-  if (compact) {
+  if (in_place_round) {
+    // nothing to stage, nothing to upload: the pass reads the caller's buffer
+  } else if (compact) {
     // A server that holds only the slots with a non-zero row: the query is COMPACTED onto them while it is staged (host_gather.cpp: one
     // sequential pass over the source through the bitmap of the kept slots, about the cost of the memcpy it replaces), so the link carries
     // n_kept of the N words -- 8/9 for a real encoded database -- and the launch needs no map.  In source pieces of 1 MiB where nobody
@@ -1200,7 +1234,9 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
         if (x.state == RespondArena::LAUNCHED) return false;
       return true;
     };
-    const double window = srv->batching_window_seconds();
+    // An in-place round always waits that moment for the callers recently seen beside this one (they were answered by the same pass and
+    // come back within tens of microseconds of each other): a second query costs the pass a tenth of its time, a second pass all of it.
+    const double window = in_place_round ? 60e-6 : srv->batching_window_seconds();
     double t_ready = -1;  // when the gate was first found open (the moment counts from there, not from when this caller arrived:
                           // the callers of the pass that has just finished are the company to wait for)
     for (;;) {
@@ -1210,7 +1246,8 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
       }
       const double now = now_seconds();
       if (t_ready < 0) t_ready = now;
-      if (a->joined >= srv->spread() || now - t_ready >= window) break;
+      const uint32_t expected = in_place_round ? (srv->peak_inside < inplace_cap ? srv->peak_inside : inplace_cap) : srv->spread();
+      if (a->joined >= expected || now - t_ready >= window) break;
       srv->cv.wait_for(lk, std::chrono::duration<double>(window - (now - t_ready)));
     }
     a->state = RespondArena::LAUNCHED;  // closed: later callers open the next arena
@@ -1218,9 +1255,42 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
     const uint32_t k = a->joined;
     int st = a->status;
     lk.unlock();
+    (in_place_round ? srv->served.in_place_rounds : srv->served.uploaded_rounds).fetch_add(1, std::memory_order_relaxed);
+    (in_place_round ? srv->served.in_place_calls : srv->served.in_uploaded_rounds).fetch_add(k, std::memory_order_relaxed);
     const double t_gate = tr ? now_seconds() : 0;
     hipError_t e = hipSuccess;
-    if (st == CPIR_OK) {
+    bool handed_over = false;
+    if (st == CPIR_OK && in_place_round) {
+      // ONE pass reads the k queries where they lie; the responses (and the word behind them, see respond_alone) are handed over by the
+      // one-block kernel that also leaves them zeroed on the device
+      uint32_t seq = 0;
+      {
+        std::lock_guard<std::mutex> ll(srv->dev->launch_mu);
+        a->r0_zero = false;
+        st = launch_respond_read_rows_in_place(srv->dev, srv->dtc, srv->phys, a->seat_q, k, srv->total_slots, srv->slot_offset, a->r_dev, srv->run_stream);
+        if (st == CPIR_OK) {
+          seq = ++a->hand_seq ? a->hand_seq : ++a->hand_seq;  // never 0
+          uint32_t* const r_host_dev = const_cast<uint32_t*>(a->q_pinned_dev) + (a->r_pinned - a->q_pinned);
+          hipLaunchKernelGGL(respond_hand_over_kernel, dim3(1), dim3(256), 0, srv->run_stream, a->r_dev, (uint32_t)(k * C + 1), r_host_dev, a->handed_dev, seq);
+          e = hipGetLastError();
+          if (e == hipSuccess) a->r0_zero = true;
+        }
+      }
+      if (st == CPIR_OK && e == hipSuccess) {
+        const double t0 = now_seconds();
+        while (!(handed_over = __atomic_load_n(a->handed, __ATOMIC_ACQUIRE) == seq)) {
+          if (now_seconds() - t0 > 5e-3) break;  // something is very slow or wrong: wait on the stream
+#if defined(__x86_64__)
+          __builtin_ia32_pause();
+#endif
+        }
+        if (!handed_over) {
+          e = hipStreamSynchronize(srv->run_stream);
+          if (e == hipSuccess && __atomic_load_n(a->handed, __ATOMIC_ACQUIRE) != seq) e = hipErrorUnknown;
+          handed_over = e == hipSuccess;
+        }
+      }
+    } else if (st == CPIR_OK) {
       std::lock_guard<std::mutex> ll(srv->dev->launch_mu);  // the launch sequences of two arenas must not interleave on the run stream
       for (uint32_t i = 0; i < k && e == hipSuccess; i++) e = hipStreamWaitEvent(srv->run_stream, a->seat_ev[i], 0);
       a->r0_zero = false;
@@ -1233,7 +1303,9 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
     const double t_enq = tr ? now_seconds() : 0;
     // always wait for what was enqueued for this arena before it can be reused: the uploads (they may have failed half way) and the launch
     hipError_t e2 = hipSuccess;
-    if (st == CPIR_OK && e == hipSuccess) {
+    if (handed_over) {
+      // (the responses are in r_pinned, the stream has nothing of this round left)
+    } else if (st == CPIR_OK && e == hipSuccess) {
       e2 = wait_for_event(a->done_ev);
     } else {
       sync_upload_streams(srv->dev);
@@ -1253,8 +1325,20 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
     lk.lock();
     a->status = st;
     a->state = RespondArena::DONE;
+    __atomic_fetch_add(&a->rounds_done, 1u, __ATOMIC_RELEASE);
     srv->cv.notify_all();
   } else {
+    if (in_place_round) {
+      // the pass is a couple of hundred microseconds away and a sleeping thread takes tens of them to wake: look for its end for a while
+      lk.unlock();
+      const double t0 = now_seconds();
+      while (__atomic_load_n(&a->rounds_done, __ATOMIC_ACQUIRE) == round_at_entry && now_seconds() - t0 < 2e-3) {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+      }
+      lk.lock();
+    }
     srv->cv.wait(lk, [&] { return a->state == RespondArena::DONE; });
     if (tr) srv->trace.ns_follow += (uint64_t)((now_seconds() - t_staged) * 1e9);
   }

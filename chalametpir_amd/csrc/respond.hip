@@ -296,6 +296,7 @@ struct Tuning {
   int host_fill_timeout_us = 2000;  // a lone pageable host query: ONE launch polling the copy's progress, each wave for at most this long (0: off)
   int host_zero_copy = 1;          // a lone host query is read by the kernel in place (page-locked memory), not uploaded first
   int upload_streams = 2;          // concurrent host callers: their uploads take this many streams in turn (1..4)
+  int inplace_seats = 4;           // concurrent page-locked host callers, up to this many at a time: ONE pass reads their queries in place (0: off)
   int helper_spin_us = 300;        // a lone pageable caller: the copy helpers keep looking for its next query this long before they sleep
   // planar packing, device-resident queries: 1 = the wide kernel takes every launch (the step-major kernel serves the in-place host path
   // only); 2 = the step-major kernel wherever it applies (passes of up to 4 queries in slice order: tests and A/B runs); 3 = as 2, launched
@@ -374,6 +375,9 @@ extern "C" int cpir_tuning_set(const char* key, int value) {
   } else if (!strcmp(key, "respond.helper_spin_us")) {
     if (value < 0 || value > 10000) return CPIR_ERR_INVALID_ARGUMENT;
     g_tuning.helper_spin_us = value;
+  } else if (!strcmp(key, "respond.inplace_seats")) {
+    if (value < 0 || value == 1 || value > (int)CPIR_PLANAR_KS_MAX_QUERIES_PER_PASS) return CPIR_ERR_INVALID_ARGUMENT;
+    g_tuning.inplace_seats = value;
   } else if (!strcmp(key, "respond.upload_streams")) {
     if (value < 1 || value > 4) return CPIR_ERR_INVALID_ARGUMENT;
     g_tuning.upload_streams = value;
@@ -465,6 +469,11 @@ uint32_t respond_helper_spin_us() {
   return (uint32_t)g_tuning.helper_spin_us;
 }
 
+uint32_t respond_inplace_seats() {
+  std::lock_guard<std::mutex> lk(g_tuning_mu);
+  return (uint32_t)g_tuning.inplace_seats;
+}
+
 uint32_t respond_upload_streams() {
   std::lock_guard<std::mutex> lk(g_tuning_mu);
   return (uint32_t)g_tuning.upload_streams;
@@ -495,6 +504,23 @@ int launch_respond_read_once(const Device* dev, const uint32_t* dtc, const cpir_
   }
   return launch_respond_planar_ks(dev, dtc, L, q, q_len, q_slot_offset, 1, 1, r_prezeroed, stream, t.planar_blocks_per_cu, t.nontemporal != 0,
                                   t.xcd_split != 0, true, true, step_lo, step_hi, fill);
+}
+
+int launch_respond_read_rows_in_place(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* const* q_rows, uint32_t batch,
+                                      uint64_t q_len, uint64_t q_slot_offset, uint32_t* r, hipStream_t stream) {
+  if (!dtc || !q_rows || !r || L.packing != CPIR_PACK_PLANAR) return CPIR_ERR_INVALID_ARGUMENT;
+  CPIR_TRY(check_layout(L));
+  if (q_slot_offset + L.num_slots > q_len) return CPIR_ERR_SHARD_RANGE;
+  if (reinterpret_cast<uintptr_t>(dtc) % 16 != 0) return CPIR_ERR_INVALID_ARGUMENT;
+  Tuning t;
+  {
+    std::lock_guard<std::mutex> lk(g_tuning_mu);
+    t = g_tuning;
+  }
+  // (contiguous units, not the strided steps of a lone query that may still be arriving: every query is complete, and the slot axis split
+  // over the XCDs keeps an XCD's share of the queries in its own L2)
+  return launch_respond_planar_ks(dev, dtc, L, nullptr, q_len, q_slot_offset, batch, 1, r, stream, t.planar_blocks_per_cu, t.nontemporal != 0,
+                                  t.xcd_split != 0, true, false, 0, 0, nullptr, q_rows);
 }
 
 int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,

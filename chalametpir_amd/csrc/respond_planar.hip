@@ -77,6 +77,9 @@ struct PlanarArgs {
   uint64_t poll_ticks;       // ... after this many ticks of the 100 MHz wall clock
   const uint32_t* keep;      // wide pass: the database holds only the slots keep[0 .. num_slots) of the query (increasing, relative to q_slot_offset;
                              // compact.hip); NULL: slot n of the database is word q_slot_offset + n of the query
+  const uint32_t *q_row0, *q_row1, *q_row2, *q_row3;  // (four plain fields: an array inside the argument struct is sent through scratch memory)
+                             // step-major kernel, one pass: where word 0 of each query of the pass lies -- the queries of concurrent host callers,
+                             // read in place from wherever each caller's page-locked buffer is (q_row0 == NULL: query i is q + i * q_len)
 #ifdef CPIR_DIAG  // (a diagnosis build only: the release library has neither field nor any code that reads them)
   uint64_t* trace;           // CPIR_KS_TRACE: per block 4 words -- wall clock at entry, after the first fragments, at the end; visits
   uint32_t ablate;           // wide pass, CPIR_WIDE_ABLATE (results are WRONG while non-zero): 1 no rebuild of the fragments, 2 no flush, 4 no MFMAs
@@ -206,13 +209,21 @@ respond_planar_ks_kernel(const PlanarArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
   const uint32_t half = lane >> 5, l32 = lane & 31;
+  const uint32_t* const qr0 = a.q_row0;
+  const uint32_t* const qr1 = a.q_row1;
+  const uint32_t* const qr2 = a.q_row2;
+  const uint32_t* const qr3 = a.q_row3;
   auto a_issue = [&](uint4(&raw)[2 * NS], uint32_t ks_, uint32_t pass_) __attribute__((always_inline)) {
     const uint64_t base = (uint64_t)ks_ * CPIR_PLANAR_SLOTS_PER_TILE + wave * 128 + l32 * 4;
 #pragma unroll
     for (int i = 0; i < 2 * NS; i++) {
       const uint32_t row = 2 * i + half;
       raw[i] = make_uint4(0, 0, 0, 0);
-      if (row < nq) raw[i] = *reinterpret_cast<const uint4*>(a.q + ((uint64_t)pass_ * nq + row) * a.q_len + a.q_slot_offset + base);
+      if (row < nq) {
+        // (a table of row addresses: uniform pointers, the lane picks the one of its row -- rows 2 i and 2 i + 1 by its half of the wave)
+        const uint32_t* const rp = qr0 ? (i == 0 ? (half ? qr1 : qr0) : (half ? qr3 : qr2)) : a.q + ((uint64_t)pass_ * nq + row) * a.q_len;
+        raw[i] = *reinterpret_cast<const uint4*>(rp + a.q_slot_offset + base);
+      }
     }
   };
   // this wave's sum of the query words of a step, per query: the four lanes that share a query word (one per byte limb) count it once
@@ -271,7 +282,11 @@ respond_planar_ks_kernel(const PlanarArgs a) {
     uint32_t part[NS];
     for (int s = 0; s < NS; s++) {
       part[s] = 0;
-      const uint32_t* qrow = a.q + ((uint64_t)pass_ * nq + qi[s]) * a.q_len + a.q_slot_offset;
+      // (two selects by bit, not a chain of comparisons: the compiler turns the chain into a table in scratch memory)
+      const uint32_t* const t_lo = (qi[s] & 1u) ? qr1 : qr0;
+      const uint32_t* const t_hi = (qi[s] & 1u) ? qr3 : qr2;
+      const uint32_t* const tabled = (qi[s] & 2u) ? t_hi : t_lo;
+      const uint32_t* qrow = (qr0 ? tabled : a.q + ((uint64_t)pass_ * nq + qi[s]) * a.q_len) + a.q_slot_offset;
       for (int h = 0; h < 2; h++) {
         const int kb = 2 * wave + h;
         const uint64_t base = slot0 + kb * 64 + grp * 16;
@@ -1000,9 +1015,10 @@ bool planar_passes_interleaved(const cpir_dtc_layout& L, uint32_t passes, int in
 int launch_respond_planar_ks(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,
                              uint64_t q_slot_offset, uint32_t batch, uint32_t passes, uint32_t* r, hipStream_t stream, int blocks_per_cu,
                              bool nontemporal, bool xcd_split, bool in_place, bool r_prezeroed, uint64_t step_lo, uint64_t step_hi,
-                             const PlanarHostFill* fill) {
+                             const PlanarHostFill* fill, const uint32_t* const* q_rows) {
   // shape invariants the kernel relies on (layout already checked by the caller)
   if (L.packing != CPIR_PACK_PLANAR || batch == 0 || batch > CPIR_PLANAR_KS_MAX_QUERIES_PER_PASS || passes == 0) return CPIR_ERR_INVALID_ARGUMENT;
+  if (q_rows && (passes != 1 || q)) return CPIR_ERR_INVALID_ARGUMENT;  // (a table of row addresses: one pass, and no base beside it)
   const uint32_t hb = planar_hi_planes(L.mat_elem_bit_len);
   KernelFn fn = pick_ks(hb, nontemporal);
   if (!fn || L.chunk_words != (8 + hb) * 256 || L.rows_padded % 16 != 0) return CPIR_ERR_INVALID_ARGUMENT;
@@ -1039,6 +1055,17 @@ int launch_respond_planar_ks(const Device* dev, const uint32_t* dtc, const cpir_
   CPIR_DIAG_ONLY(a.ablate = 0; a.trace = nullptr;)
   if (fill && (!in_place || !fill->progress || !fill->abort_flag)) return CPIR_ERR_INVALID_ARGUMENT;
   a.q_scalar = (reinterpret_cast<uintptr_t>(q) % 16 != 0 || q_slot_offset % 4 != 0 || (batch * passes > 1 && q_len % 4 != 0)) ? 1u : 0u;
+  a.q_row0 = a.q_row1 = a.q_row2 = a.q_row3 = nullptr;
+  if (q_rows) {
+    a.q_scalar = q_slot_offset % 4 != 0 ? 1u : 0u;
+    const uint32_t* rows[4];
+    for (uint32_t i = 0; i < 4; i++) {
+      rows[i] = q_rows[i < batch ? i : 0];  // (the rows beyond the batch are never read; a valid address all the same)
+      if (!rows[i]) return CPIR_ERR_INVALID_ARGUMENT;
+      if (reinterpret_cast<uintptr_t>(rows[i]) % 16 != 0) a.q_scalar = 1u;
+    }
+    a.q_row0 = rows[0], a.q_row1 = rows[1], a.q_row2 = rows[2], a.q_row3 = rows[3];
+  }
 
   // The kernel keeps a pass's responses in LDS: 64 columns x batch u32 per tile group, at most 48 KiB.  Where all tile groups do not fit
   // (one query beyond 12 288 columns) the launch is repeated over column WINDOWS of as many tile groups as fit, each a launch of its own
@@ -1142,6 +1169,7 @@ int launch_respond_planar_wide(const Device* dev, const uint32_t* dtc, const cpi
   a.trace = nullptr;
   if ((ablate_env & 8u) && hb == 1 && nt && !keep) fn = respond_planar_wide_kernel<1, true, false, true>;  // (the 32x32x32 emulation: see the kernel)
 #endif
+  a.q_row0 = a.q_row1 = a.q_row2 = a.q_row3 = nullptr;
   a.keep = keep;  // (device memory, at least L.num_slots entries, 16-byte aligned; the caller has checked that the slots it names lie inside q)
   if (keep && reinterpret_cast<uintptr_t>(keep) % 16 != 0) return CPIR_ERR_INVALID_ARGUMENT;
 

@@ -52,6 +52,13 @@ struct RespondArena {
   // stages it, uploads 8/9 of the words into q_compact, and the launch needs no map -- or whole ones (DMA straight from page-locked caller
   // buffers, the kernel applies the map).  Decided by the caller that opens the arena, the same for all its seats; guarded by Server::mu.
   bool compact_seats = false;
+  // (a few concurrent callers whose queries lie in page-locked memory) the seats of this round are not uploaded at all: ONE pass of the
+  // step-major kernel reads every seat's query IN PLACE over the host link, each from its caller's own buffer -- the upload (83 us per query
+  // at 2^20 keys x 1 kB, one after the other) disappears behind the stream of the database, as it does for a lone caller.  seat_q[i] is the
+  // device-visible address of word 0 of seat i's query.  Decided by the caller that opens the arena; guarded by Server::mu.
+  bool in_place = false;
+  const uint32_t* seat_q[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  uint32_t rounds_done = 0;  // (atomic accesses) bumped when a round's responses are in r_pinned: what the followers of an in-place round spin on
   // guarded by Server::mu
   enum State { FREE, OPEN, LAUNCHED, DONE } state = FREE;
   uint32_t joined = 0;  // seats taken
@@ -121,6 +128,10 @@ struct Server {
     std::atomic<uint64_t> polled{0}, ns_p_submit{0}, ns_p_launch{0}, ns_p_copied{0}, ns_p_done{0};
   } trace;
   bool trace_on = false;
+  // how the host callers have been served (cpir_server_host_path_counts): always counted, a relaxed add each
+  struct Served {
+    std::atomic<uint64_t> calls{0}, alone{0}, polled_void{0}, in_uploaded_rounds{0}, uploaded_rounds{0}, in_place_calls{0}, in_place_rounds{0};
+  } served;
   std::mutex mu;
   std::condition_variable cv;
   RespondArena arena[kArenas];  // each allocated on first use (a lone caller only ever needs the first)

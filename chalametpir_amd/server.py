@@ -521,6 +521,15 @@ class Server:
         _check(self._lib.cpir_server_setup_timings(self._h, out))
         return dict(zip(self.SETUP_PHASES, [float(x) for x in out]))
 
+    HOST_PATH_COUNTS = ("calls", "alone_in_place", "alone_polled", "polled_given_up", "in_uploaded_rounds", "uploaded_rounds",
+                        "in_in_place_rounds", "in_place_rounds")
+
+    def host_path_counts(self) -> dict:
+        """how the host callers of respond() have been served by this handle so far (cpir_server_host_path_counts)"""
+        out = (C.c_uint64 * 8)()
+        _check(self._lib.cpir_server_host_path_counts(self._h, out))
+        return dict(zip(self.HOST_PATH_COUNTS, [int(x) for x in out]))
+
     def export_compressed(self) -> np.ndarray:
         """compressed_transposed_parsed_db_mat_d in the reference's layout (C x ceil(N/cf)) (server.rs:18)"""
         out = np.empty((self.layout.num_cols, self.layout.words_per_row), dtype=np.uint32)

@@ -129,6 +129,7 @@ int main(int argc, char** argv) {
     g_want[k] = (uint32_t*)malloc(4 * (size_t)g_C);
     CHECK(cpir_server_respond(g_srv, g_q[k], 1, g_N, g_want[k]));
   }
+  if (getenv("CPIR_BENCH_INPLACE_SEATS")) CHECK(cpir_tuning_set("respond.inplace_seats", atoi(getenv("CPIR_BENCH_INPLACE_SEATS")))); /* A/B */
   /* 4th argument "tT" (e.g. t16) + 5th 0 / 1: ONLY T closed-loop callers with pageable / page-locked queries, three rounds (with
    * CPIR_RESPOND_TRACE=1 the library prints where their time went when the server is released) */
   if (argc > 4 && argv[4][0] == 't') {

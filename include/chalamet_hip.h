@@ -262,6 +262,9 @@ int cpir_op_synth_fill(cpir_device* dev, uint32_t* out, uint64_t count, uint64_t
  *   does not pay for waking them -- before they go to sleep; default 300, 0: sleep at once),
  *   "respond.upload_streams" 1..4 (concurrent host callers: their query uploads take this many HIP streams in turn, so that one copy is
  *   set up while another crosses the link; default 2),
+ *   "respond.inplace_seats" 0, 2..4 (a few concurrent host callers whose queries lie in page-locked memory are answered by ONE pass that
+ *   reads every query in place over the host link, each from its caller's own buffer, instead of uploading them one after the other:
+ *   up to this many callers per pass, and only while no more than that were recently seen inside at the same time; default 4, 0: off),
  *   "respond.host_zero_copy" {0,1}
  *   (1, the default: cpir_server_respond serves a caller that finds the server idle without an upload, the kernel reading the
  *   query in place from page-locked host memory; 0: always stage + upload first), "respond.host_fill_timeout_us" 0..1000000
@@ -393,6 +396,16 @@ int cpir_server_export_compressed(const cpir_server* srv, uint32_t* compressed_o
  *   [6] hint device->host                                     [7] total wall time of the call */
 #define CPIR_SETUP_TIMING_COUNT 8
 int cpir_server_setup_timings(const cpir_server* srv, double out[CPIR_SETUP_TIMING_COUNT]);
+
+/* How the host callers of cpir_server_respond have been served by this handle so far (a group handle: summed over its shards' own
+ * counts is NOT done -- a group scatters every query; all zero there):
+ *   [0] calls answered   [1] ... alone, the query read in place over the host link (no upload)
+ *   [2] ... alone, by one launch polling the copy of a pageable query   [3] such launches that gave up waiting (answered again)
+ *   [4] calls answered in uploaded rounds (concurrent callers: staged, uploaded, one fused pass per round)   [5] uploaded rounds
+ *   [6] calls answered in in-place rounds (a few concurrent callers with page-locked queries: one pass reads them where they lie)
+ *   [7] in-place rounds */
+#define CPIR_HOST_PATH_COUNT 8
+int cpir_server_host_path_counts(const cpir_server* srv, uint64_t out[CPIR_HOST_PATH_COUNT]);
 
 cpir_server* cpir_server_retain(cpir_server* srv);  /* #[derive(Clone)] (server.rs:15) */
 void cpir_server_release(cpir_server* srv);         /* Drop */

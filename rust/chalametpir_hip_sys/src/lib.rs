@@ -8,6 +8,7 @@ pub const CPIR_LWE_DIMENSION: u32 = 1774;
 pub const CPIR_SEED_BYTE_LEN: usize = 32;
 pub const CPIR_FILTER_PARAM_BYTE_LEN: usize = 68;
 pub const CPIR_SETUP_TIMING_COUNT: usize = 8;
+pub const CPIR_HOST_PATH_COUNT: usize = 8;
 
 pub const CPIR_OK: c_int = 0;
 pub const CPIR_ERR_INVALID_MATRIX_DIMENSION: c_int = 1;
@@ -151,6 +152,7 @@ unsafe extern "C" {
                                        out: *mut *mut cpir_server) -> c_int;
     pub fn cpir_server_export_compressed(srv: *const cpir_server, compressed_out: *mut u32, out_words: u64) -> c_int;
     pub fn cpir_server_setup_timings(srv: *const cpir_server, out: *mut f64) -> c_int;
+    pub fn cpir_server_host_path_counts(srv: *const cpir_server, out: *mut u64) -> c_int;
     pub fn cpir_server_retain(srv: *mut cpir_server) -> *mut cpir_server;
     pub fn cpir_server_release(srv: *mut cpir_server);
     pub fn cpir_server_layout(srv: *const cpir_server, out: *mut cpir_dtc_layout) -> c_int;

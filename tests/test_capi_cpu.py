@@ -221,7 +221,8 @@ def test_every_documented_tuning_key_is_accepted_and_bounded():
     for key, value in defaults.items():
         cp.tuning_set(key, value)
     for key, bad in (("respond.ks_major", 4), ("respond.ks_major", 0), ("respond.host_fill_timeout_us", -5),
-                     ("respond.host_fill_timeout_us", 2_000_000), ("respond.no_such_key", 1)):
+                     ("respond.host_fill_timeout_us", 2_000_000), ("respond.inplace_seats", 1), ("respond.inplace_seats", 5),
+                     ("respond.no_such_key", 1)):
         with pytest.raises(ChalametPIRError):
             cp.tuning_set(key, bad)
 

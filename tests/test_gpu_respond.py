@@ -359,6 +359,76 @@ def test_lone_host_query_is_read_in_place(orc, device):
             pin.close()
 
 
+def test_a_few_concurrent_page_locked_callers_share_one_pass_that_reads_their_queries_in_place(orc, device, packing):
+    """respond.inplace_seats (default 4): two to four concurrent callers whose queries lie in page-locked memory are answered by ONE pass of
+    the step-major kernel that reads every query where it lies (a table of row addresses: each caller's own buffer) -- no upload.  Same
+    answers as the oracle for a whole server and for a shard that starts in the middle of the query, beside pageable callers and a caller
+    whose page-locked view is not 16-byte aligned (both take the upload path); with the key at 0 no such round is ever formed."""
+    import torch
+
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(20251)
+    b, N, C = 9, (1 << 19) + 5 * 512 + 37, 21
+    D = random_db_matrix(rng, N, C, b)
+    dtc = orc.row_wise_compress(orc.transpose(D), b)
+    lo, hi = 1024 * 5, N - 777
+    dtc_shard = orc.row_wise_compress(orc.transpose(D[lo:hi]), b)
+    n_q = 6
+    qs = [random_query(rng, N) for _ in range(n_q)]
+    want = [orc.row_vector_x_compressed_transposed_matrix(q, dtc, N, b)[0] for q in qs]
+    want_shard = [orc.row_vector_x_compressed_transposed_matrix(q[lo:hi], dtc_shard, hi - lo, b)[0] for q in qs]
+    pins = [cp.PinnedArray(N + 4) for _ in range(n_q)]
+    for pa, q in zip(pins, qs):
+        pa.array[:N] = q
+    shifted = cp.PinnedArray(N + 4)
+    shifted.array[1:N + 1] = qs[0]
+    try:
+        for seats in (4, 2, 0):
+            cp.tuning_set("respond.inplace_seats", seats)
+            whole = cp.Server.from_compressed(dtc, N, b, device=device)
+            D_dev = torch.from_numpy(np.ascontiguousarray(D[lo:hi]).view(np.int32)).cuda()
+            shard = cp.Server.from_device_matrix(D_dev, hi - lo, C, b, device=device, slot_offset=lo, total_slots=N)
+            for srv, wanted in ((whole, want), (shard, want_shard)):
+                for callers in (2, 3, 4, 6):
+                    bad = []
+                    start = threading.Barrier(callers)
+
+                    def ask(t):
+                        start.wait()
+                        for i in range(12):
+                            k = (t + i) % n_q
+                            if t == 4:  # a pageable caller beside them
+                                got = srv.respond_array(qs[k])
+                            elif t == 5:  # page-locked, but not 16-byte aligned
+                                got, k = srv.respond_array(shifted.array[1:N + 1]), 0
+                            else:
+                                got = srv.respond_array(pins[k].array[:N])
+                            if not np.array_equal(got, wanted[k]):
+                                bad.append((t, i, k))
+
+                    ts = [threading.Thread(target=ask, args=(t,)) for t in range(callers)]
+                    for t in ts:
+                        t.start()
+                    for t in ts:
+                        t.join()
+                    assert not bad, (seats, callers, bad[:4])
+                counts = srv.host_path_counts()
+                assert counts["calls"] == 12 * (2 + 3 + 4 + 6), counts
+                assert counts["calls"] == counts["alone_in_place"] + counts["in_uploaded_rounds"] + counts["in_in_place_rounds"], counts
+                if seats == 0 or not packing.startswith("planar"):  # (the other packings have no kernel that reads a query once)
+                    assert counts["in_place_rounds"] == 0 and counts["in_in_place_rounds"] == 0, counts
+                else:
+                    assert counts["in_place_rounds"] > 0 and counts["in_in_place_rounds"] <= seats * counts["in_place_rounds"], counts
+            whole.close()
+            shard.close()
+    finally:
+        cp.tuning_set("respond.inplace_seats", 4)
+        for pa in pins:
+            pa.close()
+        shifted.close()
+
+
 def test_partly_registered_query_buffer_is_not_read_in_place(orc, device):
     """hipHostRegister over only the first half of a query buffer: the in-place path must see that the END of the range is not
     page-locked and stage the query instead (a kernel reading unmapped host pages would fault); registered as a whole it is read in place.

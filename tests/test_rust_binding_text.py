@@ -114,7 +114,7 @@ def test_same_constants():
     h, r = header_constants(), rust_constants()
     status = {k for k in h if k == "CPIR_OK" or k.startswith("CPIR_ERR_")}
     assert len(status) == 18
-    for k in status | {"CPIR_LWE_DIMENSION", "CPIR_SEED_BYTE_LEN", "CPIR_FILTER_PARAM_BYTE_LEN", "CPIR_SETUP_TIMING_COUNT"}:
+    for k in status | {"CPIR_LWE_DIMENSION", "CPIR_SEED_BYTE_LEN", "CPIR_FILTER_PARAM_BYTE_LEN", "CPIR_SETUP_TIMING_COUNT", "CPIR_HOST_PATH_COUNT"}:
         assert k in r and r[k] == h[k], k
     for k, v in r.items():  # nothing in the binding that the header does not define
         assert h.get(k) == v, k
