@@ -135,6 +135,8 @@ struct PlanarHostFill {
   const uint32_t* progress;
   uint32_t* abort_flag;
   uint32_t timeout_us;
+  uint32_t seats = 1;  // queries of the pass that are being copied in, each counted in CPIR_FILL_LINES copies of its own, one set behind the other
+                       // (the queries of a round of concurrent host callers, each copied by its caller's thread)
 };
 // one query whose words are read exactly once (q may therefore live in page-locked host memory: device-visible pointer), r already zero;
 // planar packing only, CPIR_ERR_INVALID_ARGUMENT where the step-major kernel does not apply
@@ -146,7 +148,7 @@ int launch_respond_read_once(const Device* dev, const uint32_t* dtc, const cpir_
 // up to CPIR_PLANAR_KS_MAX_QUERIES_PER_PASS queries answered by ONE pass that reads each of them in place (q_rows: device-visible address of
 // word 0 of every query, every one q_len words long); r (batch x C) is zeroed by the call
 int launch_respond_read_rows_in_place(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* const* q_rows, uint32_t batch,
-                                      uint64_t q_len, uint64_t q_slot_offset, uint32_t* r, hipStream_t stream);
+                                      uint64_t q_len, uint64_t q_slot_offset, uint32_t* r, hipStream_t stream, const PlanarHostFill* fill = nullptr);
 uint32_t respond_inplace_seats();   // tuning "respond.inplace_seats" (0 = off, 2..4)
 uint32_t respond_upload_streams();  // tuning "respond.upload_streams" (1..4)
 uint32_t respond_helper_spin_us();  // tuning "respond.helper_spin_us"

@@ -286,7 +286,9 @@ static void arenas_destroy(Server* srv) {
 
 // spare words behind the response seats of an arena's two blocks: the fill progress of a lone query in CPIR_FILL_LINES copies (pinned
 // block; + 16 words so that the copies can start on a 64-byte line), the abort flag (device block, behind seat 0's response)
-static constexpr size_t kArenaSpareWords = (size_t)CPIR_FILL_LINES * 16 + 16 + 16;  // (+ one line behind the fill counts: the hand-over flag)
+// (four sets of fill counts -- one per seat of an in-place round, a lone caller uses the first -- + one line behind them: the hand-over flag)
+static constexpr uint32_t kRoundSeats = CPIR_PLANAR_KS_MAX_QUERIES_PER_PASS;
+static constexpr size_t kArenaSpareWords = (size_t)kRoundSeats * CPIR_FILL_LINES * 16 + 16 + 16;
 static void publish_fill_progress(uint32_t* lines, uint32_t steps) {
   for (uint32_t i = 0; i < CPIR_FILL_LINES; i++) __atomic_store_n(lines + i * 16, steps, __ATOMIC_RELEASE);
 }
@@ -321,8 +323,8 @@ static int arena_create(Server* srv, RespondArena& a) {
     const size_t off = (qw + rw - kArenaSpareWords + 15) / 16 * 16;  // the copies start on a 64-byte line (the block itself is page-aligned)
     a.fill_progress = a.q_pinned + off;
     a.fill_progress_dev = a.q_pinned_dev + off;
-    a.handed = a.fill_progress + (size_t)CPIR_FILL_LINES * 16;  // a line of its own behind the fill counts
-    a.handed_dev = const_cast<uint32_t*>(a.fill_progress_dev) + (size_t)CPIR_FILL_LINES * 16;
+    a.handed = a.fill_progress + (size_t)kRoundSeats * CPIR_FILL_LINES * 16;  // a line of its own behind the fill counts
+    a.handed_dev = const_cast<uint32_t*>(a.fill_progress_dev) + (size_t)kRoundSeats * CPIR_FILL_LINES * 16;
     __atomic_store_n(a.handed, 0u, __ATOMIC_RELAXED);
     a.hand_seq = 0;
   }
@@ -852,7 +854,8 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
     // how long a wave waits for the words of a step (the tuning value, default 2 ms), but never less than the whole copy would take at
     // 5 GB/s -- a quarter of what ONE core copies: the last steps of a long query are legitimately waited for that long
     uint32_t fill_timeout_us = respond_host_fill_timeout_us();
-    if (fill_timeout_us > 0 && words * 4 / 5000 > fill_timeout_us) fill_timeout_us = (uint32_t)(words * 4 / 5000);
+    // (values below 100 us are taken as they are: how the tests make a launch give up)
+    if (fill_timeout_us >= 100 && words * 4 / 5000 > fill_timeout_us) fill_timeout_us = (uint32_t)(words * 4 / 5000);
     if (words >= ((size_t)1 << 19) && n_jobs <= kMaxJobs && g_staging.try_acquire()) {
       std::atomic<int> done[kMaxJobs];
       // ONE launch that overlaps the copy: the kernel takes the steps of q round-robin (front to back over the whole grid) and waits
@@ -984,6 +987,168 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
   return rc;
 }
 
+// An IN-PLACE ROUND (RespondArena::in_place): two to four concurrent callers answered by ONE pass of the step-major kernel that reads every
+// query over the host link where it lies -- a page-locked caller buffer as it is; a pageable query from the seat's part of the arena's pinned
+// block, into which its caller's own thread copies it front to back WHILE the pass, launched in front of the copies, polls each seat's
+// progress (what respond_alone does for a lone caller, once per seat).  Against the upload path -- stage, upload the queries one after the
+// other (83 us each at 2^20 keys x 1 kB), then the kernel -- a round of two costs one pass (~230 us), not an upload and a pass each.
+// The caller holds seat `seat` of the open arena `a`; q0_in_place: the device-visible address of q[0] where the query is page-locked.
+static int respond_in_round(Server* srv, RespondArena* a, uint32_t seat, const uint32_t* q, const uint32_t* q0_in_place, uint32_t inplace_cap,
+                            uint32_t round_at_entry, uint32_t* r_out) {
+  const size_t C = srv->layout.num_cols;
+  const size_t q_lo = (size_t)srv->slot_offset, words = (size_t)srv->layout.num_slots;
+  const bool leader = seat == 0, pageable = q0_in_place == nullptr;
+  const size_t stride = ((size_t)srv->total_slots + 31) / 32 * 32;  // of the seats' blocks: each starts on a 128-byte line (see respond_alone)
+  uint32_t* const my_lines = a->fill_progress + (size_t)seat * CPIR_FILL_LINES * 16;
+  // copy jobs as a lone caller's: 64 KiB (32 steps of the kernel), 256 KiB where the query is long
+  constexpr size_t kJobSmall = (size_t)1 << 14, kJobBig = (size_t)1 << 16;
+  const size_t kJob = (words + kJobSmall - 1) / kJobSmall <= 512 ? kJobSmall : kJobBig;
+  const size_t n_jobs = pageable ? (words + kJob - 1) / kJob : 0;
+  size_t next_job = 0;
+  auto copy_a_job = [&] {
+    const size_t o = next_job * kJob, n = (words - o < kJob) ? words - o : kJob;
+    memcpy(a->q_pinned + seat * stride + q_lo + o, q + q_lo + o, n * 4);
+    next_job++;
+    publish_fill_progress(my_lines, next_job == n_jobs ? 0xffffffffu : (uint32_t)(next_job * (kJob / CPIR_PLANAR_SLOTS_PER_TILE)));
+  };
+  std::unique_lock<std::mutex> lk(srv->mu, std::defer_lock);
+  int status = CPIR_OK;
+  if (!leader) {
+    while (next_job < n_jobs) copy_a_job();
+    lk.lock();
+    a->staged++;
+    srv->cv.notify_all();
+    lk.unlock();
+    // the pass is a couple of hundred microseconds away and a sleeping thread takes tens of them to wake: look for its end for a while
+    const double t0 = now_seconds();
+    while (__atomic_load_n(&a->rounds_done, __ATOMIC_ACQUIRE) == round_at_entry && now_seconds() - t0 < 2e-3) {
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+    lk.lock();
+    srv->cv.wait(lk, [&] { return a->state == RespondArena::DONE; });
+  } else {
+    // The leader closes the round when the device is free of the launch before AND the callers recently seen beside it have joined, or a
+    // moment has passed (they were answered by the same pass and come back within tens of microseconds of each other; a second query costs
+    // the pass a tenth of its time, a second pass all of it) -- and copies its own query meanwhile, job by job.
+    const double window = 60e-6;
+    double t_ready = -1;
+    uint32_t k = 0;
+    for (bool closed = false; !closed;) {
+      if (next_job < n_jobs) copy_a_job();
+      lk.lock();
+      bool device_free = true;
+      for (const RespondArena& x : srv->arena)
+        if (x.state == RespondArena::LAUNCHED) device_free = false;
+      if (device_free) {
+        const double now = now_seconds();
+        if (t_ready < 0) t_ready = now;
+        const uint32_t expected = srv->peak_inside < inplace_cap ? srv->peak_inside : inplace_cap;
+        if (a->joined >= expected || now - t_ready >= window) {
+          closed = true, k = a->joined;
+          a->state = RespondArena::LAUNCHED;  // closed: later callers open the next arena
+          srv->cv.notify_all();
+        } else if (next_job >= n_jobs) {
+          srv->cv.wait_for(lk, std::chrono::duration<double>(window - (now - t_ready)));
+        }
+      } else if (next_job >= n_jobs) {
+        srv->cv.wait(lk);  // nothing left to copy: until the launch before is done
+      }
+      lk.unlock();
+    }
+    srv->served.in_place_rounds.fetch_add(1, std::memory_order_relaxed);
+    srv->served.in_place_calls.fetch_add(k, std::memory_order_relaxed);
+    bool polled = false;
+    for (uint32_t i = 0; i < k; i++) polled = polled || a->seat_polled[i];
+    uint32_t fill_timeout_us = respond_host_fill_timeout_us();
+    if (fill_timeout_us >= 100 && words * 4 / 5000 > fill_timeout_us) fill_timeout_us = (uint32_t)(words * 4 / 5000);  // (as for a lone caller)
+    hipStream_t st = srv->run_stream;
+    hipError_t e = hipSuccess;
+    int rc = CPIR_OK;
+    for (int attempt = 0; attempt < 2; attempt++) {
+      uint32_t seq = 0;
+      {
+        std::lock_guard<std::mutex> ll(srv->dev->launch_mu);
+        a->r0_zero = false;
+        // (the word behind the k responses is the abort flag of a polled pass; whatever an uploaded round left there goes first)
+        if (polled) e = hipMemsetAsync(a->r_dev + (size_t)k * C, 0, 4, st);
+        const PlanarHostFill fill{a->fill_progress_dev, a->r_dev + (size_t)k * C, fill_timeout_us, k};
+        if (e == hipSuccess)
+          rc = launch_respond_read_rows_in_place(srv->dev, srv->dtc, srv->phys, a->seat_q, k, srv->total_slots, srv->slot_offset, a->r_dev, st,
+                                                 polled ? &fill : nullptr);
+        if (e == hipSuccess && rc == CPIR_OK) {
+          // the responses (and the flag word) are handed over by the one-block kernel that also leaves them zeroed on the device
+          seq = ++a->hand_seq ? a->hand_seq : ++a->hand_seq;  // never 0
+          uint32_t* const r_host_dev = const_cast<uint32_t*>(a->q_pinned_dev) + (a->r_pinned - a->q_pinned);
+          hipLaunchKernelGGL(respond_hand_over_kernel, dim3(1), dim3(256), 0, st, a->r_dev, (uint32_t)(k * C + 1), r_host_dev, a->handed_dev, seq);
+          e = hipGetLastError();
+          if (e == hipSuccess) a->r0_zero = true;
+        }
+      }
+      if (attempt == 0) {  // the leader's own query, under the pass that is already waiting for it
+        while (next_job < n_jobs) copy_a_job();
+        lk.lock();
+        a->staged++;
+        lk.unlock();
+      }
+      if (e == hipSuccess && rc == CPIR_OK) {
+        const double t0 = now_seconds();
+        bool got = false;
+        while (!(got = __atomic_load_n(a->handed, __ATOMIC_ACQUIRE) == seq)) {
+          if (now_seconds() - t0 > 5e-3) break;  // something is very slow or wrong: wait on the stream
+#if defined(__x86_64__)
+          __builtin_ia32_pause();
+#endif
+        }
+        if (!got) {
+          e = hipStreamSynchronize(st);
+          if (e == hipSuccess && __atomic_load_n(a->handed, __ATOMIC_ACQUIRE) != seq) e = hipErrorUnknown;
+        }
+      } else {
+        (void)hipStreamSynchronize(st);  // whatever was enqueued reads the callers' buffers / the pinned block: drain before anybody returns
+      }
+      if (!(polled && e == hipSuccess && rc == CPIR_OK && a->r_pinned[(size_t)k * C] != 0)) break;
+      // a wave gave up waiting for a copy: the pass is void.  Answer again, without polling, once every seat's copy is complete.
+      polled = false;
+      journal_note("respond: polled round VOID", a->q_pinned, words * 4, __FILE__, __LINE__);
+      srv->served.polled_void.fetch_add(1, std::memory_order_relaxed);
+      srv->fill_aborts.fetch_add(1, std::memory_order_relaxed);
+      lk.lock();
+      srv->cv.wait(lk, [&] { return a->staged == k; });
+      lk.unlock();
+    }
+    if (polled) {  // (a pass that kept up pays back one that did not, as for a lone caller)
+      uint32_t n = srv->fill_aborts.load(std::memory_order_relaxed);
+      while (n > 0 && n < 3 && !srv->fill_aborts.compare_exchange_weak(n, n - 1, std::memory_order_relaxed)) {
+      }
+    }
+    status = rc;
+    if (rc == CPIR_OK && e != hipSuccess) {
+      set_last_hip_error(e, "respond (round read in place)", __FILE__, __LINE__);
+      status = CPIR_ERR_HIP;
+    }
+    lk.lock();
+    // (a caller whose copy is still running -- a void pass that was not answered again because of an error -- must not find its block reused)
+    srv->cv.wait(lk, [&] { return a->staged == k; });
+    a->status = status;
+    a->state = RespondArena::DONE;
+    __atomic_fetch_add(&a->rounds_done, 1u, __ATOMIC_RELEASE);
+    srv->cv.notify_all();
+  }
+  status = a->status;
+  lk.unlock();
+  if (status == CPIR_OK) memcpy(r_out, a->r_pinned + seat * C, C * 4);
+  lk.lock();
+  srv->inside--;
+  if (++a->left == a->joined) {  // last one out frees the arena
+    a->state = RespondArena::FREE;
+    a->joined = a->staged = a->left = 0;
+    srv->cv.notify_all();
+  }
+  return status;
+}
+
 int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_rows, uint64_t q_cols, uint32_t* r_out) {
   if (!csrv || !q || !r_out) return CPIR_ERR_INVALID_ARGUMENT;
   Server* srv = const_cast<cpir_server*>(csrv);  // the pool is the only mutable state; it is internally locked
@@ -1008,13 +1173,17 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
     const uint32_t* const p = static_cast<const uint32_t*>(q_dev_visible) - q_lo;
     if (reinterpret_cast<uintptr_t>(p) % 16 == 0) q0_in_place = p;
   }
+  // ... or pageable and long enough for a pass to poll its copy (as a lone caller's: 2^19 words, respond.host_fill_timeout_us > 0, fewer than
+  // three passes in a row that gave up; the shard's slots start on a 128-byte line of the query)
+  const bool stage_in_place = !q0_in_place && inplace_cap >= 2 && read_once_ok && !srv->map.active() && q_hi - q_lo >= ((size_t)1 << 19) &&
+                              (q_lo * 4) % 128 == 0 && respond_host_fill_timeout_us() > 0 && srv->fill_aborts.load(std::memory_order_relaxed) < 3;
   std::unique_lock<std::mutex> lk(srv->mu);
   RespondArena* a = nullptr;
   bool solo = false;
   // ... and only while the callers recently seen inside at the same time are few enough for one such pass: more of them are link-bound
   // either way, and the upload path overlaps their copies with the kernel of the arena before
   const uint32_t company = srv->inside + 1 > srv->peak_inside ? srv->inside + 1 : srv->peak_inside;
-  const bool want_in_place = q0_in_place && company >= 2 && company <= inplace_cap;
+  const bool want_in_place = (q0_in_place || stage_in_place) && company >= 2 && company <= inplace_cap;
   for (;;) {
     if (want_in_place) {
       for (RespondArena& x : srv->arena)  // 1. an open in-place arena with a seat left
@@ -1055,9 +1224,19 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
   const bool compact = a->compact_seats;
   const bool in_place_round = a->in_place;
   const uint32_t round_at_entry = __atomic_load_n(&a->rounds_done, __ATOMIC_RELAXED);
-  if (in_place_round) a->seat_q[seat] = q0_in_place;
+  if (in_place_round) {
+    // (under the lock, before the round can be closed and launched: where the pass finds this seat's query, and how much of it is in place)
+    const size_t stride = ((size_t)srv->total_slots + 31) / 32 * 32;
+    a->seat_q[seat] = q0_in_place ? q0_in_place : a->q_pinned_dev + seat * stride;
+    a->seat_polled[seat] = q0_in_place == nullptr;
+    publish_fill_progress(a->fill_progress + (size_t)seat * CPIR_FILL_LINES * 16, q0_in_place ? 0xffffffffu : 0u);
+  }
   srv->caller_enters();
   lk.unlock();
+  if (in_place_round) {
+    srv->served.calls.fetch_add(1, std::memory_order_relaxed);
+    return respond_in_round(srv, a, seat, q, q0_in_place, inplace_cap, round_at_entry, r_out);
+  }
   const double t_seated = tr ? now_seconds() : 0;
   srv->served.calls.fetch_add(1, std::memory_order_relaxed);
   if (solo) {
@@ -1087,9 +1266,7 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
     ups = t ? srv->dev->up_more[t - 1] : srv->up_stream;
   };
   uint32_t* const qd = a->q_dev + seat * N;
-  if (in_place_round) {
-    // nothing to stage, nothing to upload: the pass reads the caller's buffer
-  } else if (compact) {
+  if (compact) {
     // A server that holds only the slots with a non-zero row: the query is COMPACTED onto them while it is staged (host_gather.cpp: one
     // sequential pass over the source through the bitmap of the kept slots, about the cost of the memcpy it replaces), so the link carries
     // n_kept of the N words -- 8/9 for a real encoded database -- and the launch needs no map.  In source pieces of 1 MiB where nobody
@@ -1234,9 +1411,7 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
         if (x.state == RespondArena::LAUNCHED) return false;
       return true;
     };
-    // An in-place round always waits that moment for the callers recently seen beside this one (they were answered by the same pass and
-    // come back within tens of microseconds of each other): a second query costs the pass a tenth of its time, a second pass all of it.
-    const double window = in_place_round ? 60e-6 : srv->batching_window_seconds();
+    const double window = srv->batching_window_seconds();
     double t_ready = -1;  // when the gate was first found open (the moment counts from there, not from when this caller arrived:
                           // the callers of the pass that has just finished are the company to wait for)
     for (;;) {
@@ -1246,8 +1421,7 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
       }
       const double now = now_seconds();
       if (t_ready < 0) t_ready = now;
-      const uint32_t expected = in_place_round ? (srv->peak_inside < inplace_cap ? srv->peak_inside : inplace_cap) : srv->spread();
-      if (a->joined >= expected || now - t_ready >= window) break;
+      if (a->joined >= srv->spread() || now - t_ready >= window) break;
       srv->cv.wait_for(lk, std::chrono::duration<double>(window - (now - t_ready)));
     }
     a->state = RespondArena::LAUNCHED;  // closed: later callers open the next arena
@@ -1255,42 +1429,11 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
     const uint32_t k = a->joined;
     int st = a->status;
     lk.unlock();
-    (in_place_round ? srv->served.in_place_rounds : srv->served.uploaded_rounds).fetch_add(1, std::memory_order_relaxed);
-    (in_place_round ? srv->served.in_place_calls : srv->served.in_uploaded_rounds).fetch_add(k, std::memory_order_relaxed);
+    srv->served.uploaded_rounds.fetch_add(1, std::memory_order_relaxed);
+    srv->served.in_uploaded_rounds.fetch_add(k, std::memory_order_relaxed);
     const double t_gate = tr ? now_seconds() : 0;
     hipError_t e = hipSuccess;
-    bool handed_over = false;
-    if (st == CPIR_OK && in_place_round) {
-      // ONE pass reads the k queries where they lie; the responses (and the word behind them, see respond_alone) are handed over by the
-      // one-block kernel that also leaves them zeroed on the device
-      uint32_t seq = 0;
-      {
-        std::lock_guard<std::mutex> ll(srv->dev->launch_mu);
-        a->r0_zero = false;
-        st = launch_respond_read_rows_in_place(srv->dev, srv->dtc, srv->phys, a->seat_q, k, srv->total_slots, srv->slot_offset, a->r_dev, srv->run_stream);
-        if (st == CPIR_OK) {
-          seq = ++a->hand_seq ? a->hand_seq : ++a->hand_seq;  // never 0
-          uint32_t* const r_host_dev = const_cast<uint32_t*>(a->q_pinned_dev) + (a->r_pinned - a->q_pinned);
-          hipLaunchKernelGGL(respond_hand_over_kernel, dim3(1), dim3(256), 0, srv->run_stream, a->r_dev, (uint32_t)(k * C + 1), r_host_dev, a->handed_dev, seq);
-          e = hipGetLastError();
-          if (e == hipSuccess) a->r0_zero = true;
-        }
-      }
-      if (st == CPIR_OK && e == hipSuccess) {
-        const double t0 = now_seconds();
-        while (!(handed_over = __atomic_load_n(a->handed, __ATOMIC_ACQUIRE) == seq)) {
-          if (now_seconds() - t0 > 5e-3) break;  // something is very slow or wrong: wait on the stream
-#if defined(__x86_64__)
-          __builtin_ia32_pause();
-#endif
-        }
-        if (!handed_over) {
-          e = hipStreamSynchronize(srv->run_stream);
-          if (e == hipSuccess && __atomic_load_n(a->handed, __ATOMIC_ACQUIRE) != seq) e = hipErrorUnknown;
-          handed_over = e == hipSuccess;
-        }
-      }
-    } else if (st == CPIR_OK) {
+    if (st == CPIR_OK) {
       std::lock_guard<std::mutex> ll(srv->dev->launch_mu);  // the launch sequences of two arenas must not interleave on the run stream
       for (uint32_t i = 0; i < k && e == hipSuccess; i++) e = hipStreamWaitEvent(srv->run_stream, a->seat_ev[i], 0);
       a->r0_zero = false;
@@ -1303,9 +1446,7 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
     const double t_enq = tr ? now_seconds() : 0;
     // always wait for what was enqueued for this arena before it can be reused: the uploads (they may have failed half way) and the launch
     hipError_t e2 = hipSuccess;
-    if (handed_over) {
-      // (the responses are in r_pinned, the stream has nothing of this round left)
-    } else if (st == CPIR_OK && e == hipSuccess) {
+    if (st == CPIR_OK && e == hipSuccess) {
       e2 = wait_for_event(a->done_ev);
     } else {
       sync_upload_streams(srv->dev);
@@ -1325,20 +1466,8 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
     lk.lock();
     a->status = st;
     a->state = RespondArena::DONE;
-    __atomic_fetch_add(&a->rounds_done, 1u, __ATOMIC_RELEASE);
     srv->cv.notify_all();
   } else {
-    if (in_place_round) {
-      // the pass is a couple of hundred microseconds away and a sleeping thread takes tens of them to wake: look for its end for a while
-      lk.unlock();
-      const double t0 = now_seconds();
-      while (__atomic_load_n(&a->rounds_done, __ATOMIC_ACQUIRE) == round_at_entry && now_seconds() - t0 < 2e-3) {
-#if defined(__x86_64__)
-        __builtin_ia32_pause();
-#endif
-      }
-      lk.lock();
-    }
     srv->cv.wait(lk, [&] { return a->state == RespondArena::DONE; });
     if (tr) srv->trace.ns_follow += (uint64_t)((now_seconds() - t_staged) * 1e9);
   }

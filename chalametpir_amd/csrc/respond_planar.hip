@@ -73,6 +73,7 @@ struct PlanarArgs {
   // step-major kernel, q read in place from host memory that is still being FILLED while the kernel runs (a lone pageable host query):
   uint32_t strided;          // blocks take whole steps round-robin (step s -> block s % blocks), so the grid consumes q front to back
   const uint32_t* progress;  // host memory: number of 512-slot steps of q in place so far, CPIR_FILL_LINES copies 64 bytes apart (NULL: all of q is in place)
+  uint32_t progress_seats;   // ... one such set of copies per query of the pass, one behind the other (1: a lone query)
   uint32_t* abort_flag;      // device memory: set when a wave has given up waiting (the launch's results are then void)
   uint64_t poll_ticks;       // ... after this many ticks of the 100 MHz wall clock
   const uint32_t* keep;      // wide pass: the database holds only the slots keep[0 .. num_slots) of the query (increasing, relative to q_slot_offset;
@@ -190,13 +191,23 @@ respond_planar_ks_kernel(const PlanarArgs a) {
   bool gave_up = false;
   uint32_t seen = 0;
   const uint32_t* const my_progress = a.progress ? a.progress + (blockIdx.x % CPIR_FILL_LINES) * 16 : nullptr;
+  // (the queries of a round of concurrent callers are copied in by their callers' threads, each at its own pace, each counted in a set of
+  // copies of its own: a step is in place when it is in place for every one of them)
+  auto in_place_so_far = [&]() __attribute__((always_inline)) {
+    uint32_t m = __hip_atomic_load(my_progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (uint32_t s = 1; s < a.progress_seats; s++) {
+      const uint32_t x = __hip_atomic_load(my_progress + s * (CPIR_FILL_LINES * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      m = x < m ? x : m;
+    }
+    return m;
+  };
   auto wait_for_step = [&](uint32_t ks_) __attribute__((always_inline)) {
     if (!my_progress || gave_up || seen > ks_) return;
     const uint64_t t0 = wall_clock64();
     // RELAXED system-scope loads (they bypass the caches by themselves): an acquire would invalidate the L2 under the whole grid's feet
     // at every poll.  Nothing needs it: the words waited for are fetched only after the loop has seen the count (control dependency),
     // from host memory that this kernel has not touched before, and the host publishes the count with a release store after the copy.
-    while ((seen = __hip_atomic_load(my_progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) <= ks_) {
+    while ((seen = in_place_so_far()) <= ks_) {
       if (wall_clock64() - t0 > a.poll_ticks) {
         gave_up = true;
         if (lane == 0) atomicOr(a.abort_flag, 1u);
@@ -388,7 +399,7 @@ respond_planar_ks_kernel(const PlanarArgs a) {
     const bool want_next = first_of_visit && more_visits;
     const bool ask = want_next && my_progress && !gave_up && seen <= nks;
     uint32_t early = 0;
-    if (ask) early = __hip_atomic_load(my_progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (ask) early = in_place_so_far();
     if (want_next && !my_progress && !g_n) a_issue(raw, nks, npass);
     // ALWAYS issued (the very last unit asks for its own tile again: 9 KiB per block and launch): with a conditional prefetch the compiler
     // cannot count the loads in flight and waits for all of them, this tile's successor included, before the first MFMA
@@ -1049,6 +1060,8 @@ int launch_respond_planar_ks(const Device* dev, const uint32_t* dtc, const cpir_
   // every word crosses the link exactly once
   a.strided = in_place ? 1u : 0u;
   a.progress = fill ? fill->progress : nullptr;
+  a.progress_seats = fill ? fill->seats : 1u;
+  if (fill && (fill->seats == 0 || fill->seats > batch)) return CPIR_ERR_INVALID_ARGUMENT;
   a.abort_flag = fill ? fill->abort_flag : nullptr;
   a.poll_ticks = fill ? (uint64_t)fill->timeout_us * 100 : 0;
   a.keep = nullptr;
@@ -1156,6 +1169,7 @@ int launch_respond_planar_wide(const Device* dev, const uint32_t* dtc, const cpi
   a.q_far = 0;
   a.strided = 0;
   a.progress = nullptr;
+  a.progress_seats = 1;
   a.abort_flag = nullptr;
   a.poll_ticks = 0;
   a.q_scalar = (reinterpret_cast<uintptr_t>(q) % 16 != 0 || q_slot_offset % 4 != 0 || (batch * passes > 1 && q_len % 4 != 0)) ? 1u : 0u;

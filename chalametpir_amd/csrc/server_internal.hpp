@@ -52,12 +52,14 @@ struct RespondArena {
   // stages it, uploads 8/9 of the words into q_compact, and the launch needs no map -- or whole ones (DMA straight from page-locked caller
   // buffers, the kernel applies the map).  Decided by the caller that opens the arena, the same for all its seats; guarded by Server::mu.
   bool compact_seats = false;
-  // (a few concurrent callers whose queries lie in page-locked memory) the seats of this round are not uploaded at all: ONE pass of the
+  // (a few concurrent callers) the seats of this round are not uploaded at all: ONE pass of the
   // step-major kernel reads every seat's query IN PLACE over the host link, each from its caller's own buffer -- the upload (83 us per query
-  // at 2^20 keys x 1 kB, one after the other) disappears behind the stream of the database, as it does for a lone caller.  seat_q[i] is the
-  // device-visible address of word 0 of seat i's query.  Decided by the caller that opens the arena; guarded by Server::mu.
+  // at 2^20 keys x 1 kB, one after the other) disappears behind the stream of the database, as it does for a lone caller -- or, a pageable
+  // query, from the seat's part of the pinned block while its caller copies it in (respond_in_round).  seat_q[i] is the device-visible
+  // address of word 0 of seat i's query.  Decided by the caller that opens the arena; guarded by Server::mu.
   bool in_place = false;
   const uint32_t* seat_q[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool seat_polled[8] = {false, false, false, false, false, false, false, false};  // seat i's query is pageable: copied into the pinned block under the pass
   uint32_t rounds_done = 0;  // (atomic accesses) bumped when a round's responses are in r_pinned: what the followers of an in-place round spin on
   // guarded by Server::mu
   enum State { FREE, OPEN, LAUNCHED, DONE } state = FREE;

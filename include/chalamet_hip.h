@@ -262,14 +262,17 @@ int cpir_op_synth_fill(cpir_device* dev, uint32_t* out, uint64_t count, uint64_t
  *   does not pay for waking them -- before they go to sleep; default 300, 0: sleep at once),
  *   "respond.upload_streams" 1..4 (concurrent host callers: their query uploads take this many HIP streams in turn, so that one copy is
  *   set up while another crosses the link; default 2),
- *   "respond.inplace_seats" 0, 2..4 (a few concurrent host callers whose queries lie in page-locked memory are answered by ONE pass that
- *   reads every query in place over the host link, each from its caller's own buffer, instead of uploading them one after the other:
- *   up to this many callers per pass, and only while no more than that were recently seen inside at the same time; default 4, 0: off),
+ *   "respond.inplace_seats" 0, 2..4 (a few concurrent host callers are answered by ONE pass that reads every query in place over the host
+ *   link instead of uploading them one after the other -- a page-locked query from its caller's own buffer, a pageable one of 2^19+ words
+ *   from the server's pinned block while its caller's thread copies it in: up to this many callers per pass, and only while no more than
+ *   that were recently seen inside at the same time; default 4, 0: off),
  *   "respond.host_zero_copy" {0,1}
  *   (1, the default: cpir_server_respond serves a caller that finds the server idle without an upload, the kernel reading the
  *   query in place from page-locked host memory; 0: always stage + upload first), "respond.host_fill_timeout_us" 0..1000000
  *   (a lone PAGEABLE query of 2^19+ words: one launch in front of the copy into pinned memory, every wave waiting at most this long
- *   for the words of a step -- default 2000, raised to what copying the whole query takes at 5 GB/s; 0: two launches, each when its half of the query is in place), "matmul.mfma" {0,1} (1, the default:
+ *   for the words of a step -- default 2000, raised to what copying the whole query takes at 5 GB/s (values below 100 are taken as they
+ *   are: tests); 0: two launches, each when its half of the query is in place.  The pageable queries of an in-place round of concurrent
+ *   callers, respond.inplace_seats, are polled the same way, seat by seat; 0 sends them through the upload path), "matmul.mfma" {0,1} (1, the default:
  *   cpir_op_mat_x_mat and the setup paths run right-hand sides below 2^16 on the i8 matrix cores; 0: on the integer VALU),
  *   "matmul.pipeline" {0,1} (1, the default: the software-pipelined matrix-core kernel; 0: its first cut),
  *   "pack.rows" {-1,0,1} (the planar pack pass with at most one bit plane: 1 = a block streams whole rows of D, 0 = 64-column waves, -1 --
@@ -402,7 +405,7 @@ int cpir_server_setup_timings(const cpir_server* srv, double out[CPIR_SETUP_TIMI
  *   [0] calls answered   [1] ... alone, the query read in place over the host link (no upload)
  *   [2] ... alone, by one launch polling the copy of a pageable query   [3] such launches that gave up waiting (answered again)
  *   [4] calls answered in uploaded rounds (concurrent callers: staged, uploaded, one fused pass per round)   [5] uploaded rounds
- *   [6] calls answered in in-place rounds (a few concurrent callers with page-locked queries: one pass reads them where they lie)
+ *   [6] calls answered in in-place rounds (a few concurrent callers: one pass reads their queries over the link, respond.inplace_seats)
  *   [7] in-place rounds */
 #define CPIR_HOST_PATH_COUNT 8
 int cpir_server_host_path_counts(const cpir_server* srv, uint64_t out[CPIR_HOST_PATH_COUNT]);

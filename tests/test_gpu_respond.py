@@ -359,11 +359,14 @@ def test_lone_host_query_is_read_in_place(orc, device):
             pin.close()
 
 
-def test_a_few_concurrent_page_locked_callers_share_one_pass_that_reads_their_queries_in_place(orc, device, packing):
-    """respond.inplace_seats (default 4): two to four concurrent callers whose queries lie in page-locked memory are answered by ONE pass of
-    the step-major kernel that reads every query where it lies (a table of row addresses: each caller's own buffer) -- no upload.  Same
-    answers as the oracle for a whole server and for a shard that starts in the middle of the query, beside pageable callers and a caller
-    whose page-locked view is not 16-byte aligned (both take the upload path); with the key at 0 no such round is ever formed."""
+def test_a_few_concurrent_callers_share_one_pass_that_reads_their_queries_in_place(orc, device, packing):
+    """respond.inplace_seats (default 4): two to four concurrent callers are answered by ONE pass of the step-major kernel that reads every
+    query over the host link where it lies -- a page-locked query in its caller's buffer (a table of row addresses), a pageable one in the
+    server's pinned block WHILE its caller copies it in (every seat's progress polled) -- no upload.  Same answers as the oracle for a whole
+    server and for a shard that starts in the middle of the query, for page-locked, pageable and mixed rounds, beside a caller whose
+    page-locked view is not 16-byte aligned (copied like a pageable one); six callers are too many for such rounds (upload path); with the
+    key at 0 no such round is ever formed; with a 1 us limit on a query long enough for the pass to catch up with its copy the polled passes
+    give up, are answered again, and after three of them pageable callers go back to the upload path."""
     import torch
 
     import chalametpir_amd as cp
@@ -383,47 +386,83 @@ def test_a_few_concurrent_page_locked_callers_share_one_pass_that_reads_their_qu
         pa.array[:N] = q
     shifted = cp.PinnedArray(N + 4)
     shifted.array[1:N + 1] = qs[0]
+    planar = packing.startswith("planar")  # (the other packings have no kernel that reads a query exactly once)
+    # who asks: "p" a page-locked query, "g" a pageable one, "s" the page-locked view that is not 16-byte aligned
+    crews = ("pp", "ppp", "pppp", "gg", "pg", "ggg", "pgsg", "ppggps")
     try:
-        for seats in (4, 2, 0):
+        for seats, timeout_us in ((4, 2000), (2, 2000), (0, 2000)):
             cp.tuning_set("respond.inplace_seats", seats)
+            cp.tuning_set("respond.host_fill_timeout_us", timeout_us)
             whole = cp.Server.from_compressed(dtc, N, b, device=device)
             D_dev = torch.from_numpy(np.ascontiguousarray(D[lo:hi]).view(np.int32)).cuda()
             shard = cp.Server.from_device_matrix(D_dev, hi - lo, C, b, device=device, slot_offset=lo, total_slots=N)
             for srv, wanted in ((whole, want), (shard, want_shard)):
-                for callers in (2, 3, 4, 6):
+                calls = 0
+                for crew in crews:
                     bad = []
-                    start = threading.Barrier(callers)
+                    start = threading.Barrier(len(crew))
 
-                    def ask(t):
+                    def ask(t, kind):
                         start.wait()
-                        for i in range(12):
+                        for i in range(10):
                             k = (t + i) % n_q
-                            if t == 4:  # a pageable caller beside them
+                            if kind == "g":
                                 got = srv.respond_array(qs[k])
-                            elif t == 5:  # page-locked, but not 16-byte aligned
+                            elif kind == "s":
                                 got, k = srv.respond_array(shifted.array[1:N + 1]), 0
                             else:
                                 got = srv.respond_array(pins[k].array[:N])
                             if not np.array_equal(got, wanted[k]):
                                 bad.append((t, i, k))
 
-                    ts = [threading.Thread(target=ask, args=(t,)) for t in range(callers)]
+                    ts = [threading.Thread(target=ask, args=(t, kind)) for t, kind in enumerate(crew)]
                     for t in ts:
                         t.start()
                     for t in ts:
                         t.join()
-                    assert not bad, (seats, callers, bad[:4])
+                    assert not bad, (seats, timeout_us, crew, bad[:4])
+                    calls += 10 * len(crew)
                 counts = srv.host_path_counts()
-                assert counts["calls"] == 12 * (2 + 3 + 4 + 6), counts
+                assert counts["calls"] == calls, counts
                 assert counts["calls"] == counts["alone_in_place"] + counts["in_uploaded_rounds"] + counts["in_in_place_rounds"], counts
-                if seats == 0 or not packing.startswith("planar"):  # (the other packings have no kernel that reads a query once)
+                if seats == 0 or not planar:
                     assert counts["in_place_rounds"] == 0 and counts["in_in_place_rounds"] == 0, counts
                 else:
                     assert counts["in_place_rounds"] > 0 and counts["in_in_place_rounds"] <= seats * counts["in_place_rounds"], counts
+                    assert counts["polled_given_up"] == 0, counts
             whole.close()
             shard.close()
+        # a query long enough for the pass to catch up with its copy (16 MB: a millisecond of one thread's memcpy), and a 1 us limit
+        if planar:
+            N2, C2 = (1 << 22) + 1024, 4
+            D2 = random_db_matrix(rng, N2, C2, b)
+            dtc2 = orc.row_wise_compress(orc.transpose(D2), b)
+            q2 = [random_query(rng, N2) for _ in range(2)]
+            want2 = [orc.row_vector_x_compressed_transposed_matrix(q, dtc2, N2, b)[0] for q in q2]
+            cp.tuning_set("respond.inplace_seats", 4)
+            cp.tuning_set("respond.host_fill_timeout_us", 1)
+            srv = cp.Server.from_compressed(dtc2, N2, b, device=device)
+            bad = []
+            start = threading.Barrier(2)
+
+            def ask2(t):
+                start.wait()
+                for i in range(8):
+                    if not np.array_equal(srv.respond_array(q2[(t + i) % 2]), want2[(t + i) % 2]):
+                        bad.append((t, i))
+
+            ts = [threading.Thread(target=ask2, args=(t,)) for t in range(2)]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+            counts = srv.host_path_counts()
+            assert not bad, (bad, counts)
+            assert counts["in_place_rounds"] > 0 and counts["polled_given_up"] >= 1, counts  # (three in a row: no more polling)
+            srv.close()
     finally:
         cp.tuning_set("respond.inplace_seats", 4)
+        cp.tuning_set("respond.host_fill_timeout_us", 2000)
         for pa in pins:
             pa.close()
         shifted.close()
