@@ -996,10 +996,18 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
 static int respond_in_round(Server* srv, RespondArena* a, uint32_t seat, const uint32_t* q, const uint32_t* q0_in_place, uint32_t inplace_cap,
                             uint32_t round_at_entry, uint32_t* r_out) {
   const size_t C = srv->layout.num_cols;
-  const size_t q_lo = (size_t)srv->slot_offset, words = (size_t)srv->layout.num_slots;
+  // With a slot map (compact.hip) the pass reads COMPACT queries -- the words of the kept slots only, from word 0 of the seat's block,
+  // q_len = map.n_pad -- which the copy jobs produce (as respond_alone's do): every caller is then a copying one, page-locked or not.
+  const bool mapped = srv->map.active();
+  const size_t q_lo = (size_t)srv->slot_offset;
+  const size_t words = mapped ? (size_t)srv->map.n_kept : (size_t)srv->layout.num_slots;  // words of a query the pass reads
+  const uint64_t kq_len = mapped ? srv->map.n_pad : srv->total_slots, kq_off = mapped ? 0 : srv->slot_offset;  // as the kernel addresses them
   const bool leader = seat == 0, pageable = q0_in_place == nullptr;
   const size_t stride = ((size_t)srv->total_slots + 31) / 32 * 32;  // of the seats' blocks: each starts on a 128-byte line (see respond_alone)
   uint32_t* const my_lines = a->fill_progress + (size_t)seat * CPIR_FILL_LINES * 16;
+  uint32_t* const my_block = a->q_pinned + seat * stride + (mapped ? 0 : q_lo);
+  const uint32_t* const idx = mapped ? srv->map.keep_host.data() : nullptr;
+  const uint8_t* const bits = (mapped && compress_words_vectorised()) ? srv->map.keep_bits.data() : nullptr;
   // copy jobs as a lone caller's: 64 KiB (32 steps of the kernel), 256 KiB where the query is long
   constexpr size_t kJobSmall = (size_t)1 << 14, kJobBig = (size_t)1 << 16;
   const size_t kJob = (words + kJobSmall - 1) / kJobSmall <= 512 ? kJobSmall : kJobBig;
@@ -1007,7 +1015,8 @@ static int respond_in_round(Server* srv, RespondArena* a, uint32_t seat, const u
   size_t next_job = 0;
   auto copy_a_job = [&] {
     const size_t o = next_job * kJob, n = (words - o < kJob) ? words - o : kJob;
-    memcpy(a->q_pinned + seat * stride + q_lo + o, q + q_lo + o, n * 4);
+    StagingHelpers::copy(mapped ? StagingHelpers::Job{my_block + o, q + q_lo, n * 4, nullptr, idx + o, bits}
+                                : StagingHelpers::Job{my_block + o, q + q_lo + o, n * 4, nullptr, nullptr, nullptr});
     next_job++;
     publish_fill_progress(my_lines, next_job == n_jobs ? 0xffffffffu : (uint32_t)(next_job * (kJob / CPIR_PLANAR_SLOTS_PER_TILE)));
   };
@@ -1075,8 +1084,7 @@ static int respond_in_round(Server* srv, RespondArena* a, uint32_t seat, const u
         if (polled) e = hipMemsetAsync(a->r_dev + (size_t)k * C, 0, 4, st);
         const PlanarHostFill fill{a->fill_progress_dev, a->r_dev + (size_t)k * C, fill_timeout_us, k};
         if (e == hipSuccess)
-          rc = launch_respond_read_rows_in_place(srv->dev, srv->dtc, srv->phys, a->seat_q, k, srv->total_slots, srv->slot_offset, a->r_dev, st,
-                                                 polled ? &fill : nullptr);
+          rc = launch_respond_read_rows_in_place(srv->dev, srv->dtc, srv->phys, a->seat_q, k, kq_len, kq_off, a->r_dev, st, polled ? &fill : nullptr);
         if (e == hipSuccess && rc == CPIR_OK) {
           // the responses (and the flag word) are handed over by the one-block kernel that also leaves them zeroed on the device
           seq = ++a->hand_seq ? a->hand_seq : ++a->hand_seq;  // never 0
@@ -1166,17 +1174,21 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
   const void* const q_dev_visible = pinned_range_device_pointer(q + q_lo, (q_hi - q_lo) * 4);
   const bool caller_pinned = q_dev_visible != nullptr;
   // A query that a pass may read in place beside those of other callers (RespondArena::in_place): page-locked, 16-byte aligned, no slot map
-  // (a compacted query exists nowhere until it is staged)
   const uint32_t inplace_cap = respond_inplace_seats();
   const uint32_t* q0_in_place = nullptr;  // the device-visible address of q[0]
-  if (caller_pinned && inplace_cap >= 2 && read_once_ok && !srv->map.active()) {
+  const bool mapped_srv = srv->map.active();
+  if (caller_pinned && inplace_cap >= 2 && read_once_ok && !mapped_srv) {
     const uint32_t* const p = static_cast<const uint32_t*>(q_dev_visible) - q_lo;
     if (reinterpret_cast<uintptr_t>(p) % 16 == 0) q0_in_place = p;
   }
   // ... or pageable and long enough for a pass to poll its copy (as a lone caller's: 2^19 words, respond.host_fill_timeout_us > 0, fewer than
   // three passes in a row that gave up; the shard's slots start on a 128-byte line of the query)
-  const bool stage_in_place = !q0_in_place && inplace_cap >= 2 && read_once_ok && !srv->map.active() && q_hi - q_lo >= ((size_t)1 << 19) &&
-                              (q_lo * 4) % 128 == 0 && respond_host_fill_timeout_us() > 0 && srv->fill_aborts.load(std::memory_order_relaxed) < 3;
+  // (a server with a slot map reads compact queries, which exist nowhere until they are staged: a pageable query is compacted while it is
+  // copied, at the cost of the copy; a page-locked one stays on the upload path there -- DMA of the whole query, the kernel applies the
+  // map -- which is as fast for two such callers and faster for four: 9.0 against 7.0 k queries/s, profiles/r5_inplace_rounds_ab.txt)
+  const bool stage_in_place = !q0_in_place && !(mapped_srv && caller_pinned) && inplace_cap >= 2 && read_once_ok &&
+                              (mapped_srv ? (size_t)srv->map.n_kept : q_hi - q_lo) >= ((size_t)1 << 19) && (mapped_srv || (q_lo * 4) % 128 == 0) &&
+                              respond_host_fill_timeout_us() > 0 && srv->fill_aborts.load(std::memory_order_relaxed) < 3;
   std::unique_lock<std::mutex> lk(srv->mu);
   RespondArena* a = nullptr;
   bool solo = false;

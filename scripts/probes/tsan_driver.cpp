@@ -83,6 +83,26 @@ static void exercise(cpir_device* dev, const Shape& sh, int round) {
       });
     for (auto& t : ts) t.join();
   }
+  // a few callers at a time: in-place rounds (respond.inplace_seats) -- page-locked queries read where they lie, pageable ones copied into
+  // their seats by their callers' threads while the pass polls every seat's progress; mixed crews; started together
+  for (int crew = 2; crew <= 4; crew++) {
+    std::atomic<int> ready{0};
+    std::vector<std::thread> ts;
+    for (int t = 0; t < crew; t++)
+      ts.emplace_back([&, t] {
+        ready++;
+        while (ready.load() < crew) std::this_thread::yield();
+        for (int k = 0; k < 4; k++) ask(srv, (t + k) % kQ, crew == 3 ? (t & 1) != 0 : crew == 2);
+      });
+    for (auto& t : ts) t.join();
+  }
+  {
+    uint64_t counts[CPIR_HOST_PATH_COUNT];
+    CK(cpir_server_host_path_counts(srv, counts));
+    fprintf(stderr, "  N %llu round %d: calls %llu, alone %llu, in uploaded rounds %llu (%llu), in in-place rounds %llu (%llu), polled passes given up %llu\n",
+            (unsigned long long)sh.N, round, (unsigned long long)counts[0], (unsigned long long)counts[1], (unsigned long long)counts[4],
+            (unsigned long long)counts[5], (unsigned long long)counts[6], (unsigned long long)counts[7], (unsigned long long)counts[3]);
+  }
   cpir_server* clone = cpir_server_retain(srv);
   cpir_server_release(srv);
   ask(clone, 0, false);

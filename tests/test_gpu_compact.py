@@ -322,6 +322,38 @@ def test_host_queries_lone_and_concurrent(orc, device):
         [t.start() for t in ts]
         [t.join() for t in ts]
         assert not errors, errors[:3]
+        # two to four callers at a time: in-place rounds (respond.inplace_seats) -- with a map a pageable caller compacts its query into its
+        # seat of the pinned block while the pass polls the seats' progress; a page-locked one (caller 1 here) stays on the upload path
+        pins = [cp.PinnedArray(N) for _ in range(2)]
+        for pa, q in zip(pins, qs):
+            pa.array[:] = q
+        before = srv.host_path_counts()
+        for crew in (2, 3, 4):
+            start = threading.Barrier(crew)
+
+            def few(k):
+                start.wait()
+                try:
+                    for i in range(10):
+                        j = (k + i) % len(qs)
+                        got = srv.respond_array(pins[j].array if (k == 1 and j < 2) else qs[j])
+                        if not np.array_equal(got, wants[j]):
+                            errors.append((crew, k, i))
+                except Exception as exc:  # noqa: BLE001
+                    errors.append(repr(exc))
+
+            ts = [threading.Thread(target=few, args=(k,)) for k in range(crew)]
+            [t.start() for t in ts]
+            [t.join() for t in ts]
+            assert not errors, errors[:3]
+        after = srv.host_path_counts()
+        assert after["calls"] - before["calls"] == 90 and after["polled_given_up"] == before["polled_given_up"], (before, after)
+        if srv.layout.packing == 2:  # planar
+            assert after["in_place_rounds"] > before["in_place_rounds"], (before, after)
+        else:
+            assert after["in_place_rounds"] == 0, after
+        for pa in pins:
+            pa.close()
         clone = srv.clone()
         assert np.array_equal(clone.respond_array(qs[0]), wants[0])
         clone.close()
