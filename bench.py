@@ -1081,7 +1081,9 @@ def host_path_timing(server, q_pool, N, torch, full=True):
         "note": "cpir_server_respond on host buffers.  A lone caller is served without an upload: the step-major kernel reads the query in "
                 "place over the host link (from the caller's page-locked buffer, or from the server's pinned block WHILE the caller's pageable query is "
                 "being copied into it: one launch in front of the copy, the kernel polling the copy's progress) + D2H. "
-                "Concurrent callers: pinned staging (skipped for page-locked queries; on a server with a slot map the query is compacted while it "
+                "Two to four concurrent callers (respond.inplace_seats): ONE pass reads their queries in place -- page-locked ones from the callers' "
+                "buffers, pageable ones from the pinned block while their callers copy them in (every seat's progress polled). More "
+                "concurrent callers: pinned staging (skipped for page-locked queries; on a server with a slot map the query is compacted while it "
                 "is staged) + H2D + batched respond + D2H, coalesced into arenas of up to 8 seats, uploads on two streams taken in turn, kernels "
                 "back to back on another; link_bound = h2d_GBps / query_bytes",
         "concurrent_callers_are": "PYTHON threads: each call holds the interpreter lock for 50-100 us around the library call, which caps this "
