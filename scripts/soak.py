@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak test (GPU box): for --seconds, random full-size queries through every respond path of the planar server -- device single,
-device batches (fused and unfused, both pass orders), host bytes (pageable and page-locked, 1..8 concurrent callers), a 5-shard
+device batches (fused and unfused, both pass orders), host bytes (pageable and page-locked; 1..8 and 20 concurrent callers, crews of 2-4), a 5-shard
 in-process group -- each compared with exact 64-bit sums computed by torch from the unpacked matrix.  Prints a count and exits 1 on
 the first mismatch."""
 import argparse
@@ -31,6 +31,9 @@ if args.holes > 0:
     D[torch.rand(N, device="cuda", generator=g) < args.holes] = 0
 srv = cp.Server.from_device_matrix(D, N, C, b, device=dev, stream=stream)
 print("slots served:", srv.slots_served(), flush=True)
+# (a handle of its own for the crews of two to four: a handle remembers the 20 callers of the burst for a hundred calls and would send the
+# crews through the upload path meanwhile)
+srv_few = cp.Server.from_device_matrix(D, N, C, b, device=dev, stream=stream)
 grp, _ = cp.Server.setup_from_matrix(bytes(32), D.cpu().numpy().view(np.uint32), b, devices=[dev] * 5)
 torch.cuda.synchronize()
 
@@ -119,11 +122,30 @@ while time.time() < t_end:
     ts = [threading.Thread(target=hammer, args=(t,)) for t in range(20)]
     [t.start() for t in ts]
     [t.join() for t in ts]
+    # crews of two to four callers, started together, four calls each: the in-place rounds (respond.inplace_seats) -- page-locked queries
+    # read where they lie, pageable ones copied in under a pass that polls every seat; all page-locked, all pageable, mixed
+    for crew in (2, 3, 4):
+        start = threading.Barrier(crew)
+
+        def few(t):
+            start.wait()
+            for rep in range(4):
+                i = (t + rep) % min(k, 4)
+                kind = (rounds + crew) % 3  # 0 page-locked, 1 pageable, 2 mixed
+                buf = pins[i].array if (kind == 0 or (kind == 2 and t % 2 == 0)) else hq[i]
+                if not np.array_equal(srv_few.respond_array(buf), want[i]):
+                    bad.append((crew, t, rep, i))
+
+        ts = [threading.Thread(target=few, args=(t,)) for t in range(crew)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
     for pa in pins:
         pa.close()
     if bad:
         print("MISMATCH concurrent", bad[:5], seed)
         sys.exit(1)
-    checks += 60
+    checks += 60 + 4 * (2 + 3 + 4)
     rounds += 1
 print(f"soak ok: {rounds} rounds, {checks} responses checked against exact 64-bit sums")
+print("how the host callers of the server were served:", srv.host_path_counts())
+print("... and the crews of two to four, on a handle of their own:", srv_few.host_path_counts())
