@@ -1174,7 +1174,13 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
   const void* const q_dev_visible = pinned_range_device_pointer(q + q_lo, (q_hi - q_lo) * 4);
   const bool caller_pinned = q_dev_visible != nullptr;
   // A query that a pass may read in place beside those of other callers (RespondArena::in_place): page-locked, 16-byte aligned, no slot map
-  const uint32_t inplace_cap = respond_inplace_seats();
+  // (as many callers per pass as the tuning allows and as the step-major kernel's LDS accumulators hold responses: 48 KiB, one u32 per query
+  // and padded column -- 8 kB values: one query, no such rounds)
+  uint32_t inplace_cap = respond_inplace_seats();
+  {
+    const uint64_t per_query = (uint64_t)(C + 63) / 64 * 256;
+    if (per_query * inplace_cap > (48u << 10)) inplace_cap = (uint32_t)((48u << 10) / per_query);
+  }
   const uint32_t* q0_in_place = nullptr;  // the device-visible address of q[0]
   const bool mapped_srv = srv->map.active();
   if (caller_pinned && inplace_cap >= 2 && read_once_ok && !mapped_srv) {

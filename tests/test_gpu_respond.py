@@ -641,6 +641,48 @@ def test_more_columns_than_one_query_fits_in_the_accumulators(orc, device):
     srv.close()
 
 
+def test_in_place_rounds_take_only_as_many_callers_as_the_accumulators_hold(orc, device, packing):
+    """an in-place round (respond.inplace_seats) is ONE pass of the step-major kernel, whose 48 KiB of LDS accumulators hold one u32 per
+    query and padded column: at 5 000 columns two queries fit (rounds of two, whatever the key allows), at 7 312 -- 8 kB values -- one:
+    no such rounds, four concurrent page-locked callers go through the upload path.  Same answers either way."""
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(7312)
+    b, N = 9, 5 * 512 + 100
+    for C, fits in ((5000, 2), (7312, 1)):
+        D = random_db_matrix(rng, N, C, b)
+        dtc = orc.row_wise_compress(orc.transpose(D), b)
+        srv = cp.Server.from_compressed(dtc, N, b, device=device)
+        qs = [random_query(rng, N) for _ in range(4)]
+        want = [orc.row_vector_x_compressed_transposed_matrix(q, dtc, N, b)[0] for q in qs]
+        pins = [cp.PinnedArray(N) for _ in range(4)]
+        for pa, q in zip(pins, qs):
+            pa.array[:] = q
+        bad = []
+        start = threading.Barrier(4)
+
+        def ask(t):
+            start.wait()
+            for i in range(10):
+                k = (t + i) % 4
+                if not np.array_equal(srv.respond_array(pins[k].array), want[k]):
+                    bad.append((t, i))
+
+        ts = [threading.Thread(target=ask, args=(t,)) for t in range(4)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        counts = srv.host_path_counts()
+        assert not bad, (C, bad[:4], counts)
+        assert counts["calls"] == 40 and counts["in_in_place_rounds"] <= fits * counts["in_place_rounds"], (C, counts)
+        if fits == 1 or not packing.startswith("planar"):
+            assert counts["in_place_rounds"] == 0, (C, counts)
+        for pa in pins:
+            pa.close()
+        srv.close()
+
+
 def test_environment_cannot_change_a_response(orc, device):
     """Server::respond has no mode in which it lies (server.rs:184-190).  Rounds 3-4 had measuring aids in the release library that the
     environment could switch on (CPIR_WIDE_ABLATE skipped parts of the wide kernel, CPIR_KS_TRACE made launches synchronous): they now
