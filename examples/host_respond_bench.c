@@ -138,7 +138,12 @@ int main(int argc, char** argv) {
     (void)run(T, 4, pinned);
     printf("{\"callers\": %d, \"pinned\": %d, \"queries_per_sec\": [", T, pinned);
     for (int r = 0; r < 3; r++) printf("%s%.0f", r ? ", " : "", run(T, 960 / T, pinned));
-    printf("], \"mismatches\": %d}\n", g_bad);
+    uint64_t served[CPIR_HOST_PATH_COUNT];
+    CHECK(cpir_server_host_path_counts(g_srv, served));
+    printf("], \"mismatches\": %d, \"served\": {\"calls\": %llu, \"alone\": %llu, \"in_uploaded_rounds\": %llu, \"uploaded_rounds\": %llu, "
+           "\"in_in_place_rounds\": %llu, \"in_place_rounds\": %llu, \"polled_given_up\": %llu}}\n",
+           g_bad, (unsigned long long)served[0], (unsigned long long)served[1], (unsigned long long)served[4], (unsigned long long)served[5],
+           (unsigned long long)served[6], (unsigned long long)served[7], (unsigned long long)served[3]);
     cpir_server_release(g_srv);
     cpir_device_close(dev);
     return g_bad ? 2 : 0;
