@@ -511,7 +511,7 @@ constexpr int kWMaxSets = 6;  // row sets of 4 queries
 // operand bytes per product, 16 accumulator registers per product instead of 4: what a 32-column image layout would make of the matrix
 // cores' and the LDS's share of a fused pass, measured without building that layout (scripts/wide_ablate.py, CPIR_WIDE_ABLATE bit 8).
 #ifdef CPIR_DIAG
-template <int HB, bool NT, bool MAP, bool EMU32 = false>
+template <int HB, bool NT, bool MAP, int DV = 0>  // DV (diagnosis variants, responses WRONG): 1 EMU32, 2 / 3 the same B / A operand for all k-blocks of a row set
 #else
 template <int HB, bool NT, bool MAP>  // (the release kernel has no such parameter: its name in a trace is respond_planar_wide_kernel<HB, NT, MAP>)
 #endif
@@ -519,6 +519,9 @@ __global__ void __launch_bounds__(kWThreads) __attribute__((amdgpu_waves_per_eu(
 respond_planar_wide_kernel(const PlanarArgs a) {
 #ifndef CPIR_DIAG
   constexpr bool EMU32 = false;
+  constexpr int DV = 0;
+#else
+  constexpr bool EMU32 = DV == 1;
 #endif
   constexpr int NL = 8 + HB;
   constexpr int ST16 = NL * 64;
@@ -830,8 +833,14 @@ respond_planar_wide_kernel(const PlanarArgs a) {
               hbv[kb][d] = (int)x;
             }
           }
-          acc_lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(as_v4i(f[kb]), as_v4i(cur[kb]), acc_lo, 0, 0, 0);
-          if constexpr (HB > 0) acc_hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(as_v4i(f[kb]), hbv[kb], acc_hi, 0, 0, 0);
+          // (diagnosis variants 2 / 3: the SAME B operands / A fragment for all eight k-blocks of a row set -- what the matrix cores draw when
+          // only one of their two operands changes from instruction to instruction; the indices fold at compile time)
+          const int kbB = DV == 2 ? 0 : kb, kbA = DV == 3 ? 0 : kb;
+          // (... and the operands that are not multiplied are still loaded and waited for: an empty statement that claims to read them)
+          if constexpr (DV == 2) asm volatile("" ::"v"(cur[kb].x), "v"(cur[kb].y), "v"(cur[kb].z), "v"(cur[kb].w));
+          if constexpr (DV == 3) asm volatile("" ::"v"(f[kb].x), "v"(f[kb].y), "v"(f[kb].z), "v"(f[kb].w));
+          acc_lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(as_v4i(f[kbA]), as_v4i(cur[kbB]), acc_lo, 0, 0, 0);
+          if constexpr (HB > 0) acc_hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(as_v4i(f[kbA]), hbv[kbB], acc_hi, 0, 0, 0);
           f[kb] = ap[kb * 64];
         }
         uint32_t val = 0;
@@ -1181,7 +1190,9 @@ int launch_respond_planar_wide(const Device* dev, const uint32_t* dtc, const cpi
   }();
   a.ablate = ablate_env;
   a.trace = nullptr;
-  if ((ablate_env & 8u) && hb == 1 && nt && !keep) fn = respond_planar_wide_kernel<1, true, false, true>;  // (the 32x32x32 emulation: see the kernel)
+  if ((ablate_env & 8u) && hb == 1 && nt && !keep) fn = respond_planar_wide_kernel<1, true, false, 1>;  // (the 32x32x32 emulation: see the kernel)
+  if ((ablate_env & 32u) && hb == 1 && nt && !keep) fn = respond_planar_wide_kernel<1, true, false, 2>;  // (the same B operands for a whole row set)
+  if ((ablate_env & 64u) && hb == 1 && nt && !keep) fn = respond_planar_wide_kernel<1, true, false, 3>;  // (the same A fragment for a whole row set)
 #endif
   a.q_row0 = a.q_row1 = a.q_row2 = a.q_row3 = nullptr;
   a.keep = keep;  // (device memory, at least L.num_slots entries, 16-byte aligned; the caller has checked that the slots it names lie inside q)

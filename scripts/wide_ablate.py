@@ -2,7 +2,9 @@
 """Diagnosis: the wide pass with parts switched off (CPIR_WIDE_ABLATE bit mask, results wrong): 1 no rebuild of the A fragments per step,
 2 no flush of the responses, 4 no MFMAs (the stream alone), 8 the row sets two at a time on v_mfma_i32_32x32x32_i8 (same byte products, half
 the fragment reads and operand bytes: what a 32-column image layout would do to the matrix cores' and the LDS's share), 16 all-zero A
-fragments (the same instructions, operands that toggle nothing: is the pass bound by the power the matrix cores draw?).  One process per setting (the mask is read once).
+fragments (the same instructions, operands that toggle nothing: is the pass bound by the power the matrix cores draw?), 32 / 64 the SAME B
+operands / A fragment for all eight k-blocks of a row set (everything still loaded and waited for: does it help when only one operand changes
+from instruction to instruction?).  One process per setting (the mask is read once).
    python scripts/wide_ablate.py            -> runs itself once per mask and prints microseconds per launch for batches of 16 and 24"""
 import os
 import subprocess
@@ -44,6 +46,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         out.append(f"batch {k}: {e0.elapsed_time(e1) * 1e3 / 20:7.1f} us")
     print(f"ablate {os.environ.get('CPIR_WIDE_ABLATE', '0'):>2}:  " + "   ".join(out), flush=True)
 else:
-    for mask in (0, 1, 2, 4, 3, 7, 8, 16, 0, 8, 16):  # (8: the 32x32x32 emulation -- same byte products, half the fragment reads)
+    for mask in (0, 1, 2, 4, 3, 7, 8, 16, 32, 64, 0, 8, 16, 32, 64):  # (8: the 32x32x32 emulation -- same byte products, half the fragment reads)
         env = dict(os.environ, CPIR_WIDE_ABLATE=str(mask))
         subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, check=False)
