@@ -364,19 +364,11 @@ static void group_ctx_destroy(Server* srv) {
       w->stop = true;
     }
     w->cv.notify_all();
-    if (w->th.joinable()) w->th.join();
+    for (std::thread& t : w->ths)
+      if (t.joinable()) t.join();
   }
   srv->workers.clear();
-  for (Server::GroupCtx& c : srv->gctx) {
-    for (size_t g = 0; g < c.lanes.size(); g++) {
-      Server::GroupLane& l = c.lanes[g];
-      DeviceGuard dg(srv->shards[g]->dev->ordinal);
-      if (l.stream) device_stream_release(srv->shards[g]->dev, l.stream);
-      if (l.q_dev) (void)CPIR_HIP_FREE(l.q_dev);  // q_dev and r_dev are one block
-      if (l.q_pinned) (void)CPIR_HIP_HOST_FREE(l.q_pinned);  // q_pinned and r_pinned are one block
-    }
-    c.lanes.clear();
-  }
+  for (Server::GroupCtx& c : srv->gctx) c.lanes.clear();
   srv->gctx_ready = false;
 }
 
@@ -415,29 +407,6 @@ void server_destroy(Server* srv) {
   delete srv;
 }
 
-// one shard's part of a group respond: stage its slots of the query, upload, answer, download, wait
-static int group_shard_respond(const Server* child, Server::GroupLane& l, const uint32_t* q, uint32_t C) {
-  const size_t n = (size_t)child->layout.num_slots;
-  hipError_t e;
-  if (pinned_range_device_pointer(q + child->slot_offset, n * 4) != nullptr) {  // this shard's slots lie in page-locked memory: DMA from there
-    e = hipMemcpyAsync(l.q_dev, q + child->slot_offset, n * 4, hipMemcpyHostToDevice, l.stream);
-  } else {
-    memcpy(l.q_pinned, q + child->slot_offset, n * 4);
-    e = hipMemcpyAsync(l.q_dev, l.q_pinned, n * 4, hipMemcpyHostToDevice, l.stream);
-  }
-  int status = CPIR_OK;
-  // a shard answered from ITS slice of the query is an unsharded respond on a database of its own slots
-  if (e == hipSuccess) status = server_respond_on_device(child, l.q_dev, n, 0, 1, true, l.r_dev, nullptr, l.q_compact, l.stream);
-  if (e == hipSuccess && status == CPIR_OK) e = hipMemcpyAsync(l.r_pinned, l.r_dev, (size_t)C * 4, hipMemcpyDeviceToHost, l.stream);
-  const hipError_t e2 = hipStreamSynchronize(l.stream);  // drain whatever was enqueued
-  if (e == hipSuccess) e = e2;
-  if (e != hipSuccess && status == CPIR_OK) {
-    set_last_hip_error(e, "group respond (shard)", __FILE__, __LINE__);
-    status = CPIR_ERR_HIP;
-  }
-  return status;
-}
-
 // (the worker is handed its own GroupWorker: srv->workers is still growing while the first threads start, and reading the vector from
 // here raced with its reallocation -- found by MALLOC_PERTURB_, which fills the freed storage)
 static void group_worker_main(Server* srv, Server::GroupWorker* worker, size_t g) {
@@ -445,7 +414,6 @@ static void group_worker_main(Server* srv, Server::GroupWorker* worker, size_t g
   const Server* child = srv->shards[g];
   (void)pthread_setname_np(pthread_self(), "cpir-group");
   (void)hipSetDevice(child->dev->ordinal);  // this thread only ever talks to its shard's device
-  const uint32_t C = srv->layout.num_cols;
   for (;;) {
     Server::GroupJob job;
     {
@@ -455,7 +423,8 @@ static void group_worker_main(Server* srv, Server::GroupWorker* worker, size_t g
       job = w.jobs.front();
       w.jobs.pop_front();
     }
-    const int st = group_shard_respond(child, job.ctx->lanes[g], job.q, C);
+    // (a shard answered from ITS slots of the query: an ordinary host call on a server whose slots start at slot_offset)
+    const int st = cpir_server_respond(static_cast<const cpir_server*>(child), job.q, 1, srv->total_slots, job.ctx->lanes[g].r.data());
     {
       std::lock_guard<std::mutex> lk(job.done->mu);
       if (st != CPIR_OK && job.done->status == CPIR_OK) job.done->status = st;
@@ -465,34 +434,17 @@ static void group_worker_main(Server* srv, Server::GroupWorker* worker, size_t g
   }
 }
 
-// per shard: a stream, a device block (query slice + response) and a pinned block of the same shape, for every call context
+// per call context and shard: room for the shard's partial response; per shard: its queue and the threads that serve it
 static int group_ctx_create(Server* srv) {
   const uint32_t C = srv->layout.num_cols;
   for (Server::GroupCtx& c : srv->gctx) {
     c.lanes.resize(srv->shards.size());
-    for (size_t g = 0; g < srv->shards.size(); g++) {
-      Server::GroupLane& l = c.lanes[g];
-      const Server* child = srv->shards[g];
-      DeviceGuard dg(child->dev->ordinal);
-      const size_t qw = ((size_t)child->layout.num_slots + 3) / 4 * 4, words = qw + (C + 3) / 4 * 4;
-      const size_t qcw = (size_t)child->map.n_pad;  // (slot map) the slice gathered onto the kept slots: behind the response, device block only
-#define TRY_(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_last_hip_error(_e, #e, __FILE__, __LINE__); group_ctx_destroy(srv); \
-    return _e == hipErrorOutOfMemory ? CPIR_ERR_OUT_OF_DEVICE_MEMORY : CPIR_ERR_HIP; } } while (0)
-      if (!(l.stream = device_stream_acquire(child->dev))) {
-        group_ctx_destroy(srv);
-        return CPIR_ERR_HIP;
-      }
-      TRY_(CPIR_HIP_MALLOC(&l.q_dev, (words + qcw) * 4));
-      TRY_(CPIR_HIP_HOST_MALLOC(&l.q_pinned, words * 4, hipHostMallocDefault));
-#undef TRY_
-      l.q_compact = qcw ? l.q_dev + words : nullptr;
-      l.r_dev = l.q_dev + qw;
-      l.r_pinned = l.q_pinned + qw;
-    }
+    for (Server::GroupLane& l : c.lanes) l.r.assign(C, 0u);
   }
   srv->workers.reserve(srv->shards.size());
   for (size_t g = 0; g < srv->shards.size(); g++) srv->workers.emplace_back(new Server::GroupWorker);
-  for (size_t g = 0; g < srv->shards.size(); g++) srv->workers[g]->th = std::thread(group_worker_main, srv, srv->workers[g].get(), g);
+  for (size_t g = 0; g < srv->shards.size(); g++)
+    for (int t = 0; t < Server::kGroupCtx; t++) srv->workers[g]->ths.emplace_back(group_worker_main, srv, srv->workers[g].get(), g);
   srv->gctx_ready = true;
   return CPIR_OK;
 }
@@ -541,9 +493,9 @@ static int group_respond(Server* srv, const uint32_t* q, uint32_t* r_out) {
     status = done.status;
   }
   if (status != CPIR_OK) return status;
-  memcpy(r_out, ctx->lanes[0].r_pinned, (size_t)C * 4);
+  memcpy(r_out, ctx->lanes[0].r.data(), (size_t)C * 4);
   for (size_t g = 1; g < srv->shards.size(); g++) {
-    const uint32_t* p = ctx->lanes[g].r_pinned;
+    const uint32_t* p = ctx->lanes[g].r.data();
     for (uint32_t c = 0; c < C; c++) r_out[c] += p[c];  // u32 wrap-around
   }
   return CPIR_OK;

@@ -148,9 +148,7 @@ struct Server {
   // responses are summed on the host (u32 wrap-around: order-independent, bit-identical to one device).
   std::vector<Server*> shards;
   struct GroupLane {  // per shard, per call context
-    hipStream_t stream = nullptr;
-    uint32_t *q_dev = nullptr, *r_dev = nullptr, *q_pinned = nullptr, *r_pinned = nullptr;
-    uint32_t* q_compact = nullptr;  // (shards with a slot map) the slice gathered onto the kept slots; part of the q_dev block
+    std::vector<uint32_t> r;  // the shard's C-word partial response
   };
   struct GroupCtx {
     bool busy = false;
@@ -175,8 +173,10 @@ struct Server {
   std::mutex gdev_mu;  // one enqueue sequence at a time
   GroupCtx gctx[kGroupCtx];
   bool gctx_ready = false;
-  // one persistent host thread per shard does that shard's staging, enqueues and wait, so the per-device host work of a
-  // query (a few tens of microseconds each) runs side by side instead of adding up over the devices
+  // Every shard is an ordinary server (its slots of the query start at slot_offset) and is asked through its own cpir_server_respond: its
+  // slots of the query are read in place over ITS device's host link, or copied in under a polled launch, and concurrent callers of the
+  // group meet again inside every shard, in its rounds and arenas.  kGroupCtx persistent host threads per shard make those calls, so the
+  // shards of one query work side by side and the queries of several callers reach a shard together.
   struct GroupDone {  // on the caller's stack
     std::mutex mu;
     std::condition_variable cv;
@@ -188,8 +188,8 @@ struct Server {
     GroupCtx* ctx = nullptr;
     GroupDone* done = nullptr;
   };
-  struct GroupWorker {
-    std::thread th;
+  struct GroupWorker {  // one queue per shard, served by kGroupCtx threads
+    std::vector<std::thread> ths;
     std::mutex mu;
     std::condition_variable cv;
     std::deque<GroupJob> jobs;
