@@ -187,6 +187,18 @@ def test_no_device_fails_loudly(native):
         cp.Server.setup_from_matrix(bytes(32), np.ones((4, 4), dtype=np.uint32), 9)
 
 
+def test_null_handles_are_refused_not_dereferenced(native):
+    """entry points that only look at a handle say CPIR_ERR_INVALID_ARGUMENT for a NULL one (no GPU needed to find that out)"""
+    import ctypes as C
+
+    out64 = (C.c_uint64 * 8)()
+    outd = (C.c_double * 8)()
+    assert native.cpir_server_host_path_counts(None, out64) == 68  # CPIR_ERR_INVALID_ARGUMENT
+    assert native.cpir_server_setup_timings(None, outd) == 68
+    q = (C.c_uint32 * 4)()
+    assert native.cpir_server_respond(None, q, 1, 4, q) == 68
+
+
 def test_product_never_imports_the_oracle():
     """the oracle is test infrastructure: nothing under chalametpir_amd/ may import, link or call it"""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
