@@ -336,10 +336,10 @@ int cpir_server_setup_kv(cpir_device* dev, uint32_t arity, const uint8_t seed_mu
  * The database is split along the filter slots over devs[0 .. n_dev) (fewer if it has fewer packing units than devices; a device
  * may be listed more than once); ONE host expansion of A feeds every device's column slab, every device packs its rows of D and
  * multiplies its slab by them, and the per-shard partial hints are summed on the host.  The handle behaves like any other in
- * cpir_server_respond / _respond_bytes / _export_compressed / _retain / _release: a host query is SCATTERED -- device g receives only
- * its slots of q over its own host link, answers its shard, and the C-word partial responses are summed on the host (u32
- * wrap-around, bit-identical to one device).  THE EXCHANGE OF THE HOST ENTRY POINTS IS A HOST SUM, not a collective: 3.7 kB per
- * shard and query, already in page-locked memory when the shards' downloads complete.
+ * cpir_server_respond / _respond_bytes / _export_compressed / _retain / _release: a host query is SCATTERED -- device g reads only
+ * its slots of q over its own host link (every shard is an ordinary server asked through cpir_server_respond: in place, in rounds with the
+ * other callers of the group), answers its shard, and the C-word partial responses are summed on the host (u32 wrap-around,
+ * bit-identical to one device).  THE EXCHANGE OF THE HOST ENTRY POINTS IS A HOST SUM, not a collective: 3.7 kB per shard and query.
  * The *_device entry points take a group handle too: q_dev and r_dev then live on the device of shard 0 (the root), every shard's own
  * stream pulls its slots of the queries over the peer link (xGMI between GPUs of one node; peer access is enabled where the hardware
  * offers it), answers them, and pushes its C-word partial responses into a table on the root, where a kernel on the caller's stream --
@@ -400,8 +400,8 @@ int cpir_server_export_compressed(const cpir_server* srv, uint32_t* compressed_o
 #define CPIR_SETUP_TIMING_COUNT 8
 int cpir_server_setup_timings(const cpir_server* srv, double out[CPIR_SETUP_TIMING_COUNT]);
 
-/* How the host callers of cpir_server_respond have been served by this handle so far (a group handle: summed over its shards' own
- * counts is NOT done -- a group scatters every query; all zero there):
+/* How the host callers of cpir_server_respond have been served by this handle so far (a group handle counts nothing itself: every
+ * query is answered by its shards, whose own counts cpir_server_group_shard does not expose; all zero there):
  *   [0] calls answered   [1] ... alone, the query read in place over the host link (no upload)
  *   [2] ... alone, by one launch polling the copy of a pageable query   [3] such launches that gave up waiting (answered again)
  *   [4] calls answered in uploaded rounds (concurrent callers: staged, uploaded, one fused pass per round)   [5] uploaded rounds
