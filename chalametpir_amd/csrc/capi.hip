@@ -403,11 +403,17 @@ int cpir_server_setup_timings(const cpir_server* srv, double out[CPIR_SETUP_TIMI
 
 int cpir_server_host_path_counts(const cpir_server* srv, uint64_t out[CPIR_HOST_PATH_COUNT]) {
   if (!srv || !out) return CPIR_ERR_INVALID_ARGUMENT;
-  const Server::Served& s = srv->served;
-  out[0] = s.calls.load(std::memory_order_relaxed), out[1] = s.alone.load(std::memory_order_relaxed);
-  out[2] = srv->fill_polled.load(std::memory_order_relaxed), out[3] = s.polled_void.load(std::memory_order_relaxed);
-  out[4] = s.in_uploaded_rounds.load(std::memory_order_relaxed), out[5] = s.uploaded_rounds.load(std::memory_order_relaxed);
-  out[6] = s.in_place_calls.load(std::memory_order_relaxed), out[7] = s.in_place_rounds.load(std::memory_order_relaxed);
+  for (int i = 0; i < CPIR_HOST_PATH_COUNT; i++) out[i] = 0;
+  auto add = [&](const Server* one) {
+    const Server::Served& s = one->served;
+    out[0] += s.calls.load(std::memory_order_relaxed), out[1] += s.alone.load(std::memory_order_relaxed);
+    out[2] += one->fill_polled.load(std::memory_order_relaxed), out[3] += s.polled_void.load(std::memory_order_relaxed);
+    out[4] += s.in_uploaded_rounds.load(std::memory_order_relaxed), out[5] += s.uploaded_rounds.load(std::memory_order_relaxed);
+    out[6] += s.in_place_calls.load(std::memory_order_relaxed), out[7] += s.in_place_rounds.load(std::memory_order_relaxed);
+  };
+  if (srv->shards.empty()) add(srv);
+  else
+    for (const Server* c : srv->shards) add(c);  // (a group: every query is answered by every shard, and counted there)
   return CPIR_OK;
 }
 

@@ -400,8 +400,8 @@ int cpir_server_export_compressed(const cpir_server* srv, uint32_t* compressed_o
 #define CPIR_SETUP_TIMING_COUNT 8
 int cpir_server_setup_timings(const cpir_server* srv, double out[CPIR_SETUP_TIMING_COUNT]);
 
-/* How the host callers of cpir_server_respond have been served by this handle so far (a group handle counts nothing itself: every
- * query is answered by its shards, whose own counts cpir_server_group_shard does not expose; all zero there):
+/* How the host callers of cpir_server_respond have been served by this handle so far (a group handle: summed over its shards, each of
+ * which answers -- and counts -- every query):
  *   [0] calls answered   [1] ... alone, the query read in place over the host link (no upload)
  *   [2] ... alone, by one launch polling the copy of a pageable query   [3] such launches that gave up waiting (answered again)
  *   [4] calls answered in uploaded rounds (concurrent callers: staged, uploaded, one fused pass per round)   [5] uploaded rounds
