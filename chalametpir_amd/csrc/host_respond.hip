@@ -871,8 +871,23 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
         srv->trace.ns_p_submit += (uint64_t)((tp1 - tp0) * 1e9), srv->trace.ns_p_launch += (uint64_t)((tp2 - tp0) * 1e9);
         srv->trace.ns_p_copied += (uint64_t)((tp3 - tp0) * 1e9);
       }
+    } else if (words >= 2 * kJobSmall && n_jobs <= kMaxJobs && fill_timeout_us > 0 && srv->fill_aborts.load(std::memory_order_relaxed) < 3 &&
+               (mapped || (q_lo * 4) % 128 == 0)) {
+      // A shorter query (the slice of a shard of a group, a small database), or the helpers are taken: this thread copies alone -- but
+      // still UNDER the launch, job by job, the kernel polling the copy's progress as above.
+      polled = true;
+      publish_fill_progress(a->fill_progress, 0u);
+      journal_note("respond: polled launch (one copier)", a->q_pinned, words * 4, __FILE__, __LINE__);
+      const PlanarHostFill fill{a->fill_progress_dev, a->r_dev + C, fill_timeout_us};
+      rc = launch_respond_read_once(srv->dev, srv->dtc, L, a->q_pinned_dev, kq_len, kq_off, a->r_dev, st, 0, 0, &fill);
+      if (rc != CPIR_OK) polled = false;  // nothing was launched
+      for (size_t i = 0; i < n_jobs; i++) {
+        StagingHelpers::copy(job(i, nullptr));
+        if (polled) publish_fill_progress(a->fill_progress, i + 1 == n_jobs ? 0xffffffffu : (uint32_t)((i + 1) * kStepsPerJob));
+      }
+      if (!polled) rc = launch_respond_read_once(srv->dev, srv->dtc, L, a->q_pinned_dev, kq_len, kq_off, a->r_dev, st);
     } else {
-      // (a short query, or the helpers are taken: this thread copies / compacts alone)
+      // (a very short query, or polling is off: this thread copies / compacts alone, then launches)
       StagingHelpers::copy(StagingHelpers::Job{qp, src, words * 4, nullptr, idx, mapped ? bits : nullptr});
       rc = launch_respond_read_once(srv->dev, srv->dtc, L, a->q_pinned_dev, kq_len, kq_off, a->r_dev, st);
     }
