@@ -1157,13 +1157,13 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
     const uint32_t* const p = static_cast<const uint32_t*>(q_dev_visible) - q_lo;
     if (reinterpret_cast<uintptr_t>(p) % 16 == 0) q0_in_place = p;
   }
-  // ... or pageable and long enough for a pass to poll its copy (as a lone caller's: 2^19 words, respond.host_fill_timeout_us > 0, fewer than
+  // ... or pageable and long enough for a pass to poll its copy (as a lone caller's: 2^15 words, respond.host_fill_timeout_us > 0, fewer than
   // three passes in a row that gave up; the shard's slots start on a 128-byte line of the query)
   // (a server with a slot map reads compact queries, which exist nowhere until they are staged: a pageable query is compacted while it is
   // copied, at the cost of the copy; a page-locked one stays on the upload path there -- DMA of the whole query, the kernel applies the
   // map -- which is as fast for two such callers and faster for four: 9.0 against 7.0 k queries/s, profiles/r5_inplace_rounds_ab.txt)
   const bool stage_in_place = !q0_in_place && !(mapped_srv && caller_pinned) && inplace_cap >= 2 && read_once_ok &&
-                              (mapped_srv ? (size_t)srv->map.n_kept : q_hi - q_lo) >= ((size_t)1 << 19) && (mapped_srv || (q_lo * 4) % 128 == 0) &&
+                              (mapped_srv ? (size_t)srv->map.n_kept : q_hi - q_lo) >= ((size_t)1 << 15) && (mapped_srv || (q_lo * 4) % 128 == 0) &&
                               respond_host_fill_timeout_us() > 0 && srv->fill_aborts.load(std::memory_order_relaxed) < 3;
   std::unique_lock<std::mutex> lk(srv->mu);
   RespondArena* a = nullptr;

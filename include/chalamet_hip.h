@@ -263,13 +263,13 @@ int cpir_op_synth_fill(cpir_device* dev, uint32_t* out, uint64_t count, uint64_t
  *   "respond.upload_streams" 1..4 (concurrent host callers: their query uploads take this many HIP streams in turn, so that one copy is
  *   set up while another crosses the link; default 2),
  *   "respond.inplace_seats" 0, 2..4 (a few concurrent host callers are answered by ONE pass that reads every query in place over the host
- *   link instead of uploading them one after the other -- a page-locked query from its caller's own buffer, a pageable one of 2^19+ words
+ *   link instead of uploading them one after the other -- a page-locked query from its caller's own buffer, a pageable one of 2^15+ words
  *   from the server's pinned block while its caller's thread copies it in: up to this many callers per pass, and only while no more than
  *   that were recently seen inside at the same time; default 4, 0: off),
  *   "respond.host_zero_copy" {0,1}
  *   (1, the default: cpir_server_respond serves a caller that finds the server idle without an upload, the kernel reading the
  *   query in place from page-locked host memory; 0: always stage + upload first), "respond.host_fill_timeout_us" 0..1000000
- *   (a lone PAGEABLE query of 2^19+ words: one launch in front of the copy into pinned memory, every wave waiting at most this long
+ *   (a lone PAGEABLE query of 2^15+ words: one launch in front of the copy into pinned memory, every wave waiting at most this long
  *   for the words of a step -- default 2000, raised to what copying the whole query takes at 5 GB/s (values below 100 are taken as they
  *   are: tests); 0: two launches, each when its half of the query is in place.  The pageable queries of an in-place round of concurrent
  *   callers, respond.inplace_seats, are polled the same way, seat by seat; 0 sends them through the upload path), "matmul.mfma" {0,1} (1, the default:
