@@ -146,9 +146,10 @@ int launch_respond_read_once(const Device* dev, const uint32_t* dtc, const cpir_
 // steps [step_lo, step_hi) of 512 slots only (0, 0 = all): a query may be answered by several launches, each over the steps whose
 // query words are in place by then; they add up in r
 // up to CPIR_PLANAR_KS_MAX_QUERIES_PER_PASS queries answered by ONE pass that reads each of them in place (q_rows: device-visible address of
-// word 0 of every query, every one q_len words long); r (batch x C) is zeroed by the call
+// word 0 of every query, every one q_len words long); r (batch x C) is zeroed by the call unless the caller says it is zero already
 int launch_respond_read_rows_in_place(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* const* q_rows, uint32_t batch,
-                                      uint64_t q_len, uint64_t q_slot_offset, uint32_t* r, hipStream_t stream, const PlanarHostFill* fill = nullptr);
+                                      uint64_t q_len, uint64_t q_slot_offset, uint32_t* r, hipStream_t stream, const PlanarHostFill* fill = nullptr,
+                                      bool r_prezeroed = false);
 uint32_t respond_inplace_seats();   // tuning "respond.inplace_seats" (0 = off, 2..4)
 uint32_t respond_upload_streams();  // tuning "respond.upload_streams" (1..4)
 uint32_t respond_helper_spin_us();  // tuning "respond.helper_spin_us"

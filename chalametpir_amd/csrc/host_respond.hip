@@ -328,7 +328,7 @@ static int arena_create(Server* srv, RespondArena& a) {
     __atomic_store_n(a.handed, 0u, __ATOMIC_RELAXED);
     a.hand_seq = 0;
   }
-  a.r0_zero = false;
+  a.r0_zero = false, a.r_zero_words = 0;
   a.seat_ev.assign(Server::kSeats, nullptr);
   for (hipEvent_t& ev : a.seat_ev)
     if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreateWithFlags");
@@ -770,7 +770,7 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
   int rc = CPIR_OK;
   // seat 0's response and the word behind it (the abort flag of a polled launch) are kept zeroed between uses
   if (!a->r0_zero) e = hipMemsetAsync(a->r_dev, 0, (C + 1) * 4, st);
-  a->r0_zero = false;
+  a->r0_zero = false, a->r_zero_words = 0;
   bool polled = false;
   // the slots this server reads, q[q_lo, q_lo + words), as the device addresses them -- if the whole range is page-locked; the kernel
   // is handed the (possibly virtual) address of q[0] and adds the offset itself
@@ -903,7 +903,7 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
       hipLaunchKernelGGL(respond_hand_over_kernel, dim3(1), dim3(256), 0, st, a->r_dev, (uint32_t)(C + 1), r_host_dev, a->handed_dev, seq);
       e = hipGetLastError();
       if (e == hipSuccess) {
-        a->r0_zero = true;
+        a->r0_zero = true, a->r_zero_words = (uint32_t)(C + 1);
         const double t0 = now_seconds();
         bool got = false;
         while (!(got = __atomic_load_n(a->handed, __ATOMIC_ACQUIRE) == seq)) {
@@ -922,7 +922,7 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
       if (e == hipSuccess) e = hipEventRecord(a->done_ev, st);
       if (e == hipSuccess) {
         // zeros for the next lone caller, off this one's critical path
-        if (hipMemsetAsync(a->r_dev, 0, (C + 1) * 4, st) == hipSuccess) a->r0_zero = true;
+        if (hipMemsetAsync(a->r_dev, 0, (C + 1) * 4, st) == hipSuccess) a->r0_zero = true, a->r_zero_words = (uint32_t)(C + 1);
         else (void)hipGetLastError();
         e = wait_for_event(a->done_ev);
       }
@@ -935,7 +935,7 @@ static int respond_alone(Server* srv, RespondArena* a, const uint32_t* q, uint32
     srv->served.polled_void.fetch_add(1, std::memory_order_relaxed);
     srv->fill_aborts.fetch_add(1, std::memory_order_relaxed);
     if (!a->r0_zero) e = hipMemsetAsync(a->r_dev, 0, (C + 1) * 4, st);
-    a->r0_zero = false;
+    a->r0_zero = false, a->r_zero_words = 0;
     if (e == hipSuccess) rc = launch_respond_read_once(srv->dev, srv->dtc, L, a->q_pinned_dev, kq_len, kq_off, a->r_dev, st);
   }
   if (polled) {
@@ -1046,19 +1046,21 @@ static int respond_in_round(Server* srv, RespondArena* a, uint32_t seat, const u
       uint32_t seq = 0;
       {
         std::lock_guard<std::mutex> ll(srv->dev->launch_mu);
-        a->r0_zero = false;
-        // (the word behind the k responses is the abort flag of a polled pass; whatever an uploaded round left there goes first)
-        if (polled) e = hipMemsetAsync(a->r_dev + (size_t)k * C, 0, 4, st);
+        // (the k responses and the word behind them -- the abort flag of a polled pass -- start from zero: left so by the hand-over of the
+        // round before where that was as wide, else cleared here)
+        const bool clean = a->r_zero_words >= k * C + 1;
+        a->r0_zero = false, a->r_zero_words = 0;
+        if (!clean) e = hipMemsetAsync(a->r_dev, 0, ((size_t)k * C + 1) * 4, st);
         const PlanarHostFill fill{a->fill_progress_dev, a->r_dev + (size_t)k * C, fill_timeout_us, k};
         if (e == hipSuccess)
-          rc = launch_respond_read_rows_in_place(srv->dev, srv->dtc, srv->phys, a->seat_q, k, kq_len, kq_off, a->r_dev, st, polled ? &fill : nullptr);
+          rc = launch_respond_read_rows_in_place(srv->dev, srv->dtc, srv->phys, a->seat_q, k, kq_len, kq_off, a->r_dev, st, polled ? &fill : nullptr, true);
         if (e == hipSuccess && rc == CPIR_OK) {
           // the responses (and the flag word) are handed over by the one-block kernel that also leaves them zeroed on the device
           seq = ++a->hand_seq ? a->hand_seq : ++a->hand_seq;  // never 0
           uint32_t* const r_host_dev = const_cast<uint32_t*>(a->q_pinned_dev) + (a->r_pinned - a->q_pinned);
           hipLaunchKernelGGL(respond_hand_over_kernel, dim3(1), dim3(256), 0, st, a->r_dev, (uint32_t)(k * C + 1), r_host_dev, a->handed_dev, seq);
           e = hipGetLastError();
-          if (e == hipSuccess) a->r0_zero = true;
+          if (e == hipSuccess) a->r0_zero = true, a->r_zero_words = (uint32_t)(k * C + 1);
         }
       }
       if (attempt == 0) {  // the leader's own query, under the pass that is already waiting for it
@@ -1424,7 +1426,7 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
     if (st == CPIR_OK) {
       std::lock_guard<std::mutex> ll(srv->dev->launch_mu);  // the launch sequences of two arenas must not interleave on the run stream
       for (uint32_t i = 0; i < k && e == hipSuccess; i++) e = hipStreamWaitEvent(srv->run_stream, a->seat_ev[i], 0);
-      a->r0_zero = false;
+      a->r0_zero = false, a->r_zero_words = 0;
       if (e == hipSuccess)
         st = compact ? respond_batched(srv->dev, srv->dtc, srv->phys, a->q_compact, srv->map.n_pad, 0, k, a->r_dev, nullptr, srv->run_stream)
                      : server_respond_on_device(srv, a->q_dev, srv->total_slots, srv->slot_offset, k, false, a->r_dev, nullptr, a->q_compact, srv->run_stream);

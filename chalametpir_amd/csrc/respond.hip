@@ -507,7 +507,8 @@ int launch_respond_read_once(const Device* dev, const uint32_t* dtc, const cpir_
 }
 
 int launch_respond_read_rows_in_place(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* const* q_rows, uint32_t batch,
-                                      uint64_t q_len, uint64_t q_slot_offset, uint32_t* r, hipStream_t stream, const PlanarHostFill* fill) {
+                                      uint64_t q_len, uint64_t q_slot_offset, uint32_t* r, hipStream_t stream, const PlanarHostFill* fill,
+                                      bool r_prezeroed) {
   if (!dtc || !q_rows || !r || L.packing != CPIR_PACK_PLANAR) return CPIR_ERR_INVALID_ARGUMENT;
   if (fill && fill->seats != batch) return CPIR_ERR_INVALID_ARGUMENT;  // (every query of the pass has a count of its own, complete from the start or not)
   CPIR_TRY(check_layout(L));
@@ -522,7 +523,7 @@ int launch_respond_read_rows_in_place(const Device* dev, const uint32_t* dtc, co
   // still be arriving -- and the far-mode fragment schedule; measured the same as contiguous units where they are complete, 228 vs 231 us
   // for two queries at 2^20 keys x 1 kB, scripts/probes/inplace_batch.py)
   return launch_respond_planar_ks(dev, dtc, L, nullptr, q_len, q_slot_offset, batch, 1, r, stream, t.planar_blocks_per_cu, t.nontemporal != 0,
-                                  t.xcd_split != 0, true, false, 0, 0, fill, q_rows);
+                                  t.xcd_split != 0, true, r_prezeroed, 0, 0, fill, q_rows);
 }
 
 int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout& L, const uint32_t* q, uint64_t q_len,

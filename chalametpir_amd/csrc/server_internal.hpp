@@ -48,6 +48,7 @@ struct RespondArena {
   uint32_t* handed_dev = nullptr;
   uint32_t hand_seq = 0;                   // (guarded like r0_zero: one lone caller per arena at a time)
   bool r0_zero = false;                    // seat 0 of r_dev holds zeros (guarded by the arena's own leader: one at a time)
+  uint32_t r_zero_words = 0;               // ... and so do this many words from r_dev[0] on (what the last hand-over kernel left behind)
   // (servers with a slot map) the seats of this round hold COMPACT queries -- every caller compacts its query onto the kept slots while it
   // stages it, uploads 8/9 of the words into q_compact, and the launch needs no map -- or whole ones (DMA straight from page-locked caller
   // buffers, the kernel applies the map).  Decided by the caller that opens the arena, the same for all its seats; guarded by Server::mu.
