@@ -386,6 +386,12 @@ void server_destroy(Server* srv) {
     fprintf(stderr, "; served alone (query read in place) %llu, %.1f us each; of those %llu by one launch polling the copy, %u such launches gave up\n",
             (unsigned long long)t.solo.load(), t.solo.load() ? t.ns_solo.load() / (double)t.solo.load() / 1e3 : 0.0,
             (unsigned long long)srv->fill_polled.load(), srv->fill_aborts.load());
+    if (t.rounds.load()) {
+      const double nr = (double)t.rounds.load();
+      fprintf(stderr, "[cpir respond trace] %.0f in-place rounds, us per round (leader): seat to closed %.1f, launch calls %.1f, own copy behind them %.1f, "
+                      "until handed over %.1f\n", nr, t.ns_r_close.load() / nr / 1e3, t.ns_r_launch.load() / nr / 1e3, t.ns_r_copy.load() / nr / 1e3,
+              t.ns_r_done.load() / nr / 1e3);
+    }
     if (t.polled.load()) {
       const double np = (double)t.polled.load();
       fprintf(stderr, "[cpir respond trace] polled launches, us from entry: jobs with the helpers %.1f, launch call back %.1f, last job copied %.1f\n",
@@ -1011,6 +1017,9 @@ static int respond_in_round(Server* srv, RespondArena* a, uint32_t seat, const u
     const double window = 60e-6;
     double t_ready = -1;
     uint32_t k = 0;
+    const bool tr = srv->trace_on;
+    const double tr0 = tr ? now_seconds() : 0;
+    double tr1 = 0, tr2 = 0, tr3 = 0;
     for (bool closed = false; !closed;) {
       if (next_job < n_jobs) copy_a_job();
       lk.lock();
@@ -1033,6 +1042,7 @@ static int respond_in_round(Server* srv, RespondArena* a, uint32_t seat, const u
       }
       lk.unlock();
     }
+    if (tr) tr1 = now_seconds();
     srv->served.in_place_rounds.fetch_add(1, std::memory_order_relaxed);
     srv->served.in_place_calls.fetch_add(k, std::memory_order_relaxed);
     bool polled = false;
@@ -1064,7 +1074,9 @@ static int respond_in_round(Server* srv, RespondArena* a, uint32_t seat, const u
         }
       }
       if (attempt == 0) {  // the leader's own query, under the pass that is already waiting for it
+        if (tr) tr2 = now_seconds();
         while (next_job < n_jobs) copy_a_job();
+        if (tr) tr3 = now_seconds();
         lk.lock();
         a->staged++;
         lk.unlock();
@@ -1100,6 +1112,12 @@ static int respond_in_round(Server* srv, RespondArena* a, uint32_t seat, const u
       while (n > 0 && n < 3 && !srv->fill_aborts.compare_exchange_weak(n, n - 1, std::memory_order_relaxed)) {
       }
     }
+    if (tr) {
+      Server::Trace& t = srv->trace;
+      t.rounds++, t.batch_hist[k]++;
+      t.ns_r_close += (uint64_t)((tr1 - tr0) * 1e9), t.ns_r_launch += (uint64_t)((tr2 - tr1) * 1e9), t.ns_r_copy += (uint64_t)((tr3 - tr2) * 1e9);
+      t.ns_r_done += (uint64_t)((now_seconds() - tr3) * 1e9);
+    }
     status = rc;
     if (rc == CPIR_OK && e != hipSuccess) {
       set_last_hip_error(e, "respond (round read in place)", __FILE__, __LINE__);
@@ -1116,6 +1134,7 @@ static int respond_in_round(Server* srv, RespondArena* a, uint32_t seat, const u
   status = a->status;
   lk.unlock();
   if (status == CPIR_OK) memcpy(r_out, a->r_pinned + seat * C, C * 4);
+  if (srv->trace_on) srv->trace.calls++;
   lk.lock();
   srv->inside--;
   if (++a->left == a->joined) {  // last one out frees the arena

@@ -129,6 +129,9 @@ struct Server {
     // a lone caller whose query is staged under a polled launch: until the jobs are with the helpers / until the launch call is back /
     // until the last job is published / until the response is there
     std::atomic<uint64_t> polled{0}, ns_p_submit{0}, ns_p_launch{0}, ns_p_copied{0}, ns_p_done{0};
+    // the leader of an in-place round: from its seat until the round is closed / until the launch calls are back / until its own copy is
+    // complete / until the responses are handed over
+    std::atomic<uint64_t> rounds{0}, ns_r_close{0}, ns_r_launch{0}, ns_r_copy{0}, ns_r_done{0};
   } trace;
   bool trace_on = false;
   // how the host callers have been served (cpir_server_host_path_counts): always counted, a relaxed add each
