@@ -386,9 +386,15 @@ def test_a_few_concurrent_callers_share_one_pass_that_reads_their_queries_in_pla
         pa.array[:N] = q
     shifted = cp.PinnedArray(N + 4)
     shifted.array[1:N + 1] = qs[0]
+    # ... and a caller whose own mapping (never heap memory: see OwnMapping) is hipHostRegister'ed: page-locked by registration
+    rt = torch.cuda.cudart()
+    own = OwnMapping(N) if hasattr(rt, "cudaHostRegister") and hasattr(rt, "cudaHostUnregister") else None
+    if own is not None:
+        own.array[:] = qs[1]
+        assert int(rt.cudaHostRegister(own.address, own.nbytes, 0)) == 0
     planar = packing.startswith("planar")  # (the other packings have no kernel that reads a query exactly once)
-    # who asks: "p" a page-locked query, "g" a pageable one, "s" the page-locked view that is not 16-byte aligned
-    crews = ("pp", "ppp", "pppp", "gg", "pg", "ggg", "pgsg", "ppggps")
+    # who asks: "p" a page-locked query, "g" a pageable one, "s" the page-locked view that is not 16-byte aligned, "r" the registered mapping
+    crews = ("pp", "ppp", "pppp", "gg", "pg", "ggg", "pgsg", "ppggps") + (("rp", "rgr") if own is not None else ())
     try:
         for seats, timeout_us in ((4, 2000), (2, 2000), (0, 2000)):
             cp.tuning_set("respond.inplace_seats", seats)
@@ -410,6 +416,8 @@ def test_a_few_concurrent_callers_share_one_pass_that_reads_their_queries_in_pla
                                 got = srv.respond_array(qs[k])
                             elif kind == "s":
                                 got, k = srv.respond_array(shifted.array[1:N + 1]), 0
+                            elif kind == "r":
+                                got, k = srv.respond_array(own.array), 1
                             else:
                                 got = srv.respond_array(pins[k].array[:N])
                             if not np.array_equal(got, wanted[k]):
@@ -466,6 +474,10 @@ def test_a_few_concurrent_callers_share_one_pass_that_reads_their_queries_in_pla
         for pa in pins:
             pa.close()
         shifted.close()
+        if own is not None:
+            err = rt.cudaHostUnregister(own.address)
+            own.close()
+            assert int(err) == 0, err
 
 
 def test_partly_registered_query_buffer_is_not_read_in_place(orc, device):
