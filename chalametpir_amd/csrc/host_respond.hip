@@ -1239,6 +1239,7 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
     a->seat_q[seat] = q0_in_place ? q0_in_place : a->q_pinned_dev + seat * stride;
     a->seat_polled[seat] = q0_in_place == nullptr;
     publish_fill_progress(a->fill_progress + (size_t)seat * CPIR_FILL_LINES * 16, q0_in_place ? 0xffffffffu : 0u);
+    if (!leader) srv->cv.notify_all();  // (a leader with nothing to copy sleeps on its window: the company it waits for is here)
   }
   srv->caller_enters();
   lk.unlock();

@@ -70,7 +70,7 @@ static double run(int threads, int calls, int pinned) {  /* queries per second *
   job_t jobs[64];
   const double t0 = now();
   for (int t = 0; t < threads; t++) {
-    jobs[t].id = t * 5, jobs[t].calls = calls, jobs[t].pinned = pinned;
+    jobs[t].id = t * 5, jobs[t].calls = calls, jobs[t].pinned = pinned == 2 ? (t & 1) == 0 : pinned; /* 2: every other caller page-locked */
     pthread_create(&th[t], NULL, caller, &jobs[t]);
   }
   for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
@@ -130,7 +130,7 @@ int main(int argc, char** argv) {
     CHECK(cpir_server_respond(g_srv, g_q[k], 1, g_N, g_want[k]));
   }
   if (getenv("CPIR_BENCH_INPLACE_SEATS")) CHECK(cpir_tuning_set("respond.inplace_seats", atoi(getenv("CPIR_BENCH_INPLACE_SEATS")))); /* A/B */
-  /* 4th argument "tT" (e.g. t16) + 5th 0 / 1: ONLY T closed-loop callers with pageable / page-locked queries, three rounds (with
+  /* 4th argument "tT" (e.g. t16) + 5th 0 / 1 / 2: ONLY T closed-loop callers with pageable / page-locked / mixed queries, three rounds (with
    * CPIR_RESPOND_TRACE=1 the library prints where their time went when the server is released) */
   if (argc > 4 && argv[4][0] == 't') {
     const int T = atoi(argv[4] + 1), pinned = argc > 5 ? atoi(argv[5]) : 0;
