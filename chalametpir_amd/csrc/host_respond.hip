@@ -1014,7 +1014,10 @@ static int respond_in_round(Server* srv, RespondArena* a, uint32_t seat, const u
     // The leader closes the round when the device is free of the launch before AND the callers recently seen beside it have joined, or a
     // moment has passed (they were answered by the same pass and come back within tens of microseconds of each other; a second query costs
     // the pass a tenth of its time, a second pass all of it) -- and copies its own query meanwhile, job by job.
-    const double window = 60e-6;
+    // (the moment: a third of what one pass over the image takes, 5 .. 60 us -- a small database must not wait longer for company that may
+    // have gone another way than answering alone would take)
+    const double pass_s = (double)srv->phys.total_words * 4 / 6.8e12;
+    const double window = pass_s * 0.3 < 5e-6 ? 5e-6 : (pass_s * 0.3 > 60e-6 ? 60e-6 : pass_s * 0.3);
     double t_ready = -1;
     uint32_t k = 0;
     const bool tr = srv->trace_on;
