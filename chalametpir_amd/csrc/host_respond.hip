@@ -1171,9 +1171,9 @@ int cpir_server_respond(const cpir_server* csrv, const uint32_t* q, uint32_t q_r
   {
     const uint64_t per_query = (uint64_t)(C + 63) / 64 * 256;
     if (per_query * inplace_cap > (48u << 10)) inplace_cap = (uint32_t)((48u << 10) / per_query);
-    // (short queries -- below 2^19 words, 2 MB -- two at a time only: their uploads are cheap, and three or four callers do better with two
-    // arenas that alternate between uploading and answering: 2^16 keys x 1 kB, 4 page-locked callers 37 against 34 k queries/s; 2: 22 -> 30 k)
-    if (q_hi - q_lo < ((size_t)1 << 19) && inplace_cap > 2) inplace_cap = 2;
+    // (short queries -- below 2^19 words, 2 MB -- at most three at a time: their uploads are cheap, and FOUR callers do 5-10 % better with two
+    // arenas that alternate between uploading and answering -- 2^18 keys x 1 kB, page-locked: 22.4 against 21.2 k queries/s; three: 15.5 -> 19.5 k)
+    if (q_hi - q_lo < ((size_t)1 << 19) && inplace_cap > 3) inplace_cap = 3;
   }
   const uint32_t* q0_in_place = nullptr;  // the device-visible address of q[0]
   const bool mapped_srv = srv->map.active();
