@@ -198,7 +198,10 @@ int cpir_device_open(int ordinal, cpir_device** out) {
   return CPIR_OK;
 }
 
-void cpir_device_close(cpir_device* dev) { device_release(dev); }
+void cpir_device_close(cpir_device* dev) {
+  if (dev) scratch_drain(dev->ordinal);
+  device_release(dev);
+}
 
 int cpir_device_ordinal(const cpir_device* dev, int* ordinal) {
   if (!dev || !ordinal) return CPIR_ERR_INVALID_ARGUMENT;
@@ -298,13 +301,11 @@ int cpir_op_mat_x_packed(cpir_device* dev, const uint32_t* A, uint64_t lda, cons
   if (!mfma_matmul_enabled() || !mfma_planar_rhs_applicable(A, lda, *layout)) return CPIR_ERR_INVALID_ARGUMENT;
   DeviceGuard g(dev->ordinal);
   hipStream_t s = pick_stream(dev, stream);
-  void* rowsum = nullptr;  // stream-ordered scratch: the row sums of A (a correction term of the signed-byte split)
-  CPIR_HIP_TRY(hipMallocAsync(&rowsum, 4 * ((rows + 127) / 128 * 128), s));
+  void* rowsum = nullptr;  // scratch (released behind the launch): the row sums of A (a correction term of the signed-byte split)
+  CPIR_TRY(scratch_acquire(&rowsum, 4 * ((rows + 127) / 128 * 128)));
   const int st = launch_mat_x_mat_mfma_planar(dev, A, lda, dtc, *layout, hi_plane, static_cast<uint32_t*>(rowsum), M, ldm, rows, accumulate, s);
-  const hipError_t e = hipFreeAsync(rowsum, s);
-  if (st != CPIR_OK) return st;
-  CPIR_HIP_TRY(e);
-  return CPIR_OK;
+  const int st2 = scratch_release_after(rowsum, s);
+  return st != CPIR_OK ? st : st2;
 }
 
 int cpir_op_dtc_import(cpir_device* dev, const uint32_t* compressed, const cpir_dtc_layout* layout, uint32_t* dtc, void* stream) {

@@ -253,6 +253,19 @@ int launch_mat_x_mat_mfma_planar(const Device* dev, const uint32_t* A, uint64_t 
                                  const void* hi_plane, uint32_t* rowsum_ws, uint32_t* M, uint64_t ldm, uint64_t rows, int accumulate,
                                  hipStream_t stream);
 uint64_t mfma_rhs_workspace_bytes(uint64_t inner, uint64_t cols, uint64_t max_rows);
+// Device scratch for work enqueued on a stream -- NOT the runtime's stream-ordered allocator.  On this runtime (ROCm 7.2, gfx950) a kernel
+// was seen reading a block of hipMallocAsync that had just been recycled on the same stream before the kernel in front of it had written it
+// (scripts/probes/mallocasync_order_probe.hip: fill + check kernels alone, 4 in 20 000 iterations; the hint products of a group's shards,
+// back to back on one stream: 1 in 100 wrong in every entry -- scripts/probes/matmul_backtoback_repro.cpp, setup_hint_repro.cpp).
+// scratch_acquire: hipMalloc on the current device; scratch_release_after: the block is freed once everything enqueued on `stream` so far
+// has completed (an event, waited for by one background thread) -- the caller may return without synchronising; scratch_drain(ordinal):
+// until every released block of that device has been freed.
+int scratch_acquire(void** p, size_t bytes);
+int scratch_release_after(void* p, hipStream_t stream);
+void scratch_drain(int ordinal);
+
+// M[r][c] = 0 for r < rows, c < cols (leading dimension ldm) as a KERNEL on `stream` (one launch whatever ldm is)
+int launch_zero_matrix(uint32_t* M, uint64_t ldm, uint64_t rows, uint64_t cols, hipStream_t stream);
 int launch_rhs_split(const Device* dev, const uint32_t* D, uint64_t ldd, uint64_t inner, uint64_t cols, void* workspace, hipStream_t stream);
 int launch_mat_x_mat_mfma(const Device* dev, const uint32_t* A, uint64_t lda, const void* workspace, uint64_t inner, uint64_t cols,
                           uint32_t* M, uint64_t ldm, uint64_t rows, uint64_t ws_max_rows, int accumulate, hipStream_t stream);

@@ -147,6 +147,119 @@ static hipError_t wait_for_event(hipEvent_t ev) {
   return hipEventSynchronize(ev);
 }
 
+namespace {
+// blocks released behind work that is still running: ONE background thread waits for each block's event and frees it (in release order)
+class ScratchReaper {
+ public:
+  struct Block {
+    void* p = nullptr;
+    int ordinal = 0;
+    hipEvent_t done = nullptr;
+  };
+  ~ScratchReaper() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    if (th_.joinable()) th_.join();
+  }
+  void push(const Block& b) {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (!th_.joinable()) th_ = std::thread([this] { run(); });
+      q_.push_back(b);
+      pending_++;
+    }
+    cv_.notify_all();
+  }
+  void drain(int ordinal) {  // until no block of that device is waiting or being freed
+    std::unique_lock<std::mutex> lk(mu_);
+    idle_cv_.wait(lk, [&] {
+      if (current_ordinal_ == ordinal) return false;
+      for (const Block& b : q_)
+        if (b.ordinal == ordinal) return false;
+      return true;
+    });
+  }
+
+ private:
+  void run() {
+    (void)pthread_setname_np(pthread_self(), "cpir-scratch");
+    for (;;) {
+      Block b;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
+        if (q_.empty()) return;  // stop requested and nothing left
+        b = q_.front();
+        q_.pop_front();
+        current_ordinal_ = b.ordinal;
+      }
+      {
+        DeviceGuard g(b.ordinal);
+        (void)hipEventSynchronize(b.done);
+        (void)hipEventDestroy(b.done);
+        (void)CPIR_HIP_FREE(b.p);
+      }
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        current_ordinal_ = -1;
+        pending_--;
+      }
+      idle_cv_.notify_all();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_, idle_cv_;
+  std::deque<Block> q_;
+  std::thread th_;
+  int current_ordinal_ = -1;
+  size_t pending_ = 0;
+  bool stop_ = false;
+};
+ScratchReaper g_scratch_reaper;
+}  // namespace
+
+int scratch_acquire(void** p, size_t bytes) {
+  if (!p || bytes == 0) return CPIR_ERR_INVALID_ARGUMENT;
+  *p = nullptr;
+  hipError_t e = CPIR_HIP_MALLOC(p, bytes);
+  if (e == hipErrorOutOfMemory) {  // blocks still waiting to be freed may be what is missing: wait for them, once
+    (void)hipGetLastError();
+    int ordinal = 0;
+    if (hipGetDevice(&ordinal) == hipSuccess) g_scratch_reaper.drain(ordinal);
+    e = CPIR_HIP_MALLOC(p, bytes);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    set_last_hip_error(e, "hipMalloc(scratch)", __FILE__, __LINE__);
+    *p = nullptr;
+    return e == hipErrorOutOfMemory ? CPIR_ERR_OUT_OF_DEVICE_MEMORY : CPIR_ERR_HIP;
+  }
+  return CPIR_OK;
+}
+
+int scratch_release_after(void* p, hipStream_t stream) {
+  if (!p) return CPIR_OK;
+  ScratchReaper::Block b;
+  b.p = p;
+  hipError_t e = hipGetDevice(&b.ordinal);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&b.done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventRecord(b.done, stream);
+  if (e != hipSuccess) {  // no event to wait on: drain the stream and free now
+    set_last_hip_error(e, "scratch_release_after", __FILE__, __LINE__);
+    if (b.done) (void)hipEventDestroy(b.done);
+    (void)hipStreamSynchronize(stream);
+    (void)CPIR_HIP_FREE(p);
+    return CPIR_ERR_HIP;
+  }
+  g_scratch_reaper.push(b);
+  return CPIR_OK;
+}
+
+void scratch_drain(int ordinal) { g_scratch_reaper.drain(ordinal); }
+
 void device_retain(Device* d) { d->refs.fetch_add(1); }
 void device_release(Device* d) {
   if (d && d->refs.fetch_sub(1) == 1) {
@@ -691,7 +804,7 @@ int server_respond_on_device(const Server* srv, const uint32_t* q, uint64_t q_le
   }
   uint32_t* own = nullptr;
   if (!qc) {
-    CPIR_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&own), (size_t)batch * m.n_pad * 4, stream));
+    CPIR_TRY(scratch_acquire(reinterpret_cast<void**>(&own), (size_t)batch * m.n_pad * 4));
     qc = own;
   }
   int st = launch_gather_query(srv->dev, q, q_len, q_slot_offset, m, batch, qc, stream);
@@ -699,11 +812,8 @@ int server_respond_on_device(const Server* srv, const uint32_t* q, uint64_t q_le
     st = lone ? launch_respond(srv->dev, srv->dtc, srv->phys, qc, m.n_pad, 0, 1, 1, r, scratch, stream)
               : respond_batched(srv->dev, srv->dtc, srv->phys, qc, m.n_pad, 0, batch, r, scratch, stream);
   if (own) {
-    const hipError_t fe = hipFreeAsync(own, stream);
-    if (st == CPIR_OK && fe != hipSuccess) {
-      set_last_hip_error(fe, "hipFreeAsync(compact queries)", __FILE__, __LINE__);
-      st = CPIR_ERR_HIP;
-    }
+    const int st2 = scratch_release_after(own, stream);
+    if (st == CPIR_OK) st = st2;
   }
   return st;
 }

@@ -237,13 +237,9 @@ static int pack_into_server(Device* dev, Server* srv, const uint32_t* D_dev, uin
       // (the other two packings) the kept rows are gathered into a temporary of (almost) D's size while D is still resident: where the
       // device has no room for that -- a database that fits beside its image but not twice -- the map is dropped and the whole matrix
       // packed as it is.  Compaction is an optimisation, never a reason for setup to fail.
-      const hipError_t ae = hipMallocAsync(reinterpret_cast<void**>(&Dc), (size_t)map->n_kept * L.num_cols * 4, stream);
-      if (ae != hipSuccess) {
-        (void)hipGetLastError();
-        if (ae != hipErrorOutOfMemory) {
-          set_last_hip_error(ae, "hipMallocAsync(compact D)", __FILE__, __LINE__);
-          return CPIR_ERR_HIP;
-        }
+      const int as = scratch_acquire(reinterpret_cast<void**>(&Dc), (size_t)map->n_kept * L.num_cols * 4);
+      if (as != CPIR_OK) {
+        if (as != CPIR_ERR_OUT_OF_DEVICE_MEMORY) return as;
         Dc = nullptr;
         map->reset();
         P = L;
@@ -253,7 +249,7 @@ static int pack_into_server(Device* dev, Server* srv, const uint32_t* D_dev, uin
   const hipError_t de = CPIR_HIP_MALLOC(&srv->dtc, (size_t)P.total_words * 4);
   if (de != hipSuccess) {
     set_last_hip_error(de, "hipMalloc(dtc)", __FILE__, __LINE__);
-    if (Dc) (void)hipFreeAsync(Dc, stream);
+    if (Dc) (void)scratch_release_after(Dc, stream);
     return de == hipErrorOutOfMemory ? CPIR_ERR_OUT_OF_DEVICE_MEMORY : CPIR_ERR_HIP;
   }
   int st;
@@ -263,11 +259,8 @@ static int pack_into_server(Device* dev, Server* srv, const uint32_t* D_dev, uin
   } else if (map->active()) {
     st = launch_gather_rows(dev, D_dev, ldd, *map, L.num_cols, Dc, stream);
     if (st == CPIR_OK) st = launch_transpose_compress(dev, Dc, L.num_cols, P, srv->dtc, flag_dev, stream, nullptr);
-    const hipError_t fe = hipFreeAsync(Dc, stream);
-    if (st == CPIR_OK && fe != hipSuccess) {
-      set_last_hip_error(fe, "hipFreeAsync(compact D)", __FILE__, __LINE__);
-      st = CPIR_ERR_HIP;
-    }
+    const int st2 = scratch_release_after(Dc, stream);
+    if (st == CPIR_OK) st = st2;
   } else {
     st = launch_transpose_compress(dev, D_dev, ldd, L, srv->dtc, flag_dev, stream, hi_plane);
   }

@@ -269,6 +269,20 @@ int mfma_ablate() { return g_mfma_ablate.load(); }
 void set_mfma_ablate(int bits) { g_mfma_ablate.store(bits); }
 #endif
 
+__global__ void __launch_bounds__(256) zero_matrix_kernel(uint32_t* __restrict__ M, uint64_t ldm, uint64_t rows, uint64_t cols) {
+  const uint64_t total = rows * cols;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) M[(i / cols) * ldm + i % cols] = 0u;
+}
+
+int launch_zero_matrix(uint32_t* M, uint64_t ldm, uint64_t rows, uint64_t cols, hipStream_t stream) {
+  if (!M || rows == 0 || cols == 0 || ldm < cols) return CPIR_ERR_INVALID_ARGUMENT;
+  uint64_t blocks = (rows * cols + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(zero_matrix_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, M, ldm, rows, cols);
+  CPIR_HIP_TRY(hipGetLastError());
+  return CPIR_OK;
+}
+
 const char* mat_x_mat_kernel_name(uint32_t rhs_max_bits) {
   if (rhs_max_bits > 16) return "mat_x_mat_u32_kernel";
   if (!mfma_matmul_enabled()) return "mat_x_mat_packed16_kernel";
@@ -283,17 +297,13 @@ int launch_mat_x_mat(const Device* dev, const uint32_t* A, uint64_t lda, const u
   if (lda < inner || ldd < cols || ldm < cols) return CPIR_ERR_INVALID_ARGUMENT;
   if (rhs_max_bits == 0 || rhs_max_bits > 32) return CPIR_ERR_INVALID_ARGUMENT;
   if (mfma_matmul_enabled() && mfma_matmul_applicable(A, lda, inner, cols, rhs_max_bits)) {
-    // the matrix-core path (matmul_mfma.hip); its prepared right-hand side lives in a stream-ordered scratch allocation
+    // the matrix-core path (matmul_mfma.hip); its prepared right-hand side lives in a scratch block released behind the launch
     void* ws = nullptr;
-    CPIR_HIP_TRY(hipMallocAsync(&ws, mfma_rhs_workspace_bytes(inner, cols, rows), stream));
+    CPIR_TRY(scratch_acquire(&ws, mfma_rhs_workspace_bytes(inner, cols, rows)));
     int st = launch_rhs_split(dev, D, ldd, inner, cols, ws, stream);
     if (st == CPIR_OK) st = launch_mat_x_mat_mfma(dev, A, lda, ws, inner, cols, M, ldm, rows, rows, accumulate, stream);
-    const hipError_t fe = hipFreeAsync(ws, stream);
-    if (st == CPIR_OK && fe != hipSuccess) {
-      set_last_hip_error(fe, "hipFreeAsync", __FILE__, __LINE__);
-      st = CPIR_ERR_HIP;
-    }
-    return st;
+    const int st2 = scratch_release_after(ws, stream);
+    return st != CPIR_OK ? st : st2;
   }
   const bool packed = rhs_max_bits <= 16;
   const uint64_t ks = packed ? 32 : 16;
@@ -332,7 +342,7 @@ int launch_mat_x_mat(const Device* dev, const uint32_t* A, uint64_t lda, const u
   a.k_per_split = k_per_split;
   a.atomic = (splits > 1 || accumulate) ? 1 : 0;
   if (a.atomic && !accumulate)
-    CPIR_HIP_TRY(hipMemset2DAsync(M, ldm * sizeof(uint32_t), 0, cols * sizeof(uint32_t), rows, stream));
+    CPIR_TRY(launch_zero_matrix(M, ldm, rows, cols, stream));
 
   const dim3 grid((unsigned)tiles_n, (unsigned)tiles_m, (unsigned)splits);
   if (packed) {

@@ -1014,7 +1014,7 @@ static int launch_product(const Device* dev, MfmaArgs& a, const uint32_t* colsum
   const bool pipe = mfma_pipe_addressable(lda, inner);
   if (!pipe && a.lo_tiles) return CPIR_ERR_INVALID_ARGUMENT;  // only the pipelined kernel reads the planar image (callers ask mfma_planar_rhs_applicable first)
   CPIR_HIP_TRY(hipMemsetAsync(a.rowsum, 0, 4 * round_up((uint32_t)rows, kBM), stream));
-  if (!accumulate) CPIR_HIP_TRY(hipMemset2DAsync(M, ldm * sizeof(uint32_t), 0, cols * sizeof(uint32_t), rows, stream));
+  if (!accumulate) CPIR_TRY(launch_zero_matrix(M, ldm, rows, cols, stream));
 #ifdef CPIR_DIAG
   if (pipe && (a.ablate & 16u)) {  // the 32x32x32 emulation (see MfmaAcc)
     if (a.lo_tiles && !a.hi_plane) hipLaunchKernelGGL((mat_x_mat_mfma_pipe_kernel<kRhsImageBit, true>), dim3(grid), dim3(kMT), 0, stream, a);

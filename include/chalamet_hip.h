@@ -123,7 +123,8 @@ const char* cpir_xof_permutation(void);
  * rhs_max_bits: an upper bound on the bit width of every D entry: <= 16 selects the matrix-core kernel (exact signed-byte split,
  * csrc/matmul_mfma.hip; it needs A 16-byte aligned with lda and inner multiples of 4, else the packed 16-bit dot-product kernel on
  * the VALU runs), 32 the general u32 kernel; results are identical whenever the bound is true.  The matrix-core path keeps its
- * prepared right-hand side (2 bytes per entry of D) in a stream-ordered scratch allocation (hipMallocAsync on `stream`).
+ * prepared right-hand side (2 bytes per entry of D) in scratch memory of its own (hipMalloc now, freed by a background thread once the
+ * work enqueued here has completed -- not hipMallocAsync: see scratch_acquire in csrc/cpir_internal.hpp).
  * accumulate != 0 adds into M (used for K-sharded / row-block pipelined hints), else M is overwritten. */
 int cpir_op_mat_x_mat(cpir_device* dev, const uint32_t* A, uint64_t lda, const uint32_t* D, uint64_t ldd, uint32_t* M,
                       uint64_t ldm, uint64_t rows, uint64_t inner, uint64_t cols, uint32_t rhs_max_bits, int accumulate,

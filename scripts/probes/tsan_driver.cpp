@@ -68,14 +68,22 @@ static void exercise(cpir_device* dev, const Shape& sh, int round) {
     memcpy(qp[i], q[i].data(), 4 * sh.N);
     CK(cpir_server_respond(srv, q[i].data(), 1, sh.N, want[i].data()));  // lone, pageable
   }
+  std::atomic<const char*> phase{"lone"};
   auto ask = [&](cpir_server* s, int i, bool pinned) {
     std::vector<uint32_t> r(sh.C);
     CK(cpir_server_respond(s, pinned ? qp[i] : q[i].data(), 1, sh.N, r.data()));
-    if (memcmp(r.data(), want[i].data(), 4 * sh.C) != 0) g_bad++;
+    if (memcmp(r.data(), want[i].data(), 4 * sh.C) != 0) {
+      g_bad++;
+      uint32_t wrong = 0;
+      for (uint32_t c = 0; c < sh.C; c++) wrong += r[c] != want[i][c];
+      fprintf(stderr, "MISMATCH: N %llu round %d, phase \"%s\", query %d %s, %u of %u columns differ (first: got %08x want %08x)\n", (unsigned long long)sh.N,
+              round, phase.load(), i, pinned ? "page-locked" : "pageable", wrong, sh.C, r[0], want[i][0]);
+    }
   };
   for (int i = 0; i < kQ; i++) ask(srv, i, true);  // lone, page-locked
   for (int i = 0; i < kQ; i++) ask(srv, i, false);
   {  // a burst of concurrent callers
+    phase = "burst of 8";
     std::vector<std::thread> ts;
     for (int t = 0; t < 8; t++)
       ts.emplace_back([&, t] {
@@ -86,6 +94,7 @@ static void exercise(cpir_device* dev, const Shape& sh, int round) {
   // a few callers at a time: in-place rounds (respond.inplace_seats) -- page-locked queries read where they lie, pageable ones copied into
   // their seats by their callers' threads while the pass polls every seat's progress; mixed crews; started together
   for (int crew = 2; crew <= 4; crew++) {
+    phase = crew == 2 ? "crew of 2 (page-locked)" : crew == 3 ? "crew of 3 (mixed)" : "crew of 4 (pageable)";
     std::atomic<int> ready{0};
     std::vector<std::thread> ts;
     for (int t = 0; t < crew; t++)
@@ -103,6 +112,7 @@ static void exercise(cpir_device* dev, const Shape& sh, int round) {
             (unsigned long long)sh.N, round, (unsigned long long)counts[0], (unsigned long long)counts[1], (unsigned long long)counts[4],
             (unsigned long long)counts[5], (unsigned long long)counts[6], (unsigned long long)counts[7], (unsigned long long)counts[3]);
   }
+  phase = "clone / second server";
   cpir_server* clone = cpir_server_retain(srv);
   cpir_server_release(srv);
   ask(clone, 0, false);
@@ -135,7 +145,7 @@ static void exercise_setup_and_group(cpir_device* dev, int round) {
   CK(cpir_server_setup(dev, seed, nullptr, D.data(), N, C, b, hint1.data(), &one));
   cpir_device* devs[3] = {dev, dev, dev};
   CK(cpir_server_setup_multi(devs, 3, seed, nullptr, D.data(), N, C, b, hint2.data(), &grp));
-  if (memcmp(hint1.data(), hint2.data(), hint1.size() * 4) != 0) g_bad++;
+  if (memcmp(hint1.data(), hint2.data(), hint1.size() * 4) != 0) g_bad++, fprintf(stderr, "MISMATCH: round %d, the group's hint\n", round);
   std::vector<uint32_t> q(N), r1(C);
   fill(q.data(), N, 5 + round, 0xFFFFFFFFu);
   CK(cpir_server_respond(one, q.data(), 1, N, r1.data()));
@@ -145,7 +155,7 @@ static void exercise_setup_and_group(cpir_device* dev, int round) {
       std::vector<uint32_t> r(C);
       for (int k = 0; k < 3; k++) {
         CK(cpir_server_respond(grp, q.data(), 1, N, r.data()));
-        if (memcmp(r.data(), r1.data(), 4 * C) != 0) g_bad++;
+        if (memcmp(r.data(), r1.data(), 4 * C) != 0) g_bad++, fprintf(stderr, "MISMATCH: round %d, group respond on host pointers (call %d of its thread)\n", round, k);
       }
     });
   for (auto& t : ts) t.join();
@@ -165,7 +175,7 @@ static void exercise_setup_and_group(cpir_device* dev, int round) {
           CK(cpir_server_respond_batch_device(grp, q_dev, kB, r_dev + (size_t)t * kB * C, nullptr, st));
           if (hipMemcpyAsync(r.data(), r_dev + (size_t)t * kB * C, r.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) exit(1);
           for (uint32_t i = 0; i < kB; i++)
-            if (memcmp(r.data() + (size_t)i * C, r1.data(), 4 * C) != 0) g_bad++;
+            if (memcmp(r.data() + (size_t)i * C, r1.data(), 4 * C) != 0) g_bad++, fprintf(stderr, "MISMATCH: round %d, group respond on device pointers (query %u)\n", round, (unsigned)i);
         }
         (void)hipStreamDestroy(st);
       });

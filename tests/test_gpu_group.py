@@ -53,6 +53,26 @@ def test_group_setup_and_respond_match_the_oracle(b, N, C, shards, orc, device, 
     assert twin.respond(wire(q)) == srv2.respond(wire(q)) == orc.server_respond(want_dtc, N, b, wire(q))
 
 
+def test_group_setup_with_empty_rows_gives_the_same_hint_every_time(orc, device, group_devices):
+    """cpir_server_setup_multi on a matrix with empty rows (every shard compacts; its hint product then takes the byte-plane split of its
+    rows of D, one product per shard back to back): forty setups, every hint equal to the single-device hint.  (One in a dozen was wrong in
+    every entry while the products' scratch came from the runtime's stream-ordered allocator: tests/test_gpu_setup.py, the test above the
+    matrix-core one.)"""
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(9728)
+    N, C, b = 3 * 1536 * 2 + 512, 20, 9
+    D = random_db_matrix(rng, N, C, b)
+    D[rng.random(N) < 0.2] = 0
+    seed = rng.bytes(32)
+    one, hint1 = cp.Server.setup_from_matrix(seed, D, b, device=device)
+    one.close()
+    for it in range(40):
+        grp, hint = cp.Server.setup_from_matrix(seed, D, b, devices=group_devices(3))
+        assert np.array_equal(hint, hint1), it
+        grp.close()
+
+
 def test_group_from_kv_database_equals_one_device(orc, device, group_devices):
     import chalametpir_amd as cp
 

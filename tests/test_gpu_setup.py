@@ -166,6 +166,33 @@ def test_mat_x_mat_matches_oracle_random(orc, device):
             assert np.array_equal(_host(M), want), ("accumulate", rows, inner, cols, bits)
 
 
+def test_products_back_to_back_on_one_stream_keep_their_scratch_to_themselves(orc, device):
+    """three hint products enqueued back to back on ONE stream (the shards of a small group: inner 3072 / 3072 / 3584, 20 columns), 300
+    times over: each keeps its prepared right-hand side in scratch memory of its own until its kernels are done.  (With the runtime's
+    stream-ordered allocator the second and third product read a recycled block before its kernel had written it -- one iteration in a
+    hundred wrong in every entry, scripts/probes/matmul_backtoback_repro.cpp, mallocasync_order_probe.hip; the library allocates such
+    scratch itself now and frees it behind an event.)"""
+    import torch
+
+    rng = np.random.default_rng(3072)
+    rows, cols, b = 1774, 20, 9
+    inners = (3072, 3072, 3584)
+    stream = torch.cuda.current_stream()
+    ops = []
+    for inner in inners:
+        A = random_query(rng, rows * inner).reshape(rows, inner)
+        D = rng.integers(0, 1 << b, size=(inner, cols), dtype=np.uint64).astype(np.uint32)
+        D[rng.random(inner) < 0.2] = 0
+        ops.append((_dev(A), _dev(D), torch.empty((rows, cols), dtype=torch.int32, device="cuda"), orc.mul(A, D), inner))
+    for it in range(300):
+        for A_dev, D_dev, M, _, inner in ops:
+            M.fill_(-1)
+            device.mat_x_mat(A_dev, D_dev, M, rows, inner, cols, rhs_max_bits=16, stream=stream)
+        torch.cuda.synchronize()
+        for g, (_, _, M, want, inner) in enumerate(ops):
+            assert np.array_equal(_host(M), want), (it, g, inner)
+
+
 def test_mat_x_mat_on_the_matrix_cores(orc, device):
     """the i8 matrix-core kernel (csrc/matmul_mfma.hip) against the oracle's impl Mul (matrix.rs:1040-1059) and against the VALU kernel:
     ragged rows / columns / k tails, padded leading dimensions, extreme byte patterns in both operands (every limb 0x00, 0x7f, 0x80,
