@@ -39,7 +39,7 @@ def test_bench_multirank_on_one_gpu(world, config):
 
 def test_bench_gpus_n_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it (what the driver runs for its scaling table) must start 2 ranks by
-    itself -- as a child torch.distributed.run, before this process touches the GPU -- and print ONE line from rank 0"""
+    itself -- as a child torch.distributed.run, before this process touches the GPU -- and only rank 0 prints"""
     env = dict(os.environ, CPIR_BENCH_BACKEND="gloo", CPIR_BENCH_SHARE_DEVICE="1", OMP_NUM_THREADS="8")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -47,10 +47,14 @@ def test_bench_gpus_n_launches_its_own_ranks():
            "--no-cpu-baseline", "--no-setup", "--verify", "--queries-per-step", "8", "--query-pool", "16"]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
-    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    out = json.loads(lines[0])
+    # (rank 0 prints the line after the timed region and again after every stage behind it: a consumer takes the LAST one; nothing else
+    # is on stdout, and the last line has nothing pending)
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert lines and all(l.startswith("{") for l in lines)
+    out = json.loads(lines[-1])
+    assert not any(k.endswith("_pending") for k in out) and json.loads(lines[0])["value"] == out["value"]
     assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["backend"] == "gloo" and out["verified_vs_oracle"] is True
+    assert out["single_gpu_reference"]["queries_per_sec"] > 0 and out["scaling_like_for_like"] > 0
 
 
 def test_driver_command_rehearsal_three_ranks():
@@ -71,7 +75,9 @@ def test_driver_command_rehearsal_three_ranks():
     assert out["server_setup_wall_sec"] > 0 and "server_setup_timed_out" not in out and out["hint_checksum"] > 0
     # like for like: the shards of this Infinity-Cache-sized database run their passes interleaved; the line also carries the same steps in
     # slice order (already in the line printed first) and rank 0's single-GPU run of the whole database, and divides the two
-    assert out["roofline"]["pass_order"] == "interleaved" and first["value_slice_order"] > 0 and first["slice_order"]["frac"] > 0
+    assert out["roofline"]["pass_order"] == "interleaved" and first["value_slice_order"] > 0 and first["slice_order"]["frac_algorithmic_equiv"] > 0
+    # Infinity-Cache-sized shards: there is no HBM rate to state, neither as dispatched nor in slice order
+    assert out["roofline"]["frac"] is None and first["slice_order"]["frac"] is None and first["slice_order"]["mall_resident"] is True
     ref = out["single_gpu_reference"]
     assert ref["queries_per_sec"] > 0 and ref["pass_order"] == "slice" and ref["queries_per_step"] == 32
     assert abs(out["scaling_like_for_like"] - out["value_slice_order"] / ref["queries_per_sec"]) < 2e-3
@@ -121,20 +127,29 @@ def test_bench_json_contract():
     assert "workload" in d["config"] and "model" not in d["config"]
     roof = d["roofline"]
     assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s") and roof["peak"] == 8000.0
-    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and "traffic" in roof
+    # `frac` is a RATE of bytes that really move through HBM; at this Infinity-Cache-sized database there is none to state (null), the
+    # kernel's consumption rate stays in `achieved` / `frac_moved` and SURVEY 8(d)'s algorithmic-bytes figure in `frac_algorithmic_equiv`
+    assert roof["frac"] is None and roof["mall_resident"] is True and "null" in roof["frac_is"] and "traffic" in roof
+    assert abs(roof["frac_moved"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert abs(roof["frac_algorithmic_equiv"] - roof["achieved_algorithmic_equiv"] / roof["peak"]) < 1e-3
+    assert 0.5 < roof["moved_over_algorithmic"] <= 1.0 and roof["traffic_over_algorithmic"] > 0
     # HBM traffic per launch is MEASURED in the run (two child runs of the timed loop under rocprofv3 --pmc): this Infinity-Cache-sized
     # database is walked in the interleaved order (its 32 passes share one stream of it on die), so anything between 1/32 of the layout
     # bytes plus the queries and a little above all of them
     assert isinstance(roof["traffic"], int) and roof["traffic"] > 0 and "measured in this run" in roof["traffic_source"]
     assert 0.01 < roof["traffic_over_moved_bytes"] < 1.2 and roof["pass_order"] == "interleaved"
     # the bytes really moved (the resident layout is tighter than the reference packing), against spec and against a live read-only probe
-    assert abs(roof["frac_moved"] - roof["moved_GBps"] / roof["peak"]) < 1e-3 and roof["frac_moved"] <= roof["frac"] + 1e-3
+    assert abs(roof["frac_moved"] - roof["moved_GBps"] / roof["peak"]) < 1e-3 and roof["frac_moved"] <= roof["frac_algorithmic_equiv"] + 1e-3
     assert roof["read_ceiling_GBps"] > 1000 and abs(roof["frac_vs_read_ceiling"] - roof["moved_GBps"] / roof["read_ceiling_GBps"]) < 1e-3
     assert d["ranks"] == 1 and d["backend"] is None
     assert abs(d["value"] - d["config"]["queries_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
     cpu = d["cpu_baseline"]
     assert cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1 and cpu["value"] > 0 and isinstance(cpu["sample"], str)
-    assert cpu["gpu_results_bit_exact"] is True
+    assert cpu["gpu_results_bit_exact"] is True and cpu["queries_compared"] == 32
+    # comparable from box to box: several samples per thread placement, the CPU's name and what the process may run on
+    assert cpu["min"] <= cpu["median"] <= cpu["max"] and cpu["value"] == cpu["median"] and isinstance(cpu["cpu_model"], str) and cpu["affinity_mask"]
+    for placement in ("threads_bound", "threads_unbound"):
+        assert len(cpu[placement]["samples"]) >= 3 and cpu[placement]["min"] <= cpu[placement]["median"] <= cpu[placement]["max"]
 
 
 def test_bench_default_sections_at_the_reference_tests_ceiling():
@@ -189,3 +204,55 @@ def test_two_ranks_over_the_real_backend_where_the_box_has_two_devices():
     assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["backend"] == ("nccl" if two else "gloo")
     assert out["multirank_bit_exact"] is True and out["ranks_seen"] == [0, 1] and out["verified_vs_oracle"] is True
     assert out["server_setup_wall_sec"] > 0 and out["hint_checksum"] > 0 and out["scaling_like_for_like"] > 0
+
+
+def test_default_line_carries_the_other_configs_and_the_cpu_figure_of_the_cpu_config():
+    """the default (N = 1) line: `other_configs` -- the headline's loop at other BASELINE shapes inside the same invocation, each with its
+    launch time, its rate and its responses checked against exact 64-bit sums -- and the CPU port's figure at BASELINE configs[0]
+    (2^16 keys: the reference's own CPU-runnable case).  Run here with small stand-ins for cfg3 / cfg4 / cfg5 so that it takes seconds."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "tiny", "--steps", "2", "--warmup", "1", "--no-setup", "--no-setup-kv",
+           "--no-host-path", "--no-live-traffic", "--no-read-ceiling", "--cpu-seconds", "1", "--other-configs", "cfg1,tiny", "--other-steps", "3"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert set(d["other_configs"]) == {"cfg1", "tiny"}
+    for name, sec in d["other_configs"].items():
+        assert "error" not in sec, sec
+        assert sec["value"] > 0 and sec["launch_us"] > 0 and sec["steps"] == 3 and sec["passes_per_launch"] == 32 and sec["pass_order"] == "slice"
+        assert sec["responses_bit_exact_vs_64bit_sums"] is True and sec["check"]["unit_queries_ok"] and sec["check"]["dense_and_all_ones_ok"]
+        assert sec["frac"] is None and sec["mall_resident"] is True and 0 < sec["frac_moved"]  # (cache-sized stand-ins: no HBM rate)
+        assert abs(sec["value"] - sec["queries_per_step"] / (sec["ms_per_step"] * 1e-3)) / sec["value"] < 0.01
+    small = d["cpu_baseline_cfg1"]
+    assert small["gpu_results_bit_exact"] is True and small["queries_compared"] == 32 and small["value"] > 0 and "cfg1" in small["workload"]
+
+
+def test_multirank_line_carries_baselines_multi_gpu_configs_and_the_group_handle():
+    """N > 1: behind the headline, the line gains `baseline_multi_gpu_configs` (BASELINE.json's own multi-GPU configs sharded over the ranks,
+    slice order, each with `multirank_bit_exact` and rank 0's single-GPU run of the same database) and -- after the process group is gone --
+    `respond_host_path_group`: ONE in-process handle over all the devices, the path rust/server_hip.rs gives a drop-in caller.  Three ranks
+    on the one GPU under the gloo hook, small stand-ins for cfg4 / cfg5."""
+    env = dict(os.environ, CPIR_BENCH_BACKEND="gloo", CPIR_BENCH_SHARE_DEVICE="1", OMP_NUM_THREADS="4")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "4", "--warmup", "2", "--config", "cfg1", "--no-setup",
+           "--other-configs", "tiny,cfg1", "--other-steps", "3", "--group-after-ranks", "always"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    first, out = lines[0], lines[-1]
+    assert first["baseline_multi_gpu_configs_pending"] is True and first["respond_host_path_group_pending"] is True and first["value"] > 0
+    assert not any(k.endswith("_pending") for k in out) and "stage_timed_out" not in out
+    secs = out["baseline_multi_gpu_configs"]
+    assert set(secs) == {"tiny", "cfg1"}
+    for name, sec in secs.items():
+        assert "error" not in sec, sec
+        assert sec["n_gpus"] == 3 and sec["queries_per_step"] == 96 and sec["pass_order"] == "slice" and sec["value"] > 0
+        assert sec["multirank_bit_exact"] is True and sec["ranks_seen"] == [0, 1, 2] and sum(sec["check"]["shard_slots"]) > 0
+        ref = sec["single_gpu_reference"]
+        assert ref["queries_per_sec"] > 0 and abs(sec["scaling_like_for_like"] - sec["value"] / ref["queries_per_sec"]) < 2e-3
+        assert sec["frac_moved"] > 0 and sec["launch_us"] > 0
+    grp = out["respond_host_path_group"]
+    assert "error" not in grp, grp
+    assert len(grp["shards"]) == 3 and grp["responses_equal_single_device"] is True and grp["device_queries_equal_single_device"] is True
+    assert grp["one_caller_us_per_query"] > 0 and grp["eight_callers_queries_per_sec"] > 0 and grp["device_queries_us_per_query"] > 0
+    assert out["value"] == first["value"] and out["multirank_bit_exact"] is True and out["single_gpu_reference"]["queries_per_sec"] > 0
