@@ -266,6 +266,9 @@ def main() -> int:
         "roofline": roof,
         "pack_seconds": round(pack_seconds, 3),
     }
+    if world > 1 and os.environ.get("CPIR_BENCH_SHARE_DEVICE") == "1":
+        # the one-GPU rehearsal hook: every rank on GPU 0, gloo as the collective -- plumbing only, no figure of this line is a measurement
+        result["rehearsal_ranks_share_one_device"] = True
     # LIKE FOR LIKE (N > 1, and the one-shard tuning runs): a shard below ~1 GB runs its passes in the interleaved order -- concurrent passes
     # share database bytes on die --, the N = 1 headline streams the database from HBM for every query.  `value` is what the product
     # dispatches; `value_slice_order` is the same shards, the same steps, every pass its own stream (slice order, `nt` loads), i.e. the
