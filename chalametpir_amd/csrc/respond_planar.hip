@@ -511,7 +511,7 @@ constexpr int kWMaxSets = 6;  // row sets of 4 queries
 // operand bytes per product, 16 accumulator registers per product instead of 4: what a 32-column image layout would make of the matrix
 // cores' and the LDS's share of a fused pass, measured without building that layout (scripts/wide_ablate.py, CPIR_WIDE_ABLATE bit 8).
 #ifdef CPIR_DIAG
-template <int HB, bool NT, bool MAP, int DV = 0>  // DV (diagnosis variants, responses WRONG): 1 EMU32, 2 / 3 the same B / A operand for all k-blocks of a row set
+template <int HB, bool NT, bool MAP, int DV = 0>  // DV (diagnosis variants, responses WRONG): 1 EMU32, 2 / 3 the same B / A operand for all k-blocks of a row set, 4 eleven of twelve MFMAs
 #else
 template <int HB, bool NT, bool MAP>  // (the release kernel has no such parameter: its name in a trace is respond_planar_wide_kernel<HB, NT, MAP>)
 #endif
@@ -816,7 +816,7 @@ respond_planar_wide_kernel(const PlanarArgs a) {
       uint4 f[8];
 #pragma unroll
       for (int kb = 0; kb < 8; kb++) f[kb] = abuf[kb * 64 + lane];
-      auto row_set = [&](uint32_t s, auto first) __attribute__((always_inline)) {
+      auto row_set = [&](uint32_t s, auto first, auto with_hi) __attribute__((always_inline)) {
         const uint4* const ap = abuf + (s + 1 < ns ? s + 1 : s) * 512 + lane;
         // no branch around the rows of a partly filled last set: they add 0 to the last query's word (their fragments are 0)
         const uint32_t query = 4 * s + grp, qq = query < nq ? query : nq - 1;
@@ -840,7 +840,7 @@ respond_planar_wide_kernel(const PlanarArgs a) {
           if constexpr (DV == 2) asm volatile("" ::"v"(cur[kb].x), "v"(cur[kb].y), "v"(cur[kb].z), "v"(cur[kb].w));
           if constexpr (DV == 3) asm volatile("" ::"v"(f[kb].x), "v"(f[kb].y), "v"(f[kb].z), "v"(f[kb].w));
           acc_lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(as_v4i(f[kbA]), as_v4i(cur[kbB]), acc_lo, 0, 0, 0);
-          if constexpr (HB > 0) acc_hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(as_v4i(f[kbA]), hbv[kbB], acc_hi, 0, 0, 0);
+          if constexpr (HB > 0 && decltype(with_hi)::value) acc_hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(as_v4i(f[kbA]), hbv[kbB], acc_hi, 0, 0, 0);
           f[kb] = ap[kb * 64];
         }
         uint32_t val = 0;
@@ -850,9 +850,18 @@ respond_planar_wide_kernel(const PlanarArgs a) {
         atomicAdd(rcol + qq * cpad, query < nq ? val : 0u);  // LDS; this wave owns tile T of the step
       };
       if constexpr (!EMU32) {
-        row_set(0u, std::integral_constant<bool, kPeel>{});
+        row_set(0u, std::integral_constant<bool, kPeel>{}, std::true_type{});
+        if constexpr (DV == 4) {
+          // (diagnosis variant 4, responses WRONG: the SIXTH row set of a pass of 24 without its high-plane MFMAs -- 11 instead of 12 matrix
+          // instructions per k-block, i.e. exactly what high-plane fragments of 3 rows per query (limb 3 x 2^8 = 0 mod 2^32) would save, with
+          // none of what they would cost: their LDS, their fragment reads, their second atomic -- the upper bound of that lever, in situ)
 #pragma unroll 1
-        for (uint32_t s = 1; s < ns; s++) row_set(s, std::false_type{});
+          for (uint32_t s = 1; s < ns && s < 5; s++) row_set(s, std::false_type{}, std::true_type{});
+          if (ns == 6) row_set(5u, std::false_type{}, std::false_type{});
+        } else {
+#pragma unroll 1
+          for (uint32_t s = 1; s < ns; s++) row_set(s, std::false_type{}, std::true_type{});
+        }
       } else {
         typedef int v16i __attribute__((ext_vector_type(16)));
         if constexpr (HB > 0 && kPeel) {
@@ -1193,6 +1202,7 @@ int launch_respond_planar_wide(const Device* dev, const uint32_t* dtc, const cpi
   if ((ablate_env & 8u) && hb == 1 && nt && !keep) fn = respond_planar_wide_kernel<1, true, false, 1>;  // (the 32x32x32 emulation: see the kernel)
   if ((ablate_env & 32u) && hb == 1 && nt && !keep) fn = respond_planar_wide_kernel<1, true, false, 2>;  // (the same B operands for a whole row set)
   if ((ablate_env & 64u) && hb == 1 && nt && !keep) fn = respond_planar_wide_kernel<1, true, false, 3>;  // (the same A fragment for a whole row set)
+  if ((ablate_env & 128u) && hb == 1 && nt && !keep) fn = respond_planar_wide_kernel<1, true, false, 4>;  // (11 of 12 matrix instructions per k-block)
 #endif
   a.q_row0 = a.q_row1 = a.q_row2 = a.q_row3 = nullptr;
   a.keep = keep;  // (device memory, at least L.num_slots entries, 16-byte aligned; the caller has checked that the slots it names lie inside q)

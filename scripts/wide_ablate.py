@@ -4,7 +4,8 @@
 the fragment reads and operand bytes: what a 32-column image layout would do to the matrix cores' and the LDS's share), 16 all-zero A
 fragments (the same instructions, operands that toggle nothing: is the pass bound by the power the matrix cores draw?), 32 / 64 the SAME B
 operands / A fragment for all eight k-blocks of a row set (everything still loaded and waited for: does it help when only one operand changes
-from instruction to instruction?).  One process per setting (the mask is read once).
+from instruction to instruction?), 128 the sixth row set of a pass of 24 without its high-plane MFMAs (11 instead of 12 matrix instructions per
+k-block: the upper bound of what high-plane fragments with 3 rows per query could save).  One process per setting (the mask is read once).
    python scripts/wide_ablate.py            -> runs itself once per mask and prints microseconds per launch for batches of 16 and 24"""
 import os
 import subprocess
@@ -46,6 +47,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         out.append(f"batch {k}: {e0.elapsed_time(e1) * 1e3 / 20:7.1f} us")
     print(f"ablate {os.environ.get('CPIR_WIDE_ABLATE', '0'):>2}:  " + "   ".join(out), flush=True)
 else:
-    for mask in (0, 1, 2, 4, 3, 7, 8, 16, 32, 64, 0, 8, 16, 32, 64):  # (8: the 32x32x32 emulation -- same byte products, half the fragment reads)
+    for mask in [int(x) for x in os.environ.get('CPIR_ABLATE_MASKS', '0,1,2,4,3,7,8,16,32,64,0,8,16,32,64').split(',')]:  # (8: the 32x32x32 emulation -- same byte products, half the fragment reads)
         env = dict(os.environ, CPIR_WIDE_ABLATE=str(mask))
         subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, check=False)
