@@ -302,7 +302,7 @@ int cpir_op_mat_x_packed(cpir_device* dev, const uint32_t* A, uint64_t lda, cons
   DeviceGuard g(dev->ordinal);
   hipStream_t s = pick_stream(dev, stream);
   void* rowsum = nullptr;  // scratch (released behind the launch): the row sums of A (a correction term of the signed-byte split)
-  CPIR_TRY(scratch_acquire(&rowsum, 4 * ((rows + 127) / 128 * 128)));
+  CPIR_TRY(scratch_acquire(&rowsum, 4 * ((rows + 127) / 128 * 128), s));
   const int st = launch_mat_x_mat_mfma_planar(dev, A, lda, dtc, *layout, hi_plane, static_cast<uint32_t*>(rowsum), M, ldm, rows, accumulate, s);
   const int st2 = scratch_release_after(rowsum, s);
   return st != CPIR_OK ? st : st2;

@@ -158,7 +158,7 @@ int build_slot_map(const Device* dev, const uint32_t* D_dev, uint64_t ldd, uint6
   if ((mode == 0 && !or_of_entries_host) || N == 0 || N >= 0xFFFFFFF0ull) return CPIR_OK;
   uint8_t* flags_dev = nullptr;
   const size_t flag_bytes = (size_t)(N + 3) / 4 * 4;  // the OR word sits behind the flags, 4-byte aligned
-  CPIR_TRY(scratch_acquire(reinterpret_cast<void**>(&flags_dev), flag_bytes + 4));
+  CPIR_TRY(scratch_acquire(reinterpret_cast<void**>(&flags_dev), flag_bytes + 4, stream));
   uint32_t* const or_dev = reinterpret_cast<uint32_t*>(flags_dev + flag_bytes);
   hipError_t e = hipMemsetAsync(or_dev, 0, 4, stream);
   std::vector<uint8_t> flags((size_t)N);
@@ -218,7 +218,7 @@ int build_slot_map_from_compressed(const Device* dev, const uint32_t* src_dev, u
   map->reset();
   if (compact_slots_mode() == 0 || N == 0 || N >= 0xFFFFFFF0ull || cf == 0 || cf > 32) return CPIR_OK;
   uint32_t* ored_dev = nullptr;
-  CPIR_TRY(scratch_acquire(reinterpret_cast<void**>(&ored_dev), (size_t)W * 4));
+  CPIR_TRY(scratch_acquire(reinterpret_cast<void**>(&ored_dev), (size_t)W * 4, stream));
   hipLaunchKernelGGL(or_rows_kernel, dim3(grid_for_items(dev, W)), dim3(kThreads), 0, stream, src_dev, W, C, ored_dev);
   hipError_t e = hipGetLastError();
   std::vector<uint32_t> ored((size_t)W);
@@ -266,7 +266,7 @@ int launch_expand_ref(const Device* dev, const uint32_t* compact_ref, uint64_t W
                       uint32_t* out, hipStream_t stream) {
   if (!compact_ref || !out || !map.keep_dev) return CPIR_ERR_INVALID_ARGUMENT;
   uint32_t* rank = nullptr;
-  CPIR_TRY(scratch_acquire(reinterpret_cast<void**>(&rank), (size_t)map.n_orig * 4));
+  CPIR_TRY(scratch_acquire(reinterpret_cast<void**>(&rank), (size_t)map.n_orig * 4, stream));
   hipError_t e = hipMemsetAsync(rank, 0xFF, (size_t)map.n_orig * 4, stream);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(rank_fill_kernel, dim3(grid_for_items(dev, map.n_kept)), dim3(kThreads), 0, stream, map.keep_dev, map.n_kept, rank);

@@ -257,10 +257,13 @@ uint64_t mfma_rhs_workspace_bytes(uint64_t inner, uint64_t cols, uint64_t max_ro
 // was seen reading a block of hipMallocAsync that had just been recycled on the same stream before the kernel in front of it had written it
 // (scripts/probes/mallocasync_order_probe.hip: fill + check kernels alone, 4 in 20 000 iterations; the hint products of a group's shards,
 // back to back on one stream: 1 in 100 wrong in every entry -- scripts/probes/matmul_backtoback_repro.cpp, setup_hint_repro.cpp).
-// scratch_acquire: hipMalloc on the current device; scratch_release_after: the block is freed once everything enqueued on `stream` so far
-// has completed (an event, waited for by one background thread) -- the caller may return without synchronising; scratch_drain(ordinal):
-// until every released block of that device has been freed.
-int scratch_acquire(void** p, size_t bytes);
+// scratch_acquire: a block of the current device for work about to be enqueued on `stream` (refused with CPIR_ERR_INVALID_ARGUMENT while that
+// stream is being captured into a graph: the entry points that need scratch are not graph-capturable) -- from a small pool, where a block
+// handed back earlier is reused only once the event recorded behind its last user has COMPLETED, else hipMalloc; scratch_release_after: the
+// block may be reused or freed once everything enqueued on `stream` so far has completed (an event; a block nobody asks for within half
+// a second of it is freed by one background thread) -- the caller may return without synchronising; scratch_drain(ordinal): until no
+// released block of that device waits for its event, the idle ones freed.
+int scratch_acquire(void** p, size_t bytes, hipStream_t stream);
 int scratch_release_after(void* p, hipStream_t stream);
 void scratch_drain(int ordinal);
 

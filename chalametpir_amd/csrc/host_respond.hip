@@ -148,15 +148,16 @@ static hipError_t wait_for_event(hipEvent_t ev) {
 }
 
 namespace {
-// blocks released behind work that is still running: ONE background thread waits for each block's event and frees it (in release order)
-class ScratchReaper {
+// Device scratch for work enqueued on a stream (see cpir_internal.hpp: never the runtime's stream-ordered allocator).  A small POOL per process:
+// a block handed back behind work that is still running (scratch_release_after: an event recorded on the caller's stream) may be handed out
+// again only once that event has COMPLETED -- the "never recycle before completion" property round 5 bought with a hipMalloc + hipFree per
+// call, without the allocation per call and without every back-to-back call keeping a workspace of its own alive until its event fires
+// (the hint product's workspace is 2 bytes per entry of D).  A block nobody has asked for within kIdleSeconds of its event is freed by the
+// pool's one background thread (hipFree waits for the device: never on a caller's thread).
+class ScratchPool {
  public:
-  struct Block {
-    void* p = nullptr;
-    int ordinal = 0;
-    hipEvent_t done = nullptr;
-  };
-  ~ScratchReaper() {
+  static constexpr double kIdleSeconds = 0.5;
+  ~ScratchPool() {
     {
       std::lock_guard<std::mutex> lk(mu_);
       stop_ = true;
@@ -164,101 +165,199 @@ class ScratchReaper {
     cv_.notify_all();
     if (th_.joinable()) th_.join();
   }
-  void push(const Block& b) {
+  int acquire(void** p, size_t bytes, int ordinal) {
+    *p = nullptr;
     {
       std::lock_guard<std::mutex> lk(mu_);
-      if (!th_.joinable()) th_ = std::thread([this] { run(); });
-      q_.push_back(b);
-      pending_++;
+      Block* best = nullptr;
+      for (Block& b : blocks_) {
+        if (b.ordinal != ordinal || b.bytes < bytes || b.bytes > bytes + bytes / 2 + (1u << 20)) continue;  // (no 17 GB block for a 4 KiB request)
+        if (b.state == PENDING && hipEventQuery(b.done) == hipSuccess) b.state = IDLE, b.t_idle = now_seconds();
+        else if (b.state == PENDING) (void)hipGetLastError();  // (hipErrorNotReady: not worth keeping)
+        if (b.state == IDLE && (!best || b.bytes < best->bytes)) best = &b;
+      }
+      if (best) {
+        best->state = IN_USE;
+        *p = best->p;
+        return CPIR_OK;
+      }
     }
-    cv_.notify_all();
+    void* q = nullptr;
+    hipError_t e = CPIR_HIP_MALLOC(&q, bytes);
+    if (e == hipErrorOutOfMemory) {  // blocks waiting for their events or idling in the pool may be what is missing: give them back, once
+      (void)hipGetLastError();
+      drain(ordinal);
+      e = CPIR_HIP_MALLOC(&q, bytes);
+    }
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      set_last_hip_error(e, "hipMalloc(scratch)", __FILE__, __LINE__);
+      return e == hipErrorOutOfMemory ? CPIR_ERR_OUT_OF_DEVICE_MEMORY : CPIR_ERR_HIP;
+    }
+    Block b;
+    b.p = q, b.bytes = bytes, b.ordinal = ordinal, b.state = IN_USE;
+    if ((e = hipEventCreateWithFlags(&b.done, hipEventDisableTiming)) != hipSuccess) {
+      set_last_hip_error(e, "hipEventCreateWithFlags(scratch)", __FILE__, __LINE__);
+      (void)CPIR_HIP_FREE(q);
+      return CPIR_ERR_HIP;
+    }
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!th_.joinable()) th_ = std::thread([this] { run(); });
+    blocks_.push_back(b);
+    *p = q;
+    return CPIR_OK;
   }
-  void drain(int ordinal) {  // until no block of that device is waiting or being freed
+  // the block may be reused (or freed) once everything enqueued on `stream` so far has completed
+  int release_after(void* p, hipStream_t stream) {
     std::unique_lock<std::mutex> lk(mu_);
-    idle_cv_.wait(lk, [&] {
-      if (current_ordinal_ == ordinal) return false;
-      for (const Block& b : q_)
-        if (b.ordinal == ordinal) return false;
-      return true;
-    });
+    for (Block& b : blocks_)
+      if (b.p == p && b.state == IN_USE) {
+        const hipError_t e = hipEventRecord(b.done, stream);
+        if (e == hipSuccess) {
+          b.state = PENDING;
+          lk.unlock();
+          cv_.notify_all();
+          return CPIR_OK;
+        }
+        // no event to wait on: drain the stream -- the device, if that fails too -- and only then let the block go
+        set_last_hip_error(e, "hipEventRecord(scratch)", __FILE__, __LINE__);
+        lk.unlock();
+        if (hipStreamSynchronize(stream) != hipSuccess) (void)hipDeviceSynchronize();
+        lk.lock();
+        for (Block& c : blocks_)
+          if (c.p == p) c.state = IDLE, c.t_idle = 0;  // (idle since for ever: the background thread frees it on its next round)
+        lk.unlock();
+        cv_.notify_all();
+        return CPIR_ERR_HIP;
+      }
+    return CPIR_ERR_INVALID_ARGUMENT;  // not a block of this pool
+  }
+  // until no block of that device waits for its event; the idle ones are freed
+  void drain(int ordinal) {
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      bool pending = false;
+      for (Block& b : blocks_)
+        if (b.ordinal == ordinal) {
+          if (b.state == IDLE) b.t_idle = 0;
+          if (b.state == PENDING || b.state == IDLE || b.state == FREEING) pending = true;
+        }
+      if (!pending) return;
+      cv_.notify_all();
+      idle_cv_.wait_for(lk, std::chrono::milliseconds(2));
+    }
   }
 
  private:
+  enum State { IN_USE, PENDING, IDLE, FREEING };
+  struct Block {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ordinal = 0;
+    hipEvent_t done = nullptr;
+    State state = IN_USE;
+    double t_idle = 0;
+  };
   void run() {
     (void)pthread_setname_np(pthread_self(), "cpir-scratch");
+    std::unique_lock<std::mutex> lk(mu_);
     for (;;) {
-      Block b;
-      {
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
-        if (q_.empty()) return;  // stop requested and nothing left
-        b = q_.front();
-        q_.pop_front();
-        current_ordinal_ = b.ordinal;
+      if (stop_) return;  // (the process is going down: nothing is given back to a runtime that may be going down too)
+      bool any_pending = false, any_idle = false;
+      void* victim = nullptr;  // a block to free, or (sync_first) a block whose event cannot be asked: looked up again by address once the lock is back
+      bool sync_first = false;
+      int victim_ordinal = 0;
+      hipEvent_t victim_ev = nullptr;
+      const double now = now_seconds();
+      for (Block& b : blocks_) {
+        if (b.state == PENDING) {
+          const hipError_t e = hipEventQuery(b.done);
+          if (e == hipSuccess) {
+            b.state = IDLE, b.t_idle = now;
+          } else {
+            (void)hipGetLastError();
+            if (e == hipErrorNotReady) {
+              any_pending = true;
+            } else if (!victim) {
+              // the event cannot be asked (a device error): nothing may be assumed about the work that reads the block -- the whole device
+              // is waited for before the block can be handed out or freed
+              victim = b.p, victim_ordinal = b.ordinal, sync_first = true;
+            }
+          }
+        }
+        if (b.state == IDLE) {
+          if (now - b.t_idle >= kIdleSeconds) {
+            if (!victim) b.state = FREEING, victim = b.p, victim_ordinal = b.ordinal, victim_ev = b.done;
+          } else {
+            any_idle = true;
+          }
+        }
       }
-      {
-        DeviceGuard g(b.ordinal);
-        (void)hipEventSynchronize(b.done);
-        (void)hipEventDestroy(b.done);
-        (void)CPIR_HIP_FREE(b.p);
-      }
-      {
-        std::lock_guard<std::mutex> lk(mu_);
-        current_ordinal_ = -1;
-        pending_--;
+      if (victim) {
+        lk.unlock();
+        {
+          DeviceGuard g(victim_ordinal);
+          if (sync_first) {
+            (void)hipDeviceSynchronize();
+          } else {
+            (void)hipEventDestroy(victim_ev);
+            (void)CPIR_HIP_FREE(victim);
+          }
+        }
+        lk.lock();
+        for (size_t i = 0; i < blocks_.size(); i++)
+          if (blocks_[i].p == victim) {
+            if (sync_first && blocks_[i].state == PENDING) blocks_[i].state = IDLE, blocks_[i].t_idle = now_seconds();
+            else if (!sync_first && blocks_[i].state == FREEING) blocks_.erase(blocks_.begin() + (long)i);
+            break;
+          }
+        idle_cv_.notify_all();
+        continue;
       }
       idle_cv_.notify_all();
+      if (any_pending) cv_.wait_for(lk, std::chrono::microseconds(200));  // events fire within a kernel's time
+      else if (any_idle) cv_.wait_for(lk, std::chrono::milliseconds(100));
+      else cv_.wait(lk, [&] {
+        if (stop_) return true;
+        for (const Block& b : blocks_)
+          if (b.state == PENDING || b.state == IDLE) return true;
+        return false;
+      });
     }
   }
   std::mutex mu_;
   std::condition_variable cv_, idle_cv_;
-  std::deque<Block> q_;
+  std::vector<Block> blocks_;
   std::thread th_;
-  int current_ordinal_ = -1;
-  size_t pending_ = 0;
   bool stop_ = false;
 };
-ScratchReaper g_scratch_reaper;
+ScratchPool g_scratch_pool;
 }  // namespace
 
-int scratch_acquire(void** p, size_t bytes) {
+int scratch_acquire(void** p, size_t bytes, hipStream_t stream) {
   if (!p || bytes == 0) return CPIR_ERR_INVALID_ARGUMENT;
   *p = nullptr;
-  hipError_t e = CPIR_HIP_MALLOC(p, bytes);
-  if (e == hipErrorOutOfMemory) {  // blocks still waiting to be freed may be what is missing: wait for them, once
-    (void)hipGetLastError();
-    int ordinal = 0;
-    if (hipGetDevice(&ordinal) == hipSuccess) g_scratch_reaper.drain(ordinal);
-    e = CPIR_HIP_MALLOC(p, bytes);
+  // The pool's bookkeeping is an event recorded behind the work and asked from the host: a stream that is being CAPTURED into a graph
+  // executes nothing now and its events cannot be asked -- and a replay of the graph would read a block that has long been handed to
+  // somebody else.  The entry points that need scratch (cpir_op_mat_x_mat, cpir_op_mat_x_packed, respond on a compacted server through
+  // kernels that cannot apply the slot map) are therefore not graph-capturable: refused here, before anything is enqueued.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+    set_last_hip_error(hipErrorStreamCaptureUnsupported, "this entry point allocates device scratch and cannot be captured into a graph", __FILE__, __LINE__);
+    return CPIR_ERR_INVALID_ARGUMENT;
   }
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    set_last_hip_error(e, "hipMalloc(scratch)", __FILE__, __LINE__);
-    *p = nullptr;
-    return e == hipErrorOutOfMemory ? CPIR_ERR_OUT_OF_DEVICE_MEMORY : CPIR_ERR_HIP;
-  }
-  return CPIR_OK;
+  (void)hipGetLastError();
+  int ordinal = 0;
+  if (hipGetDevice(&ordinal) != hipSuccess) return CPIR_ERR_HIP;
+  return g_scratch_pool.acquire(p, bytes, ordinal);
 }
 
 int scratch_release_after(void* p, hipStream_t stream) {
   if (!p) return CPIR_OK;
-  ScratchReaper::Block b;
-  b.p = p;
-  hipError_t e = hipGetDevice(&b.ordinal);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&b.done, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventRecord(b.done, stream);
-  if (e != hipSuccess) {  // no event to wait on: drain the stream and free now
-    set_last_hip_error(e, "scratch_release_after", __FILE__, __LINE__);
-    if (b.done) (void)hipEventDestroy(b.done);
-    (void)hipStreamSynchronize(stream);
-    (void)CPIR_HIP_FREE(p);
-    return CPIR_ERR_HIP;
-  }
-  g_scratch_reaper.push(b);
-  return CPIR_OK;
+  return g_scratch_pool.release_after(p, stream);
 }
 
-void scratch_drain(int ordinal) { g_scratch_reaper.drain(ordinal); }
+void scratch_drain(int ordinal) { g_scratch_pool.drain(ordinal); }
 
 void device_retain(Device* d) { d->refs.fetch_add(1); }
 void device_release(Device* d) {
@@ -804,7 +903,7 @@ int server_respond_on_device(const Server* srv, const uint32_t* q, uint64_t q_le
   }
   uint32_t* own = nullptr;
   if (!qc) {
-    CPIR_TRY(scratch_acquire(reinterpret_cast<void**>(&own), (size_t)batch * m.n_pad * 4));
+    CPIR_TRY(scratch_acquire(reinterpret_cast<void**>(&own), (size_t)batch * m.n_pad * 4, stream));
     qc = own;
   }
   int st = launch_gather_query(srv->dev, q, q_len, q_slot_offset, m, batch, qc, stream);
@@ -1111,9 +1210,14 @@ static int respond_in_round(Server* srv, RespondArena* a, uint32_t seat, const u
     a->staged++;
     srv->cv.notify_all();
     lk.unlock();
-    // the pass is a couple of hundred microseconds away and a sleeping thread takes tens of them to wake: look for its end for a while
+    // the pass is a couple of hundred microseconds away and a sleeping thread takes tens of them to wake: look for its end for a while --
+    // three times what one pass over the image takes (a round of four costs about two) + 100 us, 2 ms at most; a pass that is later than
+    // that (a void pass answered again, a device busy with somebody else's work) is slept for, so that a follower burns a core for no longer
+    // than the round can reasonably take (what the host path costs in cores)
     const double t0 = now_seconds();
-    while (__atomic_load_n(&a->rounds_done, __ATOMIC_ACQUIRE) == round_at_entry && now_seconds() - t0 < 2e-3) {
+    const double pass_seconds = (double)srv->phys.total_words * 4 / 6.8e12;
+    const double spin = 3 * pass_seconds + 100e-6 < 2e-3 ? 3 * pass_seconds + 100e-6 : 2e-3;
+    while (__atomic_load_n(&a->rounds_done, __ATOMIC_ACQUIRE) == round_at_entry && now_seconds() - t0 < spin) {
 #if defined(__x86_64__)
       __builtin_ia32_pause();
 #endif

@@ -237,7 +237,7 @@ static int pack_into_server(Device* dev, Server* srv, const uint32_t* D_dev, uin
       // (the other two packings) the kept rows are gathered into a temporary of (almost) D's size while D is still resident: where the
       // device has no room for that -- a database that fits beside its image but not twice -- the map is dropped and the whole matrix
       // packed as it is.  Compaction is an optimisation, never a reason for setup to fail.
-      const int as = scratch_acquire(reinterpret_cast<void**>(&Dc), (size_t)map->n_kept * L.num_cols * 4);
+      const int as = scratch_acquire(reinterpret_cast<void**>(&Dc), (size_t)map->n_kept * L.num_cols * 4, stream);
       if (as != CPIR_OK) {
         if (as != CPIR_ERR_OUT_OF_DEVICE_MEMORY) return as;
         Dc = nullptr;

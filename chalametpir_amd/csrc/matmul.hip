@@ -299,7 +299,7 @@ int launch_mat_x_mat(const Device* dev, const uint32_t* A, uint64_t lda, const u
   if (mfma_matmul_enabled() && mfma_matmul_applicable(A, lda, inner, cols, rhs_max_bits)) {
     // the matrix-core path (matmul_mfma.hip); its prepared right-hand side lives in a scratch block released behind the launch
     void* ws = nullptr;
-    CPIR_TRY(scratch_acquire(&ws, mfma_rhs_workspace_bytes(inner, cols, rows)));
+    CPIR_TRY(scratch_acquire(&ws, mfma_rhs_workspace_bytes(inner, cols, rows), stream));
     int st = launch_rhs_split(dev, D, ldd, inner, cols, ws, stream);
     if (st == CPIR_OK) st = launch_mat_x_mat_mfma(dev, A, lda, ws, inner, cols, M, ldm, rows, rows, accumulate, stream);
     const int st2 = scratch_release_after(ws, stream);

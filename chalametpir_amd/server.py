@@ -521,7 +521,9 @@ class Server:
         _check(self._lib.cpir_server_setup_timings(self._h, out))
         return dict(zip(self.SETUP_PHASES, [float(x) for x in out]))
 
-    HOST_PATH_COUNTS = ("calls", "alone_in_place", "alone_polled", "polled_given_up", "in_uploaded_rounds", "uploaded_rounds",
+    # (cpir_server_host_path_counts: "alone_polled" is the subset of "alone" answered by a launch that polled the copy of a pageable query;
+    # "polled_passes_given_up" counts void passes of lone launches AND of in-place rounds; calls == alone + in_uploaded_rounds + in_in_place_rounds)
+    HOST_PATH_COUNTS = ("calls", "alone", "alone_polled", "polled_passes_given_up", "in_uploaded_rounds", "uploaded_rounds",
                         "in_in_place_rounds", "in_place_rounds")
 
     def host_path_counts(self) -> dict:

@@ -141,7 +141,7 @@ int main(int argc, char** argv) {
     uint64_t served[CPIR_HOST_PATH_COUNT];
     CHECK(cpir_server_host_path_counts(g_srv, served));
     printf("], \"mismatches\": %d, \"served\": {\"calls\": %llu, \"alone\": %llu, \"in_uploaded_rounds\": %llu, \"uploaded_rounds\": %llu, "
-           "\"in_in_place_rounds\": %llu, \"in_place_rounds\": %llu, \"polled_given_up\": %llu}}\n",
+           "\"in_in_place_rounds\": %llu, \"in_place_rounds\": %llu, \"polled_passes_given_up\": %llu}}\n",
            g_bad, (unsigned long long)served[0], (unsigned long long)served[1], (unsigned long long)served[4], (unsigned long long)served[5],
            (unsigned long long)served[6], (unsigned long long)served[7], (unsigned long long)served[3]);
     cpir_server_release(g_srv);

@@ -403,8 +403,11 @@ int cpir_server_setup_timings(const cpir_server* srv, double out[CPIR_SETUP_TIMI
 
 /* How the host callers of cpir_server_respond have been served by this handle so far (a group handle: summed over its shards, each of
  * which answers -- and counts -- every query):
- *   [0] calls answered   [1] ... alone, the query read in place over the host link (no upload)
- *   [2] ... alone, by one launch polling the copy of a pageable query   [3] such launches that gave up waiting (answered again)
+ *   [0] calls answered   [1] ... alone (no upload: the query read in place over the host link -- from the caller's page-locked buffer,
+ *       or from the server's pinned block while it is copied in; [2] is the subset of [1] answered that second way)
+ *   [2] of [1]: by one launch polling the copy of a pageable query
+ *   [3] polled passes that gave up waiting for a copy and were answered again -- lone launches of [2] AND in-place rounds of [7] with a
+ *       pageable seat (so [3] may exceed what [2] alone would allow)
  *   [4] calls answered in uploaded rounds (concurrent callers: staged, uploaded, one fused pass per round)   [5] uploaded rounds
  *   [6] calls answered in in-place rounds (a few concurrent callers: one pass reads their queries over the link, respond.inplace_seats)
  *   [7] in-place rounds */

@@ -26,6 +26,7 @@ enum hipError_t {
   hipErrorPeerAccessUnsupported = 217,
   hipErrorNotReady = 600,
   hipErrorPeerAccessAlreadyEnabled = 704,
+  hipErrorStreamCaptureUnsupported = 900,
   hipErrorUnknown = 999,
 };
 
@@ -93,6 +94,12 @@ hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned flags, int prior
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t ev, unsigned flags);
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive = 1 };
+inline hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* st) {
+  *st = hipStreamCaptureStatusNone;
+  return hipSuccess;
+}
+hipError_t hipDeviceSynchronize();
 hipError_t hipEventCreateWithFlags(hipEvent_t* ev, unsigned flags);
 hipError_t hipEventDestroy(hipEvent_t ev);
 hipError_t hipEventRecord(hipEvent_t ev, hipStream_t s);

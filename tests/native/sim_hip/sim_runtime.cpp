@@ -232,6 +232,10 @@ hipError_t hipSetDevice(int ordinal) {
   return hipSuccess;
 }
 hipError_t hipGetLastError() { return hipSuccess; }
+hipError_t hipDeviceSynchronize() {
+  device_synchronize();
+  return hipSuccess;
+}
 const char* hipGetErrorString(hipError_t) { return "simulated"; }
 hipError_t hipDeviceCanAccessPeer(int* can, int, int) {
   *can = 1;

@@ -347,7 +347,7 @@ def test_host_queries_lone_and_concurrent(orc, device):
             [t.join() for t in ts]
             assert not errors, errors[:3]
         after = srv.host_path_counts()
-        assert after["calls"] - before["calls"] == 90 and after["polled_given_up"] == before["polled_given_up"], (before, after)
+        assert after["calls"] - before["calls"] == 90 and after["polled_passes_given_up"] == before["polled_passes_given_up"], (before, after)
         if srv.layout.packing == 2:  # planar
             assert after["in_place_rounds"] > before["in_place_rounds"], (before, after)
         else:

@@ -123,7 +123,7 @@ def test_group_respond_is_reentrant(orc, device, group_devices):
     # every shard is an ordinary server asked through its own respond: each answered -- and counted -- every one of the 144 queries
     counts = srv.host_path_counts()
     assert counts["calls"] == 4 * 144, counts
-    assert counts["calls"] == counts["alone_in_place"] + counts["in_uploaded_rounds"] + counts["in_in_place_rounds"], counts
+    assert counts["calls"] == counts["alone"] + counts["in_uploaded_rounds"] + counts["in_in_place_rounds"], counts
 
 
 def test_device_pointer_entry_points_take_a_group_on_the_default_stream(orc, device, group_devices):

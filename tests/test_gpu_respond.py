@@ -432,12 +432,12 @@ def test_a_few_concurrent_callers_share_one_pass_that_reads_their_queries_in_pla
                     calls += 10 * len(crew)
                 counts = srv.host_path_counts()
                 assert counts["calls"] == calls, counts
-                assert counts["calls"] == counts["alone_in_place"] + counts["in_uploaded_rounds"] + counts["in_in_place_rounds"], counts
+                assert counts["calls"] == counts["alone"] + counts["in_uploaded_rounds"] + counts["in_in_place_rounds"], counts
                 if seats == 0 or not planar:
                     assert counts["in_place_rounds"] == 0 and counts["in_in_place_rounds"] == 0, counts
                 else:
                     assert counts["in_place_rounds"] > 0 and counts["in_in_place_rounds"] <= seats * counts["in_place_rounds"], counts
-                    assert counts["polled_given_up"] == 0, counts
+                    assert counts["polled_passes_given_up"] == 0, counts
             whole.close()
             shard.close()
         # a query long enough for the pass to catch up with its copy (16 MB: a millisecond of one thread's memcpy), and a 1 us limit
@@ -466,7 +466,7 @@ def test_a_few_concurrent_callers_share_one_pass_that_reads_their_queries_in_pla
                 t.join()
             counts = srv.host_path_counts()
             assert not bad, (bad, counts)
-            assert counts["in_place_rounds"] > 0 and counts["polled_given_up"] >= 1, counts  # (three in a row: no more polling)
+            assert counts["in_place_rounds"] > 0 and counts["polled_passes_given_up"] >= 1, counts  # (three in a row: no more polling)
             srv.close()
     finally:
         cp.tuning_set("respond.inplace_seats", 4)

@@ -168,3 +168,50 @@ def test_mat_x_packed_beyond_the_pipelined_kernels_reach_is_refused_up_front(dev
         a = synth_u32_at(np.uint64(r) * np.uint64(N) + n, 0xA0).astype(np.uint64)
         d = synth_u32_at(n * np.uint64(C) + np.uint64(c), 0xD0, (1 << b) - 1).astype(np.uint64)
         assert int((a * d).sum(dtype=np.uint64) & np.uint64(0xFFFFFFFF)) == int(got[1][r, c])
+
+
+def test_scratch_blocks_are_reused_only_behind_their_events_and_refused_under_capture(orc, device):
+    """The scratch pool (host_respond.hip): cpir_op_mat_x_mat on the matrix cores takes its workspace from it.  (1) Products enqueued back to
+    back WITHOUT synchronising -- every one would find the block of the one before still waiting for its event -- and then again after a
+    pause (the block is idle: reused) all equal the oracle's product; (2) the same entry point on a stream that is being CAPTURED into a
+    graph is refused with CPIR_ERR_INVALID_ARGUMENT before anything is enqueued -- its scratch bookkeeping cannot be replayed -- and the
+    capture itself stays valid (it ends in an empty graph)."""
+    import ctypes
+
+    import torch
+
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(61)
+    rows, N, C, b = 70, 4096 + 64, 48, 9
+    A = rng.integers(0, 1 << 32, size=(rows, N), dtype=np.uint64).astype(np.uint32)
+    D = random_db_matrix(rng, N, C, b)
+    want = orc.mul(A, D)
+    stream = torch.cuda.Stream()
+    Ad, Dd = torch.from_numpy(A.view(np.int32)).cuda(), torch.from_numpy(D.view(np.int32)).cuda()
+    outs = [torch.empty((rows, C), dtype=torch.int32, device="cuda") for _ in range(6)]
+    torch.cuda.synchronize()
+    for rnd in range(3):
+        for M in outs:
+            device.mat_x_mat(Ad, Dd, M, rows, N, C, rhs_max_bits=16, stream=stream)
+        stream.synchronize()
+        for M in outs:
+            assert np.array_equal(M.cpu().numpy().view(np.uint32), want)
+            M.zero_()
+        torch.cuda.synchronize()
+        time.sleep(0.05 if rnd == 0 else 0.7)  # (second pause: beyond the pool's idle time -- the block is freed and allocated again)
+    hip = ctypes.CDLL("libamdhip64.so")
+    s_ptr = ctypes.c_void_p(stream.cuda_stream)
+    assert hip.hipStreamBeginCapture(s_ptr, 2) == 0  # hipStreamCaptureModeRelaxed
+    try:
+        with pytest.raises(cp.ChalametPIRError) as ei:
+            device.mat_x_mat(Ad, Dd, outs[0], rows, N, C, rhs_max_bits=16, stream=stream)
+        assert ei.value.code == 68  # CPIR_ERR_INVALID_ARGUMENT
+    finally:
+        graph = ctypes.c_void_p()
+        assert hip.hipStreamEndCapture(s_ptr, ctypes.byref(graph)) == 0
+        if graph.value:
+            hip.hipGraphDestroy(graph)
+    device.mat_x_mat(Ad, Dd, outs[0], rows, N, C, rhs_max_bits=16, stream=stream)  # (and the stream works as before)
+    stream.synchronize()
+    assert np.array_equal(outs[0].cpu().numpy().view(np.uint32), want)
