@@ -4,11 +4,11 @@
 set -e
 cd "$(dirname "$0")/.."
 T=$1
-for v in "" _cfg5; do
+for v in "" _cfg3 _cfg4 _cfg5; do
   P=gpurun_out/prof_$T$v
   [ -d "$P" ] || continue
   cp $P/trace/trace_kernel_stats.csv profiles/${T}${v}_kernel_stats.csv
-  cp $P/setup_trace/setup_kernel_stats.csv profiles/${T}${v}_setup_kernel_stats.csv
+  [ -f $P/setup_trace/setup_kernel_stats.csv ] && cp $P/setup_trace/setup_kernel_stats.csv profiles/${T}${v}_setup_kernel_stats.csv
   [ -f $P/full_trace/full_kernel_stats.csv ] && cp $P/full_trace/full_kernel_stats.csv profiles/${T}${v}_all_sections_kernel_stats.csv
   cp $P/summary.txt profiles/${T}${v}_rocprofv3_summary.txt
   cp $P/summary.json profiles/${T}${v}_rocprofv3_summary.json

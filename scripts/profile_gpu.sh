@@ -16,14 +16,16 @@ cd /tmp && export TMPDIR=/tmp
 # dispatch of the kernel is one step of the timed loop (32 passes), and its average duration is the bench line's `roofline.launch_us`
 BENCH="$ROOT/bench.py --headline-only --no-setup --no-setup-kv --no-cpu-baseline --no-host-path --no-read-ceiling --no-live-traffic --steps 20 --warmup 5 $*"
 # ... and the default run's other sections (fused batches, lone launches, the real database, the host path) in a trace of their own
-FULL_BENCH="$ROOT/bench.py --no-setup --no-cpu-baseline --no-read-ceiling --no-live-traffic --steps 10 --warmup 2 $*"
-SETUP_BENCH="$ROOT/bench.py --no-cpu-baseline --no-host-path --no-read-ceiling --no-live-traffic --steps 2 --warmup 1 $*"
+FULL_BENCH="$ROOT/bench.py --no-setup --no-cpu-baseline --no-read-ceiling --no-live-traffic --other-configs none --steps 10 --warmup 2 $*"
+SETUP_BENCH="$ROOT/bench.py --no-cpu-baseline --no-host-path --no-read-ceiling --no-live-traffic --other-configs none --steps 2 --warmup 1 $*"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- python3 $BENCH > "$OUT/trace_bench.json" 2> "$OUT/trace.err"
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o fetch -- python3 $BENCH > "$OUT/fetch_bench.json" 2> "$OUT/fetch.err"
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o write -- python3 $BENCH > "$OUT/write_bench.json" 2> "$OUT/write.err"
+if [ "${TRAFFIC_ONLY:-0}" != "1" ]; then  # (TRAFFIC_ONLY=1: the headline loop's kernel trace and the two counter passes, nothing else -- the other configs' traffic records)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/full_trace" -o full -- python3 $FULL_BENCH > "$OUT/full_bench.json" 2> "$OUT/full.err"
 # the offline kernels (hint matmul, transpose+pack) inside one Server::setup + the setup_roofline timing of each kernel alone
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/setup_trace" -o setup -- python3 $SETUP_BENCH > "$OUT/setup_bench.json" 2> "$OUT/setup.err"
+fi
 cd "$ROOT" && python3 scripts/summarize_rocprof.py "$OUT" "$TAG" "$HEAD" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
 # keep the merge-back small: drop the raw per-dispatch traces except the stats/counter CSVs
