@@ -327,7 +327,7 @@ def main() -> int:
             ceil = read_ceiling(min(max(4 * shard_words, 256 << 20), 4 << 30))
             if ceil:
                 roof["read_ceiling_GBps"] = ceil["read_ceiling_GBps"]
-                roof["frac_vs_read_ceiling"] = round(roof["moved_GBps"] / ceil["read_ceiling_GBps"], 4)
+                roof["frac_vs_read_ceiling"] = None if roof["on_die"] else round(roof["moved_GBps"] / ceil["read_ceiling_GBps"], 4)
                 roof["read_ceiling_note"] = f"{ceil['kernel']}; {ceil['buffer_bytes'] / 1e9:.2f} GB read once per launch, best of several launch shapes"
 
     # (run AFTER every timed section of this process: a rocprofv3 counter pass leaves the device at the profiling power state for a
@@ -714,7 +714,7 @@ def respond_roofline(C, cf, b, shard_slots, layout, shard_words, passes_per_laun
     time -- is kept beside it as `achieved_algorithmic_equiv` / `frac_algorithmic_equiv`: the planar image is 0.848 x the reference packing at
     b = 9, so that figure says how fast a kernel streaming the REFERENCE's bytes would have to be, not what moves.  Where the bytes of a
     launch do not come from HBM at all (working set of a pass inside the 256 MiB Infinity Cache, or passes walked in the interleaved
-    order, which share database bytes on die) `frac` is null: there is no HBM rate to state."""
+    order, which share database bytes on die) every `frac*` is null: there is no HBM rate to state (`achieved` still says what the kernel consumes)."""
     W_shard = -(-shard_slots // cf) if shard_slots > 0 else 0
     alg_q = 4 * C * W_shard + 4 * shard_slots + 4 * C  # SURVEY.md 8(d), this rank's shard
     moved_q = 4 * shard_words + 4 * shard_slots + 4 * C
@@ -743,11 +743,12 @@ def respond_roofline(C, cf, b, shard_slots, layout, shard_words, passes_per_laun
                     f"{packing} ({layout.fields_per_word} fields per {'u64' if int(layout.packing) == 1 else 'u32'})"),
         "moved_bytes_per_launch": moved,
         "moved_GBps": round(rate(moved), 1),
-        "frac_moved": round(rate(moved) / HBM_PEAK_GBPS, 4),  # = frac where frac is stated
+        "frac_moved": None if on_die else round(rate(moved) / HBM_PEAK_GBPS, 4),  # = frac (kept for readers of earlier rounds' lines)
         # algorithmic bytes of the reference packing over the same launch time (NOT a rate of bytes that move)
         "bytes_per_launch": alg,
         "achieved_algorithmic_equiv": round(rate(alg), 1),
-        "frac_algorithmic_equiv": round(rate(alg) / HBM_PEAK_GBPS, 4),
+        "frac_algorithmic_equiv": None if on_die else round(rate(alg) / HBM_PEAK_GBPS, 4),
+        "on_die": on_die,  # the launch's bytes are served from L2 / Infinity Cache: `achieved` is what the kernel consumes, no fraction of the HBM roof is stated
         "moved_over_algorithmic": round(moved / alg, 4) if alg else None,
         "traffic_over_algorithmic": None,
         "mall_resident": mall,
@@ -1976,12 +1977,14 @@ def setup_kv_and_real_db(cp, device, torch, args, n_keys, arity, value_bytes, q_
             "resident_bytes": resident,
             # the physical figure, a rate: the compact image + the slot map and the query words of the kept slots (gathered inside the kernel)
             # + r, over the time, against 8 TB/s
-            "frac": round((resident + 8 * served + 4 * C) / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
-            "frac_moved": round((resident + 8 * served + 4 * C) / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+            "frac": None if resident <= (256 << 20) else round((resident + 8 * served + 4 * C) / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+            "frac_moved": None if resident <= (256 << 20) else round((resident + 8 * served + 4 * C) / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+            "moved_GBps": round((resident + 8 * served + 4 * C) / (us * 1e-6) / 1e9, 1),
+            "mall_resident": bool(resident <= (256 << 20)),  # (then the bytes are served on die and no fraction of the HBM roof is stated)
             # NOT a bandwidth: the algorithmic bytes of ALL N slots in the reference packing over the time of a kernel that
             # streams only the kept ones in a tighter packing -- it may exceed 1.0; how fast a kernel streaming the reference's bytes would
             # have to be to answer as quickly
-            "frac_algorithmic_equiv": round(full_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+            "frac_algorithmic_equiv": None if resident <= (256 << 20) else round(full_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
             "note": "the headline's loop (uniform random queries -- what an LWE query is to the server --, one query per pass, "
                     f"{qps_step} passes a launch) on the server that Server::setup built from the key-value database; `frac` (= `frac_moved`) is "
                     "bytes through HBM over time",

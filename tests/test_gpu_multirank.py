@@ -74,9 +74,10 @@ def test_driver_command_rehearsal_three_ranks():
     assert out["server_setup_wall_sec"] > 0 and "server_setup_timed_out" not in out and out["hint_checksum"] > 0
     # like for like: the shards of this Infinity-Cache-sized database run their passes interleaved; the line also carries the same steps in
     # slice order (already in the line printed first) and rank 0's single-GPU run of the whole database, and divides the two
-    assert out["roofline"]["pass_order"] == "interleaved" and first["value_slice_order"] > 0 and first["slice_order"]["frac_algorithmic_equiv"] > 0
+    assert out["roofline"]["pass_order"] == "interleaved" and first["value_slice_order"] > 0 and first["slice_order"]["us_per_query_per_gpu"] > 0
     # Infinity-Cache-sized shards: there is no HBM rate to state, neither as dispatched nor in slice order
     assert out["roofline"]["frac"] is None and first["slice_order"]["frac"] is None and first["slice_order"]["mall_resident"] is True
+    assert first["slice_order"]["frac_algorithmic_equiv"] is None and out["roofline"]["achieved"] > 0
     ref = out["single_gpu_reference"]
     assert ref["queries_per_sec"] > 0 and ref["pass_order"] == "slice" and ref["queries_per_step"] == 32
     assert abs(out["scaling_like_for_like"] - out["value_slice_order"] / ref["queries_per_sec"]) < 2e-3
@@ -128,9 +129,8 @@ def test_bench_json_contract():
     assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s") and roof["peak"] == 8000.0
     # `frac` is a RATE of bytes that really move through HBM; at this Infinity-Cache-sized database there is none to state (null), the
     # kernel's consumption rate stays in `achieved` / `frac_moved` and SURVEY 8(d)'s algorithmic-bytes figure in `frac_algorithmic_equiv`
-    assert roof["frac"] is None and roof["mall_resident"] is True and "null" in roof["frac_is"] and "traffic" in roof
-    assert abs(roof["frac_moved"] - roof["achieved"] / roof["peak"]) < 1e-3
-    assert abs(roof["frac_algorithmic_equiv"] - roof["achieved_algorithmic_equiv"] / roof["peak"]) < 1e-3
+    assert roof["frac"] is None and roof["mall_resident"] is True and roof["on_die"] is True and "null" in roof["frac_is"] and "traffic" in roof
+    assert roof["frac_moved"] is None and roof["frac_algorithmic_equiv"] is None and roof["achieved"] > 0 and roof["achieved_algorithmic_equiv"] >= roof["achieved"]
     assert 0.5 < roof["moved_over_algorithmic"] <= 1.0 and roof["traffic_over_algorithmic"] > 0
     # HBM traffic per launch is MEASURED in the run (two child runs of the timed loop under rocprofv3 --pmc): this Infinity-Cache-sized
     # database is walked in the interleaved order (its 32 passes share one stream of it on die), so anything between 1/32 of the layout
@@ -138,8 +138,7 @@ def test_bench_json_contract():
     assert isinstance(roof["traffic"], int) and roof["traffic"] > 0 and "measured in this run" in roof["traffic_source"]
     assert 0.01 < roof["traffic_over_moved_bytes"] < 1.2 and roof["pass_order"] == "interleaved"
     # the bytes really moved (the resident layout is tighter than the reference packing), against spec and against a live read-only probe
-    assert abs(roof["frac_moved"] - roof["moved_GBps"] / roof["peak"]) < 1e-3 and roof["frac_moved"] <= roof["frac_algorithmic_equiv"] + 1e-3
-    assert roof["read_ceiling_GBps"] > 1000 and abs(roof["frac_vs_read_ceiling"] - roof["moved_GBps"] / roof["read_ceiling_GBps"]) < 1e-3
+    assert roof["moved_GBps"] == roof["achieved"] and roof["read_ceiling_GBps"] > 1000 and roof["frac_vs_read_ceiling"] is None
     assert d["ranks"] == 1 and d["backend"] is None
     assert abs(d["value"] - d["config"]["queries_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
     cpu = d["cpu_baseline"]
@@ -219,7 +218,7 @@ def test_default_line_carries_the_other_configs_and_the_cpu_figure_of_the_cpu_co
         assert "error" not in sec, sec
         assert sec["value"] > 0 and sec["launch_us"] > 0 and sec["steps"] == 3 and sec["passes_per_launch"] == 32 and sec["pass_order"] == "slice"
         assert sec["responses_bit_exact_vs_64bit_sums"] is True and sec["check"]["unit_queries_ok"] and sec["check"]["dense_and_all_ones_ok"]
-        assert sec["frac"] is None and sec["mall_resident"] is True and 0 < sec["frac_moved"]  # (cache-sized stand-ins: no HBM rate)
+        assert sec["frac"] is None and sec["frac_moved"] is None and sec["mall_resident"] is True and sec["moved_GBps_per_gpu"] > 0  # (cache-sized stand-ins: no HBM rate)
         assert abs(sec["value"] - sec["queries_per_step"] / (sec["ms_per_step"] * 1e-3)) / sec["value"] < 0.01
     small = d["cpu_baseline_cfg1"]
     assert small["gpu_results_bit_exact"] is True and small["queries_compared"] == 32 and small["value"] > 0 and "cfg1" in small["workload"]
@@ -249,7 +248,7 @@ def test_multirank_line_carries_baselines_multi_gpu_configs_and_the_group_handle
         assert sec["multirank_bit_exact"] is True and sec["ranks_seen"] == [0, 1, 2] and sum(sec["check"]["shard_slots"]) > 0
         ref = sec["single_gpu_reference"]
         assert ref["queries_per_sec"] > 0 and abs(sec["scaling_like_for_like"] - sec["value"] / ref["queries_per_sec"]) < 2e-3
-        assert sec["frac_moved"] > 0 and sec["launch_us"] > 0
+        assert sec["moved_GBps_per_gpu"] > 0 and sec["launch_us"] > 0
     grp = out["respond_host_path_group"]
     assert "error" not in grp, grp
     assert len(grp["shards"]) == 3 and grp["responses_equal_single_device"] is True and grp["device_queries_equal_single_device"] is True
