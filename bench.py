@@ -19,9 +19,14 @@ sums, after the timed region; on by default).
 `roofline.traffic` (HBM bytes per launch from the PMC counters) is measured in the run itself: the timed loop alone, twice, as a child
 process under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (live_traffic() below).
 
-Rank 0 prints ONE JSON line -- in a multi-rank run with the server_setup extra, that line twice: first as soon as the timed respond
-region and its reduction are done ("server_setup_pending": true), then again enriched with the sharded setup's timing, which runs
-under a deadline (--setup-deadline) so that an optional extra can never cost the headline; take the LAST line.  `roofline` describes the respond kernel against the HBM roof (8 TB/s,
+Rank 0 prints ONE JSON line -- in a multi-rank run that line several times: first as soon as the timed respond region and its reduction are
+done (with "..._pending": true for what is still to come), then again after every stage behind it -- rank 0's single-GPU reference, BASELINE.json's
+own multi-GPU configs (cfg4, cfg5) sharded over the ranks (`baseline_multi_gpu_configs`), the sharded setup, and, once the process group is gone,
+the in-process GROUP handle over all visible devices timed in a child of rank 0 (`respond_host_path_group`: the multi-GPU path a drop-in
+caller gets) -- each stage under a deadline of its own, so that an optional extra can never cost the headline; take the LAST line.
+The default (N = 1, cfg2) line also carries `other_configs` (cfg3 / cfg4 / cfg5: 5 steps x 32 passes each, responses checked against exact
+64-bit sums) and `cpu_baseline_cfg1`.  `roofline.frac` is a RATE (bytes really moved / time / 8 TB/s; null where the bytes are served on die);
+SURVEY.md 8(d)'s algorithmic-bytes figure is `roofline.frac_algorithmic_equiv`.  `roofline` describes the respond kernel against the HBM roof (8 TB/s,
 /opt/skills/guides/MI355X_MICROARCH.md); `cpu_baseline` is the test oracle's restatement of the reference CPU path
 (oracle/, kind "port": the Rust reference cannot be built in this image) timed on this box's host cores on the same
 database and queries, and it doubles as a full-size bit-exact parity check of the GPU results.
@@ -221,6 +226,13 @@ def main() -> int:
         sweep(cp, torch, run_step, qps_step)
 
     elapsed, kernel_region_ms = timed_region(args.warmup, args.steps)
+    # the contract's figure is THAT region (W warm-up steps, exactly K steps); two more regions of K steps right behind it say how much one such
+    # sample moves on this box (`value_samples`: the driver's 20 steps are 0.12 s of device time)
+    repeats = []
+    if world == 1 and not args.headline_only and args.shard_of <= 1:
+        for _ in range(2):
+            e2, _ms = timed_region(0, args.steps)
+            repeats.append(args.steps * qps_step / e2)
 
     n_queries = args.steps * qps_step
     qps = n_queries / elapsed
@@ -266,6 +278,10 @@ def main() -> int:
         "roofline": roof,
         "pack_seconds": round(pack_seconds, 3),
     }
+    if repeats:
+        samples = [qps] + repeats
+        result["value_samples"] = {"queries_per_sec": [round(x, 2) for x in samples], "min": round(min(samples), 2), "median": round(sorted(samples)[1], 2),
+                                   "max": round(max(samples), 2), "note": "`value` is the first: the contract's timed region; the other two are the same K steps again, no warm-up between"}
     if world > 1 and os.environ.get("CPIR_BENCH_SHARE_DEVICE") == "1":
         # the one-GPU rehearsal hook: every rank on GPU 0, gloo as the collective -- plumbing only, no figure of this line is a measurement
         result["rehearsal_ranks_share_one_device"] = True
@@ -591,6 +607,9 @@ def main() -> int:
         with stage_lock:
             stage["label"], stage["deadline"] = label, time.monotonic() + seconds
         try:
+            hang = os.environ.get("CPIR_BENCH_TEST_HANG_STAGE")  # test hook: this rank never comes out of the named stage (tests/test_gpu_multirank.py)
+            if hang and label.startswith(hang):
+                time.sleep(1e6)
             return fn()
         except Exception as exc:  # noqa: BLE001
             log(f"rank {rank}: stage '{label}' failed: {exc!r}")

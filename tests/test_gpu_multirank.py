@@ -141,6 +141,8 @@ def test_bench_json_contract():
     assert roof["moved_GBps"] == roof["achieved"] and roof["read_ceiling_GBps"] > 1000 and roof["frac_vs_read_ceiling"] is None
     assert d["ranks"] == 1 and d["backend"] is None
     assert abs(d["value"] - d["config"]["queries_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
+    vs = d["value_samples"]  # the contract's region + the same K steps twice more: how much one sample moves
+    assert vs["queries_per_sec"][0] == d["value"] and len(vs["queries_per_sec"]) == 3 and vs["min"] <= vs["median"] <= vs["max"]
     cpu = d["cpu_baseline"]
     assert cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1 and cpu["value"] > 0 and isinstance(cpu["sample"], str)
     assert cpu["gpu_results_bit_exact"] is True and cpu["queries_compared"] == 32
@@ -254,3 +256,19 @@ def test_multirank_line_carries_baselines_multi_gpu_configs_and_the_group_handle
     assert len(grp["shards"]) == 3 and grp["responses_equal_single_device"] is True and grp["device_queries_equal_single_device"] is True
     assert grp["one_caller_us_per_query"] > 0 and grp["eight_callers_queries_per_sec"] > 0 and grp["device_queries_us_per_query"] > 0
     assert out["value"] == first["value"] and out["multirank_bit_exact"] is True and out["single_gpu_reference"]["queries_per_sec"] > 0
+
+
+def test_a_stage_that_hangs_ends_the_run_with_a_line_that_says_which():
+    """every stage behind the headline has a deadline of its own: ranks that never come out of `baseline_multi_gpu_configs` (a collective
+    that does not come back) end the run with exit code 3, and the LAST line names the stage and still carries the headline's figures"""
+    env = dict(os.environ, CPIR_BENCH_BACKEND="gloo", CPIR_BENCH_SHARE_DEVICE="1", OMP_NUM_THREADS="4", CPIR_BENCH_TEST_HANG_STAGE="baseline_multi_gpu_configs")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "tiny", "--no-setup",
+           "--other-configs", "tiny", "--other-deadline", "5", "--group-after-ranks", "never"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0, p.stdout[-2000:]
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert lines[0]["baseline_multi_gpu_configs_pending"] is True and lines[0]["value"] > 0
+    assert lines[-1]["stage_timed_out"].startswith("baseline_multi_gpu_configs") and lines[-1]["value"] == lines[0]["value"]
+    assert lines[-1]["multirank_bit_exact"] is True and "single_gpu_reference" in lines[-1]  # what was done before the hang is in the line
