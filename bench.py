@@ -1408,8 +1408,76 @@ def group_child(cp, torch, device, args):
     torch.cuda.synchronize()
     n_vis = torch.cuda.device_count()
     out = group_host_path_timing(cp, torch, device, single, q_pool, N, C, b, mask, args.group_shards, n_vis, stream)
+    single.close()
+    del single, q_pool
+    torch.cuda.empty_cache()
+    if n_keys * (32 + value_bytes) <= (2 << 30):
+        # ... and the group handle exactly as the drop-in builds it: from the KEY-VALUE database (cpir_server_setup_kv_multi)
+        try:
+            out["from_kv_database"] = group_kv_timing(cp, device, n_keys, arity, value_bytes, args.group_shards, n_vis)
+        except Exception as exc:  # noqa: BLE001
+            out["from_kv_database"] = {"error": repr(exc)}
     print(json.dumps(out), flush=True)
     return 0
+
+
+def group_kv_timing(cp, device0, n_keys, arity, value_bytes, shards, n_vis):
+    """`Server::setup::<ARITY>(seed, kv database)` over SEVERAL devices behind one handle -- cpir_server_setup_kv_multi, the call
+    rust/server_hip.rs makes when CHALAMET_HIP_DEVICES names more than one -- next to the same setup on one device with the same filter
+    seeds: the same filter parameters, the same hint, the same responses; then one host caller's latency and eight callers' throughput on
+    the group (every shard keeps only its slots that hold something: the real database's slot maps, shard by shard)."""
+    import threading
+
+    keys, key_off, values, val_off = synthetic_kv_database(n_keys, value_bytes)
+    seeds = np.random.default_rng(0xF117).integers(0, 256, size=32 * 100, dtype=np.uint8).tobytes()
+    devs = [device0 if (i % n_vis) == device0.ordinal else cp.Device(i % n_vis) for i in range(shards)]
+    t0 = time.perf_counter()
+    grp, hint_g, filt_g = cp.Server.setup_flat(SEED_MU, keys, key_off, values, val_off, arity, devices=devs, filter_seed_material=seeds)
+    wall_g = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    one, hint_1, filt_1 = cp.Server.setup_flat(SEED_MU, keys, key_off, values, val_off, arity, device=device0, filter_seed_material=seeds)
+    wall_1 = time.perf_counter() - t0
+    del keys, values
+    N = grp.decompressed_num_cols
+    rng = np.random.default_rng(0x9E)
+    qs = [rng.integers(0, 1 << 32, size=N, dtype=np.uint64).astype(np.uint32) for _ in range(8)]
+    same = all(bool(np.array_equal(grp.respond_array(q), one.respond_array(q))) for q in qs[:3])
+    for q in qs[:4]:
+        grp.respond_array(q)
+    n1 = 32
+    t0 = time.perf_counter()
+    for i in range(n1):
+        grp.respond_array(qs[i % len(qs)])
+    lat = (time.perf_counter() - t0) / n1
+    threads, per = 8, 16
+
+    def work(k):
+        for i in range(per):
+            grp.respond_array(qs[(k + i) % len(qs)])
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
+    t0 = time.perf_counter()
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    thr = threads * per / (time.perf_counter() - t0)
+    served, of = grp.slots_served()
+    out = {
+        "entry_point": "cpir_server_setup_kv_multi",
+        "shards": grp.group_shards(),
+        "server_setup_kv_multi_wall_sec": round(wall_g, 3),
+        "server_setup_kv_single_device_wall_sec": round(wall_1, 3),
+        "same_filter_params_as_single_device": filt_g == filt_1,
+        "same_hint_as_single_device": hint_g == hint_1,
+        "responses_equal_single_device": same,
+        "slots_served": served, "slots_of": of,
+        "one_caller_us_per_query": round(lat * 1e6, 1),
+        "eight_callers_queries_per_sec": round(thr, 1),
+        "note": "the multi-GPU path of the Rust drop-in, end to end on host bytes: Server::setup from the key-value database split over the listed "
+                "devices, Server::respond scattering each query's slots over every device's own host link, partial responses summed on the host",
+    }
+    grp.close()
+    one.close()
+    return out
 
 
 def group_host_path_timing(cp, torch, device0, single, q_pool, N, C, b, mask, shards, n_vis, stream):

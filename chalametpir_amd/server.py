@@ -368,17 +368,18 @@ class Server:
 
     @staticmethod
     def setup_flat(seed_mu: bytes, keys, key_off, values, val_off, arity: int = 3, *, device: Optional[Device] = None,
-                   filter_seed_material: Optional[bytes] = None,
+                   devices: Optional[Sequence[Device]] = None, filter_seed_material: Optional[bytes] = None,
                    max_attempts: int = SERVER_SETUP_MAX_ATTEMPT_COUNT) -> Tuple["Server", bytes, bytes]:
         """Server::setup on a database already flattened into the cpir_kv_db arrays (what the Rust shim hands over):
-        keys / values are u8 buffers, key_off / val_off hold num_pairs + 1 offsets.  Keys must be distinct."""
+        keys / values are u8 buffers, key_off / val_off hold num_pairs + 1 offsets.  Keys must be distinct.
+        `devices`: the group handle (cpir_server_setup_kv_multi: what rust/server_hip.rs calls when CHALAMET_HIP_DEVICES names several)."""
         lib = _native.load()
         if arity not in (3, 4):
             raise ChalametPIRError(17, lib.cpir_strerror(17).decode())
         flat = _FlatKvDb(arrays=(keys, key_off, values, val_off))
         if flat.n == 0:
             raise ChalametPIRError(8, lib.cpir_strerror(8).decode())
-        return Server._setup_flat(seed_mu, flat, arity, device, filter_seed_material, max_attempts)
+        return Server._setup_flat(seed_mu, flat, arity, device, filter_seed_material, max_attempts, devices)
 
     @staticmethod
     def _setup_flat(seed_mu, flat, arity, device, filter_seed_material, max_attempts, devices=None):

@@ -255,6 +255,12 @@ def test_multirank_line_carries_baselines_multi_gpu_configs_and_the_group_handle
     assert "error" not in grp, grp
     assert len(grp["shards"]) == 3 and grp["responses_equal_single_device"] is True and grp["device_queries_equal_single_device"] is True
     assert grp["one_caller_us_per_query"] > 0 and grp["eight_callers_queries_per_sec"] > 0 and grp["device_queries_us_per_query"] > 0
+    # ... and the group exactly as the Rust drop-in builds it: Server::setup from the KEY-VALUE database over the devices (cpir_server_setup_kv_multi)
+    kv = grp["from_kv_database"]
+    assert "error" not in kv, kv
+    assert kv["entry_point"] == "cpir_server_setup_kv_multi" and len(kv["shards"]) == 3 and kv["server_setup_kv_multi_wall_sec"] > 0
+    assert kv["same_filter_params_as_single_device"] and kv["same_hint_as_single_device"] and kv["responses_equal_single_device"] is True
+    assert kv["slots_served"] == 65536 and kv["slots_of"] == 77824 and kv["one_caller_us_per_query"] > 0 and kv["eight_callers_queries_per_sec"] > 0
     assert out["value"] == first["value"] and out["multirank_bit_exact"] is True and out["single_gpu_reference"]["queries_per_sec"] > 0
 
 
