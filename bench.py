@@ -509,7 +509,11 @@ def main() -> int:
                 torch.cuda.empty_cache()
     if rank == 0 and world == 1:
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(sharded.local, q_pool, r_step, N, C, b, full_bytes, args.cpu_seconds, torch, stream, args.config)
+            try:
+                result["cpu_baseline"] = cpu_baseline(sharded.local, q_pool, r_step, N, C, b, full_bytes, args.cpu_seconds, torch, stream, args.config)
+            except Exception as exc:  # noqa: BLE001 -- the baseline beside the figure must never cost the figure
+                log(f"CPU baseline failed: {exc!r}")
+                result["cpu_baseline"] = {"error": repr(exc), "kind": "port"}
             if args.config != "cfg1" and not args.headline_only and not args.no_cpu_cfg1:
                 # BASELINE.json configs[0] IS the CPU reference path (2^16 keys): its figure from the same port, on the same cores
                 try:
@@ -1719,10 +1723,17 @@ def summarize_cpu_runs(runs, full_bytes, sample_text):
     }
 
 
-def cpu_workdir():
+def cpu_workdir(need_bytes: int = 0):
+    """a directory for the files the CPU baseline's child processes read: memory-backed where that has the room, else /tmp"""
+    import shutil
     import tempfile
 
-    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+    base = "/tmp"
+    try:
+        if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) and shutil.disk_usage("/dev/shm").free > need_bytes + (256 << 20):
+            base = "/dev/shm"
+    except OSError:
+        pass
     return tempfile.mkdtemp(prefix="cpir_cpu_", dir=base)
 
 
@@ -1734,7 +1745,7 @@ def cpu_baseline(server, q_pool, r_step, N, C, b, full_bytes, budget_s, torch, s
     import shutil
 
     nq = min(q_pool.shape[0], 32)
-    work = cpu_workdir()
+    work = cpu_workdir(full_bytes + 4 * N * nq)
     try:
         np.save(os.path.join(work, "dtc.npy"), server.export_compressed())  # the reference's own C x ceil(N / cf) words, exported from the device image
         np.save(os.path.join(work, "q.npy"), q_pool[:nq].cpu().numpy().view(np.uint32))
