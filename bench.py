@@ -98,7 +98,7 @@ def main() -> int:
                     help="do not measure roofline.traffic in this run (two child runs of the timed loop under rocprofv3 --pmc); quote the committed pass instead")
     ap.add_argument("--headline-only", action="store_true", help=argparse.SUPPRESS)  # internal: the timed loop and nothing else (the counter passes' child)
     ap.add_argument("--no-host-path", action="store_true", help="skip timing Server.respond on host buffers (PCIe inclusive)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline (half of it per thread placement, three samples each)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline (a third of it per thread placement, three samples each)")
     ap.add_argument("--cpu-baseline-child", default="", help=argparse.SUPPRESS)  # internal: the CPU baseline's own process (no torch, no GPU)
     ap.add_argument("--tune", default="", help="comma list key=value for cpir_tuning_set, e.g. respond.interleave_passes=0")
     ap.add_argument("--sweep", action="store_true", help="time every respond kernel variant (stderr table) before the run")
@@ -1669,13 +1669,16 @@ def cpu_baseline_child(args) -> int:
 
 
 def run_cpu_children(workdir, budget_s):
-    """the CPU baseline twice, each in a child process: threads bound (OMP_PROC_BIND=close OMP_PLACES=cores: comparable from box to box where
-    the box lets the process have those cores) and unbound (the scheduler places them: what a quota'd container on a shared host often does
-    better with); returns {"bound": {...}, "unbound": {...}} (an entry may hold "error")"""
+    """the CPU baseline three times, each in a child process: threads bound side by side (OMP_PROC_BIND=close OMP_PLACES=cores: comparable from
+    box to box where the box lets the process have those cores -- but 16 threads side by side share two core complexes' links to memory),
+    bound far apart (OMP_PROC_BIND=spread: one thread per core complex where there are enough, what a bandwidth-bound loop wants) and unbound
+    (the scheduler places them: what a quota'd container on a shared host often does best with); returns {"bound": {...}, "spread": {...},
+    "unbound": {...}} (an entry may hold "error")"""
     import subprocess
 
     out = {}
-    for name, env_extra in (("bound", {"OMP_PROC_BIND": "close", "OMP_PLACES": "cores"}), ("unbound", {"OMP_PROC_BIND": "false"})):
+    for name, env_extra in (("bound", {"OMP_PROC_BIND": "close", "OMP_PLACES": "cores"}), ("spread", {"OMP_PROC_BIND": "spread", "OMP_PLACES": "cores"}),
+                            ("unbound", {"OMP_PROC_BIND": "false"})):
         env = {k: v for k, v in os.environ.items() if k not in ("OMP_PLACES", "OMP_PROC_BIND", "OMP_NUM_THREADS", "GOMP_CPU_AFFINITY")}
         env.update(env_extra)
         env["OMP_WAIT_POLICY"] = "active"  # the child has its cores to itself while it runs (the parent waits, its device idle)
@@ -1707,9 +1710,10 @@ def summarize_cpu_runs(runs, full_bytes, sample_text):
         "cores": any_run["threads"],
         "kind": "port",
         "sample": sample_text,
-        "value_is": f"median of {len(good[best]['samples'])} samples, OpenMP threads {best} (the better median of the two placements)",
+        "value_is": f"median of {len(good[best]['samples'])} samples, OpenMP threads {best} (the best median of the three placements)",
         "min": good[best]["min"], "median": good[best]["median"], "max": good[best]["max"],
         "threads_bound": good.get("bound") or runs.get("bound"),      # OMP_PROC_BIND=close OMP_PLACES=cores
+        "threads_spread": good.get("spread") or runs.get("spread"),   # OMP_PROC_BIND=spread OMP_PLACES=cores
         "threads_unbound": good.get("unbound") or runs.get("unbound"),  # OMP_PROC_BIND=false
         "cpu_model": any_run["cpu_model"],
         "affinity_mask": any_run["affinity_mask"],
@@ -1750,10 +1754,10 @@ def cpu_baseline(server, q_pool, r_step, N, C, b, full_bytes, budget_s, torch, s
         np.save(os.path.join(work, "dtc.npy"), server.export_compressed())  # the reference's own C x ceil(N / cf) words, exported from the device image
         np.save(os.path.join(work, "q.npy"), q_pool[:nq].cpu().numpy().view(np.uint32))
         with open(os.path.join(work, "meta.json"), "w") as fh:
-            json.dump({"N": N, "b": b, "queries": nq, "seconds": budget_s / 2, "samples": 3}, fh)
+            json.dump({"N": N, "b": b, "queries": nq, "seconds": budget_s / 3, "samples": 3}, fh)
         runs = run_cpu_children(work, budget_s)
         out = summarize_cpu_runs(runs, full_bytes, f"full-size queries of {config} back to back on the same packed DB ({full_bytes / 1e9:.3f} GB/query) for "
-                                 f"{budget_s / 2:.0f} s per thread placement, OpenMP over the C outputs like the reference's rayon loop, rows first-touched by "
+                                 f"{budget_s / 3:.0f} s per thread placement, OpenMP over the C outputs like the reference's rayon loop, rows first-touched by "
                                  "the threads that stream them")
         if "error" in out:
             return out
@@ -1786,10 +1790,10 @@ def cpu_baseline_small(cp, device, torch, name, stream, budget_s=4.0):
     work = cpu_workdir()
     try:
         with open(os.path.join(work, "meta.json"), "w") as fh:
-            json.dump({"N": N, "C": C, "b": b, "queries": nq, "seconds": budget_s / 2, "samples": 3, "generate": True}, fh)
+            json.dump({"N": N, "C": C, "b": b, "queries": nq, "seconds": budget_s / 3, "samples": 3, "generate": True}, fh)
         runs = run_cpu_children(work, budget_s)
         out = summarize_cpu_runs(runs, full_bytes, f"full-size queries of {name} back to back ({full_bytes / 1e6:.1f} MB/query: last-level-cache sized on a "
-                                 f"server CPU) for {budget_s / 2:.0f} s per thread placement, database built by the oracle's own transpose + row_wise_compress")
+                                 f"server CPU) for {budget_s / 3:.1f} s per thread placement, database built by the oracle's own transpose + row_wise_compress")
         if "error" in out:
             return out
         wants = np.load(os.path.join(work, "responses.npy"))

@@ -148,7 +148,7 @@ def test_bench_json_contract():
     assert cpu["gpu_results_bit_exact"] is True and cpu["queries_compared"] == 32
     # comparable from box to box: several samples per thread placement, the CPU's name and what the process may run on
     assert cpu["min"] <= cpu["median"] <= cpu["max"] and cpu["value"] == cpu["median"] and isinstance(cpu["cpu_model"], str) and cpu["affinity_mask"]
-    for placement in ("threads_bound", "threads_unbound"):
+    for placement in ("threads_bound", "threads_spread", "threads_unbound"):
         assert len(cpu[placement]["samples"]) >= 3 and cpu[placement]["min"] <= cpu[placement]["median"] <= cpu[placement]["max"]
 
 
