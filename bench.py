@@ -834,6 +834,12 @@ class RespondLoop:
         torch.cuda.synchronize()
         # HIP events on the stream the respond kernels are launched on, bracketing the kernel launches of every timed step
         events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        # (torch creates the underlying HIP event at the first record(): the measuring apparatus is built BEFORE the timed region, not inside it;
+        # measured: it makes no difference to the figure -- the first region of a process runs ~2 % below the next ones either way, the device
+        # needs more than the contract's W = 5 warm-up steps to reach its steady clocks: `value_samples`)
+        for a, b in events:
+            a.record(self.stream), b.record(self.stream)
+        torch.cuda.synchronize()
         t_begin = time.perf_counter()
         for k in range(steps):
             self.run_step(events[k])
