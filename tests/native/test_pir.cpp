@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <map>
 #include <random>
+#include <thread>
 #include <unordered_map>
 
 #include "chalamet_hip.hpp"
@@ -139,6 +140,26 @@ void test_keyword_pir(size_t iterations, unsigned max_lg, uint64_t seed) {
         std::abort();
       }
       i++;
+    }
+
+    // one Arc<Server> answered from many tasks at once (chalametpir_server/examples/server.rs:45-93): the queries of four keys prepared one
+    // after the other, answered by four threads side by side -- each through a clone of its own --, decoded one after the other
+    {
+      std::vector<Bytes> keys4(all_keys.begin(), all_keys.begin() + std::min<size_t>(4, all_keys.size()));
+      std::vector<std::vector<uint8_t>> queries(keys4.size()), responses(keys4.size());
+      for (size_t i = 0; i < keys4.size();)
+        if (client.query(keys4[i], &queries[i]) == OR_OK) i++;
+      std::vector<std::thread> tasks;
+      for (size_t i = 0; i < keys4.size(); i++)
+        tasks.emplace_back([&, i, mine = server] { responses[i] = mine.respond(queries[i]).expect("Server can't respond"); });
+      for (std::thread& t : tasks) t.join();
+      for (size_t i = 0; i < keys4.size(); i++) {
+        std::vector<uint8_t> received_value;
+        if (client.process_response(keys4[i], responses[i], &received_value) != OR_OK || !(Bytes(received_value) == kv_db_as_ref.at(keys4[i]))) {
+          std::fprintf(stderr, "arity %u: concurrent task %zu got a wrong value\n", ARITY, i);
+          std::abort();
+        }
+      }
     }
 
     // what the reference's Server::respond rejects, this one rejects the same way (matrix.rs:973-1010, 329-331)

@@ -21,7 +21,7 @@ def compile_cpp(src, exe, extra=()):
     orc.lib()  # (builds oracle/_build/libchalamet_oracle.so if it is not there)
     cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), "-I" + ORACLE, src, "-o", exe,
            "-L" + LIB, "-lchalamet_hip", "-L" + os.path.join(ORACLE, "_build"), "-lchalamet_oracle", "-Wl,-rpath," + LIB,
-           "-Wl,-rpath," + os.path.join(ORACLE, "_build"), "-Wl,-rpath-link,/opt/rocm/lib", "-fopenmp", *extra]
+           "-Wl,-rpath," + os.path.join(ORACLE, "_build"), "-Wl,-rpath-link,/opt/rocm/lib", "-fopenmp", "-pthread", *extra]
     b = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert b.returncode == 0, b.stderr[-4000:]
 
