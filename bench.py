@@ -317,6 +317,20 @@ def main() -> int:
             "note": "the same shards and steps with every pass its own stream of the shard (slice order, nt loads): comparable with the N = 1 "
                     "headline; `value` is the product's dispatch (pass_order above), which at this shard size shares database bytes on die",
         }
+    if world == 1 and not args.headline_only and args.shard_of <= 1 and not args.no_multirank_check:
+        # the N = 1 line's own proof (as every other config of the line has one): unit / dense / all-ones queries against exact 64-bit sums of
+        # the regenerated rows, both dispatch modes -- BEHIND the timed regions (a check in front of them would also warm the device up:
+        # `value_samples` shows that the first region of a process runs ~2 % below the next ones; the contract's W warm-up steps stay all there is)
+        drain()
+        try:
+            chk1 = multirank_check(torch, dist, device, sharded, N, C, b, mask, lo, hi, 0, 1, full_layout, stream)
+            result["headline_check"] = {"responses_bit_exact_vs_64bit_sums": chk1.get("multirank_bit_exact"), "unit_queries": chk1.get("unit_queries"),
+                                        "dense_and_all_ones_queries": chk1.get("dense_and_all_ones_queries"), "dispatch_modes": chk1.get("dispatch_modes"),
+                                        "seconds": chk1.get("seconds")}
+        except Exception as exc:  # noqa: BLE001 -- a check that could not run is reported as such
+            log(f"headline check failed to run: {exc!r}")
+            result["headline_check"] = {"responses_bit_exact_vs_64bit_sums": None, "error": repr(exc)}
+        cp.tuning_set("respond.batch_fusion", 0)
     if world > 1 and not args.no_multirank_check:
         drain()
         try:

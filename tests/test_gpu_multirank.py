@@ -141,6 +141,7 @@ def test_bench_json_contract():
     assert roof["moved_GBps"] == roof["achieved"] and roof["read_ceiling_GBps"] > 1000 and roof["frac_vs_read_ceiling"] is None
     assert d["ranks"] == 1 and d["backend"] is None
     assert abs(d["value"] - d["config"]["queries_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
+    assert d["headline_check"]["responses_bit_exact_vs_64bit_sums"] is True and d["headline_check"]["unit_queries"] >= 2
     vs = d["value_samples"]  # the contract's region + the same K steps twice more: how much one sample moves
     assert vs["queries_per_sec"][0] == d["value"] and len(vs["queries_per_sec"]) == 3 and vs["min"] <= vs["median"] <= vs["max"]
     cpu = d["cpu_baseline"]
