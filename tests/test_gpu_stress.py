@@ -215,3 +215,55 @@ def test_scratch_blocks_are_reused_only_behind_their_events_and_refused_under_ca
     device.mat_x_mat(Ad, Dd, outs[0], rows, N, C, rhs_max_bits=16, stream=stream)  # (and the stream works as before)
     stream.synchronize()
     assert np.array_equal(outs[0].cpu().numpy().view(np.uint32), want)
+
+
+def test_plain_respond_entry_points_can_be_captured_into_a_graph_and_replayed(orc, device):
+    """the device-pointer respond entry points on the planar packing enqueue a memset and kernels, nothing else -- so a caller
+    with a launch-bound loop may capture them into a hipGraph.  One query and a fused batch of 5 are captured once and replayed on fresh query
+    contents three times: every replay equals the oracle (the first, eager call has done the one-time attribute set-up)."""
+    import ctypes
+
+    import torch
+
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(77)
+    N, C, b = 3 * 1536 + 77, 33, 9
+    D = random_db_matrix(rng, N, C, b)
+    srv, _ = cp.Server.setup_from_matrix(bytes(range(32)), D, b, device=device)
+    dtc = orc.row_wise_compress(orc.transpose(D), b)
+    stream = torch.cuda.Stream()
+    nb = 5
+    q_dev = torch.zeros((nb, N), dtype=torch.int32, device="cuda")
+    r1 = torch.zeros(C, dtype=torch.int32, device="cuda")
+    rb = torch.zeros((nb, C), dtype=torch.int32, device="cuda")
+    srv.respond_device(q_dev[0], r1, stream=stream)          # eager once: module load, function attributes
+    srv.respond_batch_device(q_dev, nb, rb, stream=stream)
+    stream.synchronize()
+    hip = ctypes.CDLL("libamdhip64.so")
+    s_ptr = ctypes.c_void_p(stream.cuda_stream)
+    assert hip.hipStreamBeginCapture(s_ptr, 2) == 0  # hipStreamCaptureModeRelaxed
+    try:
+        srv.respond_device(q_dev[0], r1, stream=stream)
+        srv.respond_batch_device(q_dev, nb, rb, stream=stream)
+    finally:
+        graph = ctypes.c_void_p()
+        assert hip.hipStreamEndCapture(s_ptr, ctypes.byref(graph)) == 0
+    assert graph.value
+    inst = ctypes.c_void_p()
+    assert hip.hipGraphInstantiate(ctypes.byref(inst), graph, None, None, 0) == 0
+    try:
+        for rep in range(3):
+            qs = np.stack([random_query(rng, N) for _ in range(nb)])
+            q_dev.copy_(torch.from_numpy(qs.view(np.int32)))
+            r1.fill_(-1), rb.fill_(-1)
+            torch.cuda.synchronize()
+            assert hip.hipGraphLaunch(inst, s_ptr) == 0
+            stream.synchronize()
+            want = [orc.row_vector_x_compressed_transposed_matrix(qs[i], dtc, N, b)[0] for i in range(nb)]
+            assert np.array_equal(r1.cpu().numpy().view(np.uint32), want[0]), rep
+            assert np.array_equal(rb.cpu().numpy().view(np.uint32), np.stack(want)), rep
+    finally:
+        hip.hipGraphExecDestroy(inst)
+        hip.hipGraphDestroy(graph)
+        srv.close()
