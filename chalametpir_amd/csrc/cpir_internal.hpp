@@ -269,6 +269,12 @@ void scratch_drain(int ordinal);
 
 // M[r][c] = 0 for r < rows, c < cols (leading dimension ldm) as a KERNEL on `stream` (one launch whatever ldm is)
 int launch_zero_matrix(uint32_t* M, uint64_t ldm, uint64_t rows, uint64_t cols, hipStream_t stream);
+// `words` u32 zeroed by that kernel.  Everything a kernel of this library ACCUMULATES into (responses, column / row sums) is zeroed this
+// way in front of it, never by hipMemsetAsync: captured into a hipGraph, a memset node in front of the respond kernel was not ordered before
+// it on the second and later launches of the first graph a process instantiated (ROCm 7.2, gfx950; scripts/probes/graph_capture_dbg.py:
+// the responses lacked the contributions of the blocks that ran before the late memset) -- two kernel nodes are ordered every time
+// (tests/test_gpu_stress.py::test_plain_respond_entry_points_can_be_captured_into_a_graph_and_replayed).
+inline int zero_words(uint32_t* p, uint64_t words, hipStream_t stream) { return words ? launch_zero_matrix(p, words, 1, words, stream) : CPIR_OK; }
 int launch_rhs_split(const Device* dev, const uint32_t* D, uint64_t ldd, uint64_t inner, uint64_t cols, void* workspace, hipStream_t stream);
 int launch_mat_x_mat_mfma(const Device* dev, const uint32_t* A, uint64_t lda, const void* workspace, uint64_t inner, uint64_t cols,
                           uint32_t* M, uint64_t ldm, uint64_t rows, uint64_t ws_max_rows, int accumulate, hipStream_t stream);

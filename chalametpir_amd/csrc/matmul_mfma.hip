@@ -926,7 +926,7 @@ int launch_rhs_split(const Device* dev, const uint32_t* D, uint64_t ldd, uint64_
   sa.ks_total = (uint32_t)((inner + kBK - 1) / kBK);
   sa.planes = reinterpret_cast<uint4*>(workspace);
   sa.colsum = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(workspace) + rhs_planes_bytes(inner, cols));
-  CPIR_HIP_TRY(hipMemsetAsync(sa.colsum, 0, 4 * rhs_colsum_words(cols), stream));
+  CPIR_TRY(zero_words(sa.colsum, rhs_colsum_words(cols), stream));
   const uint64_t blocks = (uint64_t)((sa.ks_total + 7) / 8) * sa.stripe_groups;
   if (blocks > 0x7fffffffull) return CPIR_ERR_INVALID_ARGUMENT;
   const bool vec = (ldd % 4 == 0) && (reinterpret_cast<uintptr_t>(D) % 16 == 0);
@@ -1013,7 +1013,7 @@ static int launch_product(const Device* dev, MfmaArgs& a, const uint32_t* colsum
   // the hand-pipelined kernel addresses a row tile of A with 32-bit byte offsets
   const bool pipe = mfma_pipe_addressable(lda, inner);
   if (!pipe && a.lo_tiles) return CPIR_ERR_INVALID_ARGUMENT;  // only the pipelined kernel reads the planar image (callers ask mfma_planar_rhs_applicable first)
-  CPIR_HIP_TRY(hipMemsetAsync(a.rowsum, 0, 4 * round_up((uint32_t)rows, kBM), stream));
+  CPIR_TRY(zero_words(a.rowsum, round_up((uint32_t)rows, kBM), stream));
   if (!accumulate) CPIR_TRY(launch_zero_matrix(M, ldm, rows, cols, stream));
 #ifdef CPIR_DIAG
   if (pipe && (a.ablate & 16u)) {  // the 32x32x32 emulation (see MfmaAcc)

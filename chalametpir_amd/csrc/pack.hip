@@ -745,7 +745,7 @@ int launch_planar_pack(const uint32_t* src, uint64_t ld, bool from_ref, const cp
   const uint32_t col_tiles = L.rows_padded / 16;
   if (!planar_offered(L.mat_elem_bit_len) || ks_total > 0x7fffffffull || col_tiles > 65535u) return CPIR_ERR_INVALID_ARGUMENT;
   uint32_t* colsum = dtc + (uint64_t)L.rows_padded * L.words_per_row_padded;
-  CPIR_HIP_TRY(hipMemsetAsync(colsum, 0, (size_t)L.rows_padded * sizeof(uint32_t), stream));
+  CPIR_TRY(zero_words(colsum, L.rows_padded, stream));
   if (from_ref && (hi_plane || keep)) return CPIR_ERR_INVALID_ARGUMENT;
   if (from_ref) {
     const dim3 grid((unsigned)ks_total, col_tiles);

@@ -595,7 +595,7 @@ int launch_respond(const Device* dev, const uint32_t* dtc, const cpir_dtc_layout
     if (grid == 0) grid = 1, a.nx = 1;
   }
 
-  CPIR_HIP_TRY(hipMemsetAsync(r, 0, (size_t)batch * passes * L.num_cols * sizeof(uint32_t), stream));
+  CPIR_TRY(zero_words(r, (uint64_t)batch * passes * L.num_cols, stream));
   hipLaunchKernelGGL(k.fn, dim3((unsigned)grid), dim3(kThreads), 0, stream, a);
   CPIR_HIP_TRY(hipGetLastError());
   return CPIR_OK;

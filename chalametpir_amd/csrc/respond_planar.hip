@@ -1125,7 +1125,7 @@ int launch_respond_planar_ks(const Device* dev, const uint32_t* dtc, const cpir_
   const uint32_t nq = batch * passes;
   const bool first = (step_lo == 0);
   a.colsum = first ? dtc + (uint64_t)L.rows_padded * L.words_per_row_padded : nullptr;
-  if (first && !r_prezeroed) CPIR_HIP_TRY(hipMemsetAsync(r, 0, (size_t)nq * L.num_cols * sizeof(uint32_t), stream));
+  if (first && !r_prezeroed) CPIR_TRY(zero_words(r, (uint64_t)nq * L.num_cols, stream));
   for (uint32_t w = 0; w < windows; w++) {
     a.tg_lo = w * tg_per_window;
     if (a.tg_lo >= a.tile_groups) break;
@@ -1221,7 +1221,7 @@ int launch_respond_planar_wide(const Device* dev, const uint32_t* dtc, const cpi
   if (!lds_raised[hb][nt ? 1 : 0][keep ? 1 : 0].exchange(true, std::memory_order_relaxed)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLdsBudget) != hipSuccess) (void)hipGetLastError();
   }
-  CPIR_HIP_TRY(hipMemsetAsync(r, 0, (size_t)batch * passes * L.num_cols * sizeof(uint32_t), stream));
+  CPIR_TRY(zero_words(r, (uint64_t)batch * passes * L.num_cols, stream));
   for (uint32_t w = 0; w < windows; w++) {
     a.tg_lo = w * tg_per_window;
     if (a.tg_lo >= a.tile_groups) break;
