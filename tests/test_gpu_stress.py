@@ -267,3 +267,52 @@ def test_plain_respond_entry_points_can_be_captured_into_a_graph_and_replayed(or
         hip.hipGraphExecDestroy(inst)
         hip.hipGraphDestroy(graph)
         srv.close()
+
+
+def test_pack_and_respond_device_ops_replayed_from_a_graph_on_fresh_matrices(orc, device):
+    """the layer-1 device ops on caller-owned memory (what replaces gpu_utils::mat_transpose + the respond the reference lacks): transpose +
+    pack of D followed by a respond on the freshly packed image, captured ONCE and replayed after the host has rewritten D and q -- the pack
+    pass's column sums and the response are zeroed by kernels of the library, so every replay starts clean"""
+    import ctypes
+
+    import torch
+
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(78)
+    N, C, b = 2 * 1536 + 5, 21, 10
+    L = cp.dtc_layout_for(N, C, b, packing=2)
+    stream = torch.cuda.Stream()
+    D_dev = torch.zeros((N, C), dtype=torch.int32, device="cuda")
+    q_dev = torch.zeros(N, dtype=torch.int32, device="cuda")
+    dtc = torch.zeros(int(L.total_words) + int(L.rows_padded) + 64, dtype=torch.int32, device="cuda")
+    r = torch.zeros(C, dtype=torch.int32, device="cuda")
+    device.transpose_compress(D_dev, L, dtc, stream=stream)  # eager once
+    device.respond(dtc, L, q_dev, r, stream=stream)
+    stream.synchronize()
+    hip = ctypes.CDLL("libamdhip64.so")
+    s_ptr = ctypes.c_void_p(stream.cuda_stream)
+    assert hip.hipStreamBeginCapture(s_ptr, 2) == 0
+    try:
+        device.transpose_compress(D_dev, L, dtc, stream=stream)
+        device.respond(dtc, L, q_dev, r, stream=stream)
+    finally:
+        graph = ctypes.c_void_p()
+        assert hip.hipStreamEndCapture(s_ptr, ctypes.byref(graph)) == 0
+    inst = ctypes.c_void_p()
+    assert graph.value and hip.hipGraphInstantiate(ctypes.byref(inst), graph, None, None, 0) == 0
+    try:
+        for rep in range(4):
+            D = random_db_matrix(rng, N, C, b)
+            q = random_query(rng, N)
+            D_dev.copy_(torch.from_numpy(D.view(np.int32)))
+            q_dev.copy_(torch.from_numpy(q.view(np.int32)))
+            r.fill_(-1)
+            torch.cuda.synchronize()
+            assert hip.hipGraphLaunch(inst, s_ptr) == 0
+            stream.synchronize()
+            want = orc.row_vector_x_compressed_transposed_matrix(q, orc.row_wise_compress(orc.transpose(D), b), N, b)[0]
+            assert np.array_equal(r.cpu().numpy().view(np.uint32), want), rep
+    finally:
+        hip.hipGraphExecDestroy(inst)
+        hip.hipGraphDestroy(graph)
