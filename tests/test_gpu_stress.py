@@ -227,10 +227,29 @@ def test_plain_respond_entry_points_can_be_captured_into_a_graph_and_replayed(or
 
     import chalametpir_amd as cp
 
+    _capture_and_replay(orc, device, holes=False)
+
+
+def test_respond_on_a_compacted_server_can_be_captured_too(orc, device):
+    """... and so can a server that keeps only the slots that hold something, where the wide kernel applies the slot map itself (no scratch,
+    no gather pass in front): a fifth of the rows of D zero, the same capture and replays"""
+    _capture_and_replay(orc, device, holes=True)
+
+
+def _capture_and_replay(orc, device, holes):
+    import ctypes
+
+    import torch
+
+    import chalametpir_amd as cp
+
     rng = np.random.default_rng(77)
     N, C, b = 3 * 1536 + 77, 33, 9
     D = random_db_matrix(rng, N, C, b)
+    if holes:
+        D[rng.random(N) < 0.2] = 0
     srv, _ = cp.Server.setup_from_matrix(bytes(range(32)), D, b, device=device)
+    assert (srv.slots_served()[0] < N) == holes
     dtc = orc.row_wise_compress(orc.transpose(D), b)
     stream = torch.cuda.Stream()
     nb = 5
