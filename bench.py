@@ -440,7 +440,7 @@ def main() -> int:
         result["lone_query_launch"] = {
             "us_per_query": round(lone_us, 2),
             "queries_per_sec": round(1e6 / lone_us, 1),
-            "note": "one query per launch, launches back to back on one stream (memset of r + one kernel each; on the planar packing the "
+            "note": "one query per launch, launches back to back on one stream (r zeroed by a small kernel + one respond kernel each; on the planar packing the "
                     "wide-pass kernel with one row set, which adds the correction terms itself)",
         }
     # also row f3: the same independent passes (one query each, no fusion), but walked in the interleaved order so that concurrent
