@@ -331,3 +331,34 @@ def test_release_library_has_no_wrong_answer_switches(native):
         src = re.sub(r"#ifdef CPIR_DIAG.*?#endif", "", src, flags=re.S)  # (the diagnosis build's own)
         for var in re.findall(r'getenv\("([A-Z_0-9]+)"\)', src):
             assert var in allowed, (name, var)
+
+
+def test_product_encoder_fuzz_against_the_oracle(native, orc):
+    """Matrix::from_kv_database on shapes the reference's own tests do not draw (utils.rs:22-45 draws keys of 16-32 and values of 1-512 bytes):
+    keys of 0..79 bytes, values of 0..299 bytes, 1..3000 pairs, every bit length, both arities -- same D, same 68 filter bytes, the same
+    refusals as the oracle; and the reference's own quirk holds: an EMPTY value encodes, but its row is RowNotDecodable (the boundary mark
+    must lie beyond byte 32: serialization.rs:169), in the product's matrix exactly as in the oracle's"""
+    import chalametpir_amd as cp
+
+    rng = np.random.default_rng(4242)
+    empty_values_seen = 0
+    for case in range(80):
+        arity = int(rng.integers(3, 5))
+        n = int([rng.integers(1, 6), rng.integers(1, 200), rng.integers(200, 3000)][int(rng.integers(0, 3))])
+        keys = list({rng.bytes(int(rng.integers(0, 80))): 0 for _ in range(n)})
+        vals = [rng.bytes(int(rng.integers(0, 300))) for _ in keys]
+        b = int(rng.integers(4, 15))
+        fseeds = rng.bytes(3200)
+        D1, f1 = cp.encode_kv_database(dict(zip(keys, vals)), arity, b, fseeds)
+        D2, f2, _ = orc.from_kv_database(arity, keys, vals, b, fseeds)
+        assert np.array_equal(D1, D2) and f1 == f2.to_bytes(), (case, n, b, arity)
+        filt = orc.Filter.from_bytes(f1)
+        for k, v in list(zip(keys, vals))[:6]:
+            if len(v) == 0:
+                empty_values_seen += 1
+                with pytest.raises(Exception) as e:
+                    orc.recover_value(D1, filt, k)
+                assert "11" in str(e.value)  # RowNotDecodable (error.rs:37)
+            else:
+                assert orc.recover_value(D1, filt, k) == v, (case, len(k), len(v))
+    assert empty_values_seen > 0
